@@ -1,0 +1,385 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by running the UNMODIFIED
+reference (/root/reference) on CPU in the build container.
+
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 python /root/repo/tests/golden/make_goldens.py
+
+The reference imports third-party modules that are absent here (torchdiffeq,
+torchvision, diffusers, timm, ...).  None of them is touched by
+`training_losses` / `train_step` with learn_align=False, so they are replaced
+by name-only stub modules.  The single exception is
+`timm.models.vision_transformer.{Attention,Mlp,PatchEmbed}`, whose arithmetic
+DiT needs: it is served by oracle/timm_restatement.py (parity unpinned at that
+boundary; everything the reference itself owns in DiT is pinned by these files).
+
+Only data is written: inputs, seeds, weights of tiny models, expected outputs.
+The reference's source never enters the repository.  Fixtures are loaded in
+tests with torch.load(weights_only=True) / numpy / json.
+"""
+import json
+import os
+import sys
+import types
+import warnings
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+warnings.filterwarnings("ignore")
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def install_stubs():
+    sys.path.insert(0, REPO)
+    from oracle import timm_restatement as tr
+    _stub("torchdiffeq", odeint=None)
+    _stub("torchvision")
+    _stub("torchvision.utils", make_grid=None, save_image=None)
+    _stub("torchvision.transforms")
+    _stub("diffusers")
+    _stub("diffusers.models", AutoencoderKL=None)
+    _stub("timm")
+    _stub("timm.data", IMAGENET_DEFAULT_MEAN=None, IMAGENET_DEFAULT_STD=None)
+    _stub("timm.models")
+    _stub("timm.models.vision_transformer", Attention=tr.Attention, Mlp=tr.Mlp, PatchEmbed=tr.PatchEmbed)
+    _stub("tools.encoders", load_encoders=None)
+    sys.path.insert(0, REF)
+
+
+def base_args(**kw):
+    a = dict(weight_type="lambda", gamma=0.0, learn_sigma=False, p2_gamma=1, p2_k=1, time_dist=["uniform", -0.8, 0.8],
+             learn_align=False, align_type="mse", amp=False, dataset="CIFAR-10", class_cond=False, parallel=False,
+             grad_accumulation=1, in_chans=3, latent_scale=0.18215, grad_clip=None, ema_decay=0.9999,
+             enc_type="dinov2-vit-b", image_size=32, path_type="cosine", sampler_type="ode", lr=1e-4, final_lr=0.0,
+             warmup_steps=0, total_steps=1000, cosine_decay=False)
+    a.update(kw)
+    return SimpleNamespace(**a)
+
+
+class Pbar:
+    def update(self, n):
+        pass
+
+    def set_postfix(self, **kw):
+        pass
+
+
+def perturb_(model, seed, std=0.05):
+    """Make zero-initialised layers non-trivial, deterministically."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.requires_grad:
+                p.add_(torch.randn(p.shape, generator=g) * std)
+
+
+def tolist(t):
+    return t.detach().double().cpu().numpy().tolist()
+
+
+def summarize(tensors):
+    """Per-tensor fingerprint: [sum, abs-sum, l2] in float64 plus a 64-element strided sample.
+    Full weights are NOT stored: tests rebuild the model from the same seed with the oracle's
+    constructor (which mirrors the reference's RNG order) and must reproduce these fingerprints."""
+    out = {}
+    for k, v in tensors.items():
+        f = v.detach().double().flatten()
+        stride = max(1, f.numel() // 64)
+        out[k] = {"stats": torch.stack([f.sum(), f.abs().sum(), f.norm()]), "sample": f[::stride][:64].clone()}
+    return out
+
+
+def gen_tables(gd):
+    out = {}
+    for name in ("linear", "cosine", "linear_logsnr"):
+        betas = gd.get_named_beta_schedule(name, 1000)
+        d = gd.GaussianDiffusion(args=base_args(), betas=betas, model_mean_type=gd.ModelMeanType.EPSILON,
+                                 model_var_type=gd.ModelVarType.FIXED_LARGE, loss_type=gd.LossType.MSE,
+                                 rescale_timesteps=True, device="cpu")
+        for k in ("betas", "alphas_cumprod", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod",
+                  "log_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
+                  "posterior_variance", "posterior_log_variance_clipped", "posterior_mean_coef1",
+                  "posterior_mean_coef2"):
+            out[f"{name}.{k}"] = getattr(d, k)
+    out["linear250.betas"] = gd.get_named_beta_schedule("linear", 250)
+    out["cosine50.betas"] = gd.get_named_beta_schedule("cosine", 50)
+    np.savez_compressed(os.path.join(HERE, "diffusion_tables.npz"), **out)
+
+
+WEIGHT_TYPES = ["constant", "lambda", "min_snr_5", "min_snr_1.5", "max_snr_2", "debias", "p2", "min_debias",
+                "max_debias", "trunc_snr", "snr", "inv_snr", "bogus"]
+
+
+def gen_loss_weights(gd):
+    ts = [0, 1, 10, 250, 500, 750, 998, 999]
+    rec = {"t": ts, "diffusion": {}, "flow": {}, "edge": {}}
+    betas = gd.get_named_beta_schedule("cosine", 1000)
+    d = gd.GaussianDiffusion(args=base_args(), betas=betas, model_mean_type=gd.ModelMeanType.EPSILON,
+                             model_var_type=gd.ModelVarType.FIXED_LARGE, loss_type=gd.LossType.MSE,
+                             rescale_timesteps=True, device="cpu")
+    t = torch.tensor(ts)
+    for mt in ("EPSILON", "START_X", "VELOCITY", "VECTOR"):
+        for wt in WEIGHT_TYPES:
+            alpha = gd._extract_into_tensor(d.sqrt_alphas_cumprod, t, t.shape).clone()
+            sigma = gd._extract_into_tensor(d.sqrt_one_minus_alphas_cumprod, t, t.shape).clone()
+            try:
+                w = gd.compute_mse_loss_weight(gd.ModelMeanType[mt], wt, t, alpha, sigma, 1, 1)
+                rec["diffusion"][f"{mt}/{wt}"] = {"w": tolist(w), "dtype": str(w.dtype)}
+            except ValueError as e:
+                rec["diffusion"][f"{mt}/{wt}"] = {"error": "ValueError"}
+    # continuous-time (flow) coefficients incl. the snr==0 edge (t=1 on the linear path => alpha=0)
+    tf = torch.tensor([0.0, 0.001, 0.25, 0.5, 0.9, 1.0])
+    rec["flow_t"] = tolist(tf)
+    for path in ("linear", "cosine", "linear_logsnr"):
+        fm = gd.FlowMatching(args=base_args(path_type=path), model_mean_type=gd.ModelMeanType.VECTOR)
+        a, s, da, ds = fm.interpolant(tf)
+        rec["flow"][f"{path}/interpolant"] = {"a": tolist(a), "s": tolist(s), "da": tolist(da), "ds": tolist(ds)}
+        for mt in ("EPSILON", "START_X", "VELOCITY", "VECTOR"):
+            for wt in ("constant", "lambda", "min_snr_5"):
+                a, s, _, _ = fm.interpolant(tf)
+                try:
+                    w = gd.compute_mse_loss_weight(gd.ModelMeanType[mt], wt, tf, a.clone(), s.clone(), 1, 1)
+                    rec["flow"][f"{path}/{mt}/{wt}"] = {"w": tolist(w), "dtype": str(w.dtype)}
+                except ValueError:
+                    rec["flow"][f"{path}/{mt}/{wt}"] = {"error": "ValueError"}
+    # aliasing edge: sigma patched in place where snr==0
+    alpha = torch.tensor([0.0, 0.5]); sigma = torch.tensor([1.0, 0.8])
+    w = gd.compute_mse_loss_weight(gd.ModelMeanType.EPSILON, "lambda", torch.tensor([0, 1]), alpha, sigma)
+    rec["edge"]["alias"] = {"w": tolist(w), "sigma_after": tolist(sigma)}
+    json.dump(rec, open(os.path.join(HERE, "loss_weight.json"), "w"))
+
+
+def fake_model(x, t, **kw):
+    """A deterministic stand-in denoiser so the objective can be pinned without a network."""
+    return 0.5 * x + 1e-3 * t.view(-1, 1, 1, 1).float() + (0.01 * kw["y"].view(-1, 1, 1, 1).float() if "y" in kw else 0)
+
+
+def gen_objective(gd):
+    g = torch.Generator().manual_seed(7)
+    x0 = torch.rand(4, 3, 8, 8, generator=g) * 2 - 1
+    noise = torch.randn(4, 3, 8, 8, generator=g)
+    t = torch.tensor([0, 17, 500, 999])
+    y = torch.tensor([1, 2, 3, 4])
+    out = {"x0": x0, "noise": noise, "t": t, "y": y}
+    for sched in ("cosine", "linear"):
+        betas = gd.get_named_beta_schedule(sched, 1000)
+        for mt in ("EPSILON", "START_X", "VELOCITY"):
+            for wt in ("lambda", "constant", "min_snr_5"):
+                d = gd.GaussianDiffusion(args=base_args(weight_type=wt), betas=betas,
+                                         model_mean_type=gd.ModelMeanType[mt],
+                                         model_var_type=gd.ModelVarType.FIXED_LARGE, loss_type=gd.LossType.MSE,
+                                         rescale_timesteps=True, device="cpu")
+                terms = d.training_losses(fake_model, x0, None, t=t, model_kwargs={"y": y}, noise=noise)
+                out[f"{sched}/{mt}/{wt}/mse"] = terms["mse"].float()
+                out[f"{sched}/{mt}/{wt}/loss"] = terms["loss"].float()
+                if wt == "lambda":
+                    out[f"{sched}/{mt}/x_t"] = d.q_sample(x0, t, noise)
+                    out[f"{sched}/{mt}/target"] = d.compute_target(x0, noise, t).clone()
+    # RNG order: noise is drawn BEFORE t
+    d = gd.GaussianDiffusion(args=base_args(), betas=gd.get_named_beta_schedule("cosine", 1000),
+                             model_mean_type=gd.ModelMeanType.EPSILON, model_var_type=gd.ModelVarType.FIXED_LARGE,
+                             loss_type=gd.LossType.MSE, rescale_timesteps=True, device="cpu")
+    torch.manual_seed(42)
+    out["seed42/mse"] = d.training_losses(fake_model, x0, None)["mse"]
+    # flow matching
+    tf = torch.tensor([0.03, 0.4, 0.77, 0.999])
+    for path in ("linear", "cosine", "linear_logsnr"):
+        for mt in ("VECTOR", "EPSILON", "VELOCITY", "START_X"):
+            fm = gd.FlowMatching(args=base_args(path_type=path), model_mean_type=gd.ModelMeanType[mt])
+            terms = fm.training_losses(fake_model, x0, None, t=tf, model_kwargs={"y": y}, noise=noise)
+            out[f"flow/{path}/{mt}/mse"] = terms["mse"].float()
+    out["flow/t"] = tf
+    fm = gd.FlowMatching(args=base_args(path_type="linear", time_dist=["lognorm", -0.8, 0.8]),
+                         model_mean_type=gd.ModelMeanType.VECTOR)
+    torch.manual_seed(5)
+    out["flow/lognorm_t"] = fm.sample_t(x0)
+    torch.save(out, os.path.join(HERE, "objective.pt"))
+
+
+def fwd_bwd(model, x, t, y, gout):
+    x = x.clone().requires_grad_(True)
+    model.zero_grad()
+    raw = model(x, t, y=y) if y is not None else model(x, t)
+    out = raw[0] if isinstance(raw, tuple) else raw
+    (out * gout).sum().backward()
+    grads = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    return out.detach(), x.grad.clone(), grads
+
+
+def gen_dit_tiny():
+    from models.dit import DiT
+    rec = {}
+    for tag, kw in {"p2": dict(image_size=8, patch_size=2, hidden_size=64, depth=2, num_heads=2),
+                    "p4": dict(image_size=16, patch_size=4, hidden_size=128, depth=1, num_heads=2)}.items():
+        torch.manual_seed(11)
+        m = DiT(in_channels=4, class_dropout_prob=0.0, num_classes=10, learn_sigma=False, **kw)
+        rec[f"{tag}/init_sd"] = summarize(m.state_dict())
+        m.train()
+        g = torch.Generator().manual_seed(3)
+        x = torch.randn(3, 4, kw["image_size"], kw["image_size"], generator=g)
+        t = torch.tensor([0.0, 421.0, 999.0])
+        y = torch.tensor([0, 5, 9])
+        out0, _ = m(x, t, y)
+        rec[f"{tag}/out_at_init_absmax"] = out0.abs().max()
+        perturb_(m, 99)
+        gout = torch.randn(out0.shape, generator=g)
+        out, gx, grads = fwd_bwd(m, x, t, y, gout)
+        rec.update({f"{tag}/kw": kw, f"{tag}/sd": summarize(m.state_dict()),
+                    f"{tag}/x": x, f"{tag}/t": t, f"{tag}/y": y, f"{tag}/gout": gout, f"{tag}/out": out,
+                    f"{tag}/gx": gx, f"{tag}/grads": summarize(grads)})
+    torch.save(rec, os.path.join(HERE, "dit_tiny.pt"))
+
+
+def gen_unet_tiny():
+    from models import unet as U
+    from tools.nn import timestep_embedding
+    rec = {}
+    g = torch.Generator().manual_seed(4)
+    rec["temb/t"] = torch.tensor([0.0, 1.0, 333.5, 999.0])
+    rec["temb/out64"] = timestep_embedding(rec["temb/t"], 64)
+    rec["temb/out33"] = timestep_embedding(rec["temb/t"], 33)
+    # full tiny models: new attention order + legacy order, class-cond + uncond
+    cfgs = {
+        "new": dict(image_size=16, in_channels=3, model_channels=32, out_channels=3, num_res_blocks=1,
+                    attention_resolutions=(2,), channel_mult=(1, 2), num_classes=10, num_heads=2,
+                    use_scale_shift_norm=True, resblock_updown=True, use_new_attention_order=True),
+        "legacy": dict(image_size=16, in_channels=3, model_channels=32, out_channels=6, num_res_blocks=1,
+                       attention_resolutions=(1, 2), channel_mult=(1, 3), num_classes=0, num_heads=1,
+                       num_head_channels=16, use_scale_shift_norm=False, resblock_updown=False,
+                       use_new_attention_order=False),
+    }
+    for tag, kw in cfgs.items():
+        torch.manual_seed(21)
+        m = U.UNetModel(**kw)
+        rec[f"{tag}/init_sd"] = summarize(m.state_dict())
+        m.train()
+        perturb_(m, 77, std=0.03)
+        x = torch.randn(2, 3, 16, 16, generator=g)
+        t = torch.tensor([12.0, 845.0])
+        y = torch.tensor([3, 7]) if kw["num_classes"] else None
+        gout = torch.randn(2, kw["out_channels"], 16, 16, generator=g)
+        out, gx, grads = fwd_bwd(m, x, t, y, gout)
+        rec.update({f"{tag}/kw": kw, f"{tag}/sd": summarize(m.state_dict()), f"{tag}/x": x,
+                    f"{tag}/t": t, f"{tag}/y": y if y is not None else torch.zeros(0), f"{tag}/gout": gout,
+                    f"{tag}/out": out, f"{tag}/gx": gx, f"{tag}/grads": summarize(grads)})
+    # factory topology check: parameter counts of the presets used by BASELINE configs
+    rec["nparams/UNet_64_uncond"] = sum(p.numel() for p in U.UNet_64(class_cond=False).parameters())
+    rec["nparams/ADM_64_c1000"] = sum(p.numel() for p in U.ADM_64(num_classes=1000, class_cond=True).parameters())
+    torch.save(rec, os.path.join(HERE, "unet_tiny.pt"))
+
+
+def synth_loader(B, C, H, n_batches, num_classes, seed=123, latent=False):
+    g = torch.Generator().manual_seed(seed)
+    batches = []
+    for _ in range(n_batches):
+        if latent:
+            x = torch.cat([torch.randn(B, C // 2, H, H, generator=g) * 4,
+                           torch.rand(B, C // 2, H, H, generator=g) * 1.45 + 0.05], dim=1)
+        else:
+            x = torch.rand(B, C, H, H, generator=g) * 2 - 1
+        y = torch.randint(0, max(num_classes, 1), (B,), generator=g)
+        batches.append((x, y))
+    return batches
+
+
+def run_trainer(make_model, args, batches, steps, betas2=(0.9, 0.95)):
+    import copy
+    import random
+    from tools import gaussian_diffusion as gd
+    from tools.trainer import Trainer
+    from tools.utils import get_lr_lambda
+    random.seed(42); np.random.seed(42); torch.manual_seed(42)
+    model = make_model()
+    ema_model = copy.deepcopy(model)
+    opt = torch.optim.AdamW(model.parameters(), lr=args.lr, betas=betas2, weight_decay=0.0, eps=1e-8)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=get_lr_lambda(args))
+    diff = gd.GaussianDiffusion(args=args, betas=gd.get_named_beta_schedule(args.path_type, 1000),
+                                model_mean_type=gd.ModelMeanType.EPSILON, model_var_type=gd.ModelVarType.FIXED_LARGE,
+                                loss_type=gd.LossType.MSE, rescale_timesteps=True, device="cpu")
+    tr = Trainer(args, torch.device("cpu"), model, ema_model, opt, sched, diff, batches, Pbar())
+    losses = [tr.train_step(s) for s in range(1, steps + 1)]
+    psum = float(sum(p.double().abs().sum() for p in model.parameters()))
+    esum = float(sum(v.double().abs().sum() for v in ema_model.state_dict().values()))
+    return {"losses": losses, "param_abs_sum": psum, "ema_abs_sum": esum, "lr_last": sched.get_last_lr()[0]}
+
+
+def gen_trainer():
+    from models import unet as U
+    from models.dit import DiT
+    rec = {}
+    cfg1 = lambda: U.UNetModel(32, 3, 64, 3, 2, attention_resolutions=(), channel_mult=(1, 2, 2, 2), num_heads=4,
+                               use_scale_shift_norm=True, resblock_updown=True, use_new_attention_order=True)
+    b16 = synth_loader(16, 3, 32, 4, 0)
+    rec["cfg1"] = run_trainer(cfg1, base_args(), b16, 5)
+    rec["cfg1_accum2_clip"] = run_trainer(cfg1, base_args(grad_accumulation=2, grad_clip=1.0), b16, 3)
+    rec["cfg1_warmup_cosine_minsnr"] = run_trainer(
+        cfg1, base_args(weight_type="min_snr_5", warmup_steps=2, cosine_decay=True, total_steps=10, final_lr=1e-5),
+        b16, 4)
+    tiny_dit = lambda: DiT(image_size=8, patch_size=2, in_channels=4, hidden_size=64, depth=2, num_heads=2,
+                           class_dropout_prob=0.0, num_classes=10, learn_sigma=False)
+    lat = synth_loader(8, 8, 8, 3, 10, latent=True)
+    rec["dit_tiny_latent"] = run_trainer(tiny_dit, base_args(in_chans=4, class_cond=True, dataset="Latent",
+                                                              image_size=8, lr=1e-3), lat, 6)
+    # DiT-B/4 (BASELINE config 4) at a reduced batch: seeded build, 3 steps
+    dit_b4 = lambda: DiT(image_size=32, patch_size=4, in_channels=4, hidden_size=768, depth=12, num_heads=12,
+                         class_dropout_prob=0.0, num_classes=1000, learn_sigma=False)
+    latb = synth_loader(8, 8, 32, 3, 1000, latent=True)
+    rec["dit_b4_b8"] = run_trainer(dit_b4, base_args(in_chans=4, class_cond=True, dataset="Latent", image_size=32),
+                                   latb, 3)
+    json.dump(rec, open(os.path.join(HERE, "trainer.json"), "w"), indent=1)
+
+
+def gen_misc():
+    from tools.utils import warmup_cosine_lr
+    from tools import resample as R
+    from tools.trainer import sample_from_latent, ema
+    rec = {}
+    rec["lr"] = [[s, warmup_cosine_lr(s, 5, 50, 1e-4, 1e-6, True), warmup_cosine_lr(s, 5, 50, 1e-4, 1e-6, False),
+                  warmup_cosine_lr(s, 0, 50, 1e-4, 0.0, True)] for s in range(0, 51, 3)]
+    diff = SimpleNamespace(num_timesteps=20)
+    s = R.create_named_schedule_sampler("loss-second-moment", diff)
+    rng = np.random.RandomState(0)
+    w_before = s.weights().tolist()
+    for _ in range(15):
+        ts = list(range(20))
+        s.update_with_all_losses(ts, (rng.rand(20) * (1 + np.arange(20))).tolist())
+    rec["lsm_weights_before"] = w_before
+    rec["lsm_weights_after"] = s.weights().tolist()
+    np.random.seed(3)
+    idx, w = s.sample(16, "cpu")
+    rec["lsm_sample_idx"] = idx.tolist(); rec["lsm_sample_w"] = tolist(w)
+    u = R.create_named_schedule_sampler("uniform", diff)
+    np.random.seed(3)
+    idx, w = u.sample(8, "cpu")
+    rec["uni_sample_idx"] = idx.tolist(); rec["uni_sample_w"] = tolist(w)
+    g = torch.Generator().manual_seed(9)
+    lat = torch.randn(2, 8, 4, 4, generator=g)
+    torch.manual_seed(1)
+    rec["sfl_in"] = tolist(lat); rec["sfl_out"] = tolist(sample_from_latent(lat, 0.18215))
+    json.dump(rec, open(os.path.join(HERE, "misc.json"), "w"))
+
+
+def main():
+    install_stubs()
+    torch.set_num_threads(8)
+    from tools import gaussian_diffusion as gd
+    jobs = {"tables": lambda: gen_tables(gd), "weights": lambda: gen_loss_weights(gd),
+            "objective": lambda: gen_objective(gd), "dit": gen_dit_tiny, "unet": gen_unet_tiny, "misc": gen_misc,
+            "trainer": gen_trainer}
+    for name in (sys.argv[1:] or list(jobs)):
+        jobs[name]()
+        print("wrote", name)
+
+
+if __name__ == "__main__":
+    main()
