@@ -1,0 +1,186 @@
+/* vaw_hip.h -- C ABI of libvaw_hip.so: the MI355X (gfx950) kernels underneath the
+ * variance-aware-weighted diffusion training step.
+ *
+ * The reference (LilYau350/Variance-Aware-Weight) has no FFI for this path: it is
+ * Python calling ATen/cuDNN/cuBLAS.  The drop-in boundary is therefore its Python
+ * call surface (Trainer.train_step -> GaussianDiffusion.training_losses -> model),
+ * mirrored by the `vaw_amd` package, and THIS header is what that package binds
+ * through ctypes.  Each entry point names the reference arithmetic it replaces
+ * (paths are relative to the reference repository root).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless its name ends in _host;
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *  - no allocation, no synchronisation, no hidden state: safe for stream capture;
+ *  - return value: VAW_OK or a negative vaw_status; vaw_last_error_string() gives
+ *    the message of the calling thread's last failure;
+ *  - "act dtype" is the storage type of activations: VAW_F32 (parity mode) or
+ *    VAW_BF16 (throughput mode).  Accumulation, statistics, the residual stream,
+ *    gradients of parameters and the optimizer state are always f32.
+ */
+#ifndef VAW_HIP_H
+#define VAW_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { VAW_OK = 0, VAW_ERR_INVALID = -1, VAW_ERR_LAUNCH = -2, VAW_ERR_UNSUPPORTED = -3 } vaw_status;
+typedef enum { VAW_F32 = 0, VAW_BF16 = 1 } vaw_dtype;
+typedef void* vaw_stream;
+
+int vaw_version(void);
+const char* vaw_last_error_string(void);
+
+/* ---------------------------------------------------------------------------
+ * Diffusion objective  (tools/gaussian_diffusion.py)
+ * ------------------------------------------------------------------------- */
+
+/* q_sample :234-252 with the table gather of _extract_into_tensor :1059-1072 fused in:
+ *   x_t[b,:] = tab_a[t[b]] * x0[b,:] + tab_s[t[b]] * noise[b,:]
+ * tab_a/tab_s: f32[T] = float(float64 table).  t out of [0,T) poisons the row with NaN. */
+int vaw_qsample_fwd(const float* x0, const float* noise, const int64_t* t, const float* tab_a, const float* tab_s,
+                    int num_timesteps, float* x_t, int B, int64_t per_sample, vaw_stream stream);
+
+/* out[b,:] = ca[b]*x[b,:] + cb[b]*y[b,:]  -- FlowMatching.q_sample :1277-1281 and the
+ * VELOCITY / VECTOR targets of compute_target :818-832, :1284-1300. */
+int vaw_mix_rows(const float* x, const float* y, const float* ca, const float* cb, float* out, int B,
+                 int64_t per_sample, vaw_stream stream);
+
+/* training_losses :908-913 fused: target = ca[b]*x0 + cb[b]*noise (compute_target),
+ * mse[b] = w[b] * mean_flat((target - model_out)^2)  (tools/nn.py:86-90). */
+int vaw_wmse_fwd(const float* model_out, const float* x0, const float* noise, const float* ca, const float* cb,
+                 const float* w, float* mse, int B, int64_t per_sample, vaw_stream stream);
+/* d(model_out)[b,:] = gmse[b] * w[b] * 2 * (model_out - target) / per_sample */
+int vaw_wmse_bwd(const float* model_out, const float* x0, const float* noise, const float* ca, const float* cb,
+                 const float* w, const float* gmse, float* dout, int B, int64_t per_sample, vaw_stream stream);
+
+/* ---------------------------------------------------------------------------
+ * Dense layers  (nn.Linear / Conv2d(k=p,s=p) / Conv1d(k=1) in models/dit.py, models/unet.py;
+ * cuBLAS in the reference).  One GEMM entry point, MFMA inside.
+ * ------------------------------------------------------------------------- */
+
+typedef struct {
+    const float* bias;     /* f32[N] added to every row, or NULL */
+    int act;               /* 0 none | 1 GELU(tanh) forward | 2 multiply by GELU'(aux_in) (backward) */
+    const void* aux_in;    /* act dtype [M,N] (ld = ldc): pre-activation for act==2 */
+    void* aux_out;         /* act dtype [M,N] (ld = ldc): value BEFORE act/gate/residual is stored here, or NULL */
+    const float* gate;     /* f32: gate[(m / rows_per_batch) * gate_ld + n], or NULL */
+    int64_t gate_ld;
+    const float* resid;    /* f32 [M,N] (ld = ldc) residual stream added AFTER the gate, or NULL */
+    const float* rowadd;   /* f32 [rows_per_batch, N] added by (m % rows_per_batch): frozen pos_embed, or NULL */
+    int rows_per_batch;    /* tokens per sample (T); required when gate/rowadd is set */
+    float alpha;           /* scales the accumulator first */
+    float beta;            /* C = beta*C_old + value (f32 output only; 0 = overwrite, C_old not read) */
+    int out_f32;           /* 1: C is f32 regardless of act dtype; 0: C has act dtype */
+} vaw_epilogue;
+
+/* C[M,N] = epilogue( alpha * op(A)[M,K] . op(B)[K,N] )
+ *   a_kmajor=1: A stored [M][K] (lda = row stride);  0: stored [K][M]
+ *   b_kmajor=1: B stored [N][K] (ldb = row stride);  0: stored [K][N]
+ * forward  y = x W^T + b : (1,1)   dgrad dx = dy W : (1,0)   wgrad dW = dy^T x : (0,0)
+ * A and B are act dtype.  value = acc*alpha + bias -> [aux_out] -> act -> *gate -> +resid -> +rowadd. */
+int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
+             const void* B, int64_t ldb, void* C, int64_t ldc, const vaw_epilogue* epi_host, vaw_stream stream);
+
+/* out[n] = beta*out[n] + sum_m X[m,n]  (bias gradients). X act dtype, out f32.  Two fixed-order stages through a
+ * caller-provided f32 workspace of vaw_colsum_workspace_floats(M,N) elements: no atomics, bitwise reproducible. */
+int64_t vaw_colsum_workspace_floats(int64_t M, int64_t N);
+int vaw_colsum(vaw_dtype dt, const void* X, int64_t M, int64_t N, int64_t ldx, float* out, float beta,
+               float* workspace, int64_t workspace_floats, vaw_stream stream);
+
+/* ---------------------------------------------------------------------------
+ * DiT pieces  (models/dit.py)
+ * ------------------------------------------------------------------------- */
+
+/* modulate(LayerNorm(x), shift, scale) :24-25,125,135: eps=1e-6, no affine.  x: f32 [B*T, D] residual
+ * stream; shift/scale: f32 rows of the adaLN output with row stride mod_ld; out: act dtype [B*T, D];
+ * mean/rstd: f32 [B*T] saved for backward. */
+int vaw_ln_modulate_fwd(vaw_dtype dt, const float* x, const float* shift, const float* scale, int64_t mod_ld,
+                        void* out, float* mean, float* rstd, int B, int T, int D, float eps, vaw_stream stream);
+/* Backward of the above, fused with the residual-stream gradient:
+ *   dx[b,t,:]   = (dres_in ? dres_in : 0) + LN'(dout * (1+scale))
+ *   dshift[b,:] = sum_t dout ;  dscale[b,:] = sum_t dout * xhat     (rows with stride dmod_ld)
+ * dx may alias dres_in. */
+int vaw_ln_modulate_bwd(vaw_dtype dt, const void* dout, const float* x, const float* mean, const float* rstd,
+                        const float* scale, int64_t mod_ld, const float* dres_in, float* dx, float* dshift,
+                        float* dscale, int64_t dmod_ld, int B, int T, int D, vaw_stream stream);
+/* Backward of `x + gate.unsqueeze(1) * y` :135-136 w.r.t. the branch:
+ *   dy[b,t,:] = dres[b,t,:] * gate[b,:] (act dtype) ; dgate[b,:] = sum_t dres * y. */
+int vaw_gate_bwd(vaw_dtype dt, const float* dres, const void* y, const float* gate, int64_t mod_ld, void* dy,
+                 float* dgate, int64_t dmod_ld, int B, int T, int D, vaw_stream stream);
+
+/* timm PatchEmbed (dit.py:192) input side: x f32 [B,C,H,W] -> tokens act dtype [B*(H/p)*(W/p), C*p*p],
+ * column order (c, i, j) = Conv2d weight flattening. */
+int vaw_patchify(vaw_dtype dt, const float* img, void* tok, int B, int C, int H, int W, int p, vaw_stream stream);
+/* gradient of patchify w.r.t. the image: dtok f32 [B*h*w, C*p*p] -> dimg f32 [B,C,H,W] */
+int vaw_patchify_bwd(const float* dtok, float* dimg, int B, int C, int H, int W, int p, vaw_stream stream);
+/* unpatchify :243-256: tokens f32 [B*h*w, p*p*C] (column order (i, j, c)) -> img f32 [B,C,h*p,w*p];
+ * vaw_unpatchify_bwd is the transpose map (dimg -> token rows, act dtype). */
+int vaw_unpatchify(vaw_dtype dt, const float* tok, float* img, int B, int C, int H, int W, int p,
+                   vaw_stream stream);
+int vaw_unpatchify_bwd(vaw_dtype dt, const float* dimg, void* dtok, int B, int C, int H, int W, int p,
+                       vaw_stream stream);
+
+/* sinusoidal embedding (dit.py:56-74 == tools/nn.py:103-121): out[b] = [cos(t f_i) | sin(t f_i)], act dtype. */
+int vaw_timestep_embedding(vaw_dtype dt, const float* t, void* out, int B, int dim, float max_period,
+                           vaw_stream stream);
+/* SiLU on f32 input; out act dtype.  bwd: dx(f32) += / = dy * silu'(x). */
+int vaw_silu_fwd(vaw_dtype dt, const float* x, void* out, int64_t n, vaw_stream stream);
+int vaw_silu_bwd(const float* x, const float* dy, float* dx, int64_t n, vaw_stream stream);
+/* out[b,:] = a[b,:] + table[idx[b],:]  (c = t_emb + y_emb, dit.py:267-269 / unet.py:676) */
+int vaw_add_embedding(const float* a, const float* table, const int64_t* idx, float* out, int B, int D,
+                      int num_rows, vaw_stream stream);
+/* nn.Embedding backward: dtable[r,:] = beta*dtable[r,:] + sum_{b: idx[b]==r} dc[b,:] (b ascending; every row
+ * of the table is written, no atomics, no pre-zeroing) */
+int vaw_embedding_bwd(const float* dc, const int64_t* idx, float* dtable, int B, int D, int num_rows, float beta,
+                      vaw_stream stream);
+
+/* Multi-head attention, softmax(scale * q k^T) v, strided so both layouts of the reference are served:
+ *   DiT (timm Attention, dit.py:126): qkv [B*T, 3*H*hd] token-major -> stride_t = 3*H*hd, stride_d = 1
+ *   UNet QKVAttention (unet.py:362-390): qkv [B, 3*H*ch, T] channel-major -> stride_t = 1, stride_d = T
+ * q/k/v/o point at element (b=0, h=0, t=0, d=0) of each operand; stride_b / stride_h in elements.
+ * lse: f32 [B*H*T] (row log-sum-exp, saved for backward). */
+typedef struct {
+    int B, H, T, hd;
+    int64_t q_sb, q_sh, q_st, q_sd; /* shared by q, k, v (same tensor, different base) */
+    int64_t o_sb, o_sh, o_st, o_sd;
+    float scale;
+} vaw_attn_desc;
+int vaw_attn_fwd(vaw_dtype dt, const vaw_attn_desc* d_host, const void* q, const void* k, const void* v, void* o,
+                 float* lse, vaw_stream stream);
+/* dq/dk/dv use the q strides, d_o the o strides.  delta: f32 [B*H*T] workspace. */
+int vaw_attn_bwd(vaw_dtype dt, const vaw_attn_desc* d_host, const void* q, const void* k, const void* v,
+                 const void* o, const void* d_o, const float* lse, float* delta, void* dq, void* dk, void* dv,
+                 vaw_stream stream);
+
+/* ---------------------------------------------------------------------------
+ * Optimizer side  (torch.optim.AdamW at main.py:354, ema() tools/trainer.py:12-18,
+ * clip_grad_norm_ tools/trainer.py:60-62)
+ * ------------------------------------------------------------------------- */
+
+/* sumsq_out[0] = (accumulate ? sumsq_out[0] : 0) + sum g^2 over n elements; fixed-order two-stage reduction
+ * through a workspace of vaw_sumsq_workspace_floats() f32. */
+int64_t vaw_sumsq_workspace_floats(void);
+int vaw_sumsq(const float* g, int64_t n, float* sumsq_out, int accumulate, float* workspace, vaw_stream stream);
+/* One fused pass over flat f32 buffers: decoupled-weight-decay Adam, then EMA, then the bf16 shadow copy.
+ *   g' = g * gscale, gscale = clip_max_norm>0 ? min(1, clip_max_norm/(sqrt(*sumsq)+1e-6)) : 1
+ *   p *= 1 - lr*wd ; m += (g'-m)(1-b1) ; v = b2 v + (1-b2) g'^2
+ *   p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+ *   ema = ema*decay + p*(1-decay)   (if ema != NULL)
+ *   shadow = bf16(p)                (if shadow != NULL)
+ *   g = 0                           (if zero_grad)
+ * bc1 = 1-b1^step, bc2 = 1-b2^step are computed on the host. */
+int vaw_adamw_ema_step(float* p, float* g, float* m, float* v, float* ema, void* shadow_bf16, int64_t n, float lr,
+                       float beta1, float beta2, float eps, float weight_decay, float bc1, float bc2,
+                       float ema_decay, const float* sumsq, float clip_max_norm, int zero_grad, vaw_stream stream);
+/* ema = ema*decay + src*(1-decay) over n f32 (buffers that are not optimizer-owned, e.g. frozen pos_embed) */
+int vaw_ema_update(float* ema, const float* src, int64_t n, float decay, vaw_stream stream);
+/* dst(bf16) = src(f32) */
+int vaw_cast_bf16(const float* src, void* dst, int64_t n, vaw_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VAW_HIP_H */

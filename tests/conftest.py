@@ -42,7 +42,7 @@ def perturb_(model, seed, std=0.05):
     with torch.no_grad():
         for p in model.parameters():
             if p.requires_grad:
-                p.add_(torch.randn(p.shape, generator=g) * std)
+                p.add_((torch.randn(p.shape, generator=g) * std).to(p.device))
 
 
 def fingerprint(v):

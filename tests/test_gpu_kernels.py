@@ -1,0 +1,382 @@
+"""Parity of each HIP kernel (through the C ABI, libvaw_hip.so) with the CPU oracle / a float64 torch
+statement of the same op, on seeded inputs.  Run on the MI355X box: pytest -m gpu."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import base_args, fake_model, load_json, load_pt
+
+pytestmark = pytest.mark.gpu
+
+import vaw_amd
+from vaw_amd import ops
+from vaw_amd._lib import BF16, F32, lib, ptr, stream_ptr
+
+from oracle import diffusion as od
+
+DEV = "cuda"
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ------------------------------------------------------------------------------------------------
+# diffusion objective
+# ------------------------------------------------------------------------------------------------
+def _pair(sched="cosine", mt="EPSILON", wt="lambda"):
+    kw = dict(args=base_args(weight_type=wt), model_var_type=None, loss_type=None, rescale_timesteps=True)
+    o = od.GaussianDiffusion(betas=od.get_named_beta_schedule(sched, 1000), model_mean_type=od.ModelMeanType[mt],
+                             **{**kw, "model_var_type": od.ModelVarType.FIXED_LARGE, "loss_type": od.LossType.MSE})
+    p = vaw_amd.GaussianDiffusion(betas=vaw_amd.get_named_beta_schedule(sched, 1000),
+                                  model_mean_type=vaw_amd.ModelMeanType[mt],
+                                  **{**kw, "model_var_type": vaw_amd.ModelVarType.FIXED_LARGE,
+                                     "loss_type": vaw_amd.LossType.MSE})
+    return o, p
+
+
+def test_qsample_bit_exact_vs_oracle_and_golden():
+    g = load_pt("objective.pt")
+    x0, noise, t = g["x0"], g["noise"], g["t"]
+    for sched in ("cosine", "linear"):
+        o, p = _pair(sched)
+        got = p.q_sample(x0.to(DEV), t.to(DEV), noise.to(DEV)).cpu()
+        assert torch.equal(got, g[f"{sched}/EPSILON/x_t"]) and torch.equal(got, o.q_sample(x0, t, noise))
+    # ragged per-sample size (not a multiple of 4) and a big batch
+    o, p = _pair()
+    x = _rand(37, 3, 5, 7, seed=1); n = _rand(37, 3, 5, 7, seed=2)
+    tt = torch.randint(0, 1000, (37,), generator=torch.Generator().manual_seed(3))
+    assert torch.equal(p.q_sample(x.to(DEV), tt.to(DEV), n.to(DEV)).cpu(), o.q_sample(x, tt, n))
+    bad = p.q_sample(x.to(DEV), torch.full((37,), 1000).to(DEV), n.to(DEV))
+    assert torch.isnan(bad).all()          # out-of-range timestep poisons the row instead of reading out of bounds
+
+
+@pytest.mark.parametrize("mt", ["EPSILON", "START_X", "VELOCITY"])
+@pytest.mark.parametrize("wt", ["lambda", "constant", "min_snr_5"])
+def test_training_losses_vs_golden(mt, wt):
+    g = load_pt("objective.pt")
+    x0, noise, t, y = (g[k].to(DEV) for k in ("x0", "noise", "t", "y"))
+    for sched in ("cosine", "linear"):
+        _, p = _pair(sched, mt, wt)
+        terms = p.training_losses(fake_model, x0, None, t=t, model_kwargs={"y": y}, noise=noise)
+        torch.testing.assert_close(terms["mse"].cpu(), g[f"{sched}/{mt}/{wt}/mse"], rtol=2e-6, atol=1e-9)
+        assert terms["loss"] is terms["mse"]
+        if wt == "lambda":
+            torch.testing.assert_close(p.compute_target(x0, noise, t).cpu(), g[f"{sched}/{mt}/target"], rtol=1e-6, atol=1e-7)
+
+
+def test_wmse_backward_matches_autograd():
+    o, p = _pair("cosine", "VELOCITY", "min_snr_5")
+    x0, noise = _rand(6, 3, 9, 5, seed=4), _rand(6, 3, 9, 5, seed=5)
+    t = torch.tensor([0, 5, 250, 500, 998, 999])
+    out = _rand(6, 3, 9, 5, seed=6).requires_grad_(True)
+    ref = o.training_losses(lambda x, tt, **k: out, x0, None, t=t, noise=noise)["mse"]
+    gm = _rand(6, seed=7)
+    (ref * gm).sum().backward()
+    outd = out.detach().to(DEV).requires_grad_(True)
+    got = p.training_losses(lambda x, tt, **k: outd, x0.to(DEV), None, t=t.to(DEV), noise=noise.to(DEV))["mse"]
+    (got * gm.to(DEV)).sum().backward()
+    torch.testing.assert_close(got.detach().cpu(), ref.detach(), rtol=2e-6, atol=1e-9)
+    torch.testing.assert_close(outd.grad.cpu(), out.grad, rtol=2e-6, atol=1e-7)   # atol: cancellation in (out - target)
+
+
+def test_flow_matching_vs_golden():
+    g = load_pt("objective.pt")
+    x0, noise, y, tf = (g[k].to(DEV) for k in ("x0", "noise", "y", "flow/t"))
+    for path in ("linear", "cosine", "linear_logsnr"):
+        for mt in ("VECTOR", "EPSILON", "VELOCITY", "START_X"):
+            fm = vaw_amd.FlowMatching(args=base_args(path_type=path), model_mean_type=vaw_amd.ModelMeanType[mt])
+            terms = fm.training_losses(fake_model, x0, None, t=tf, model_kwargs={"y": y}, noise=noise)
+            torch.testing.assert_close(terms["mse"].cpu(), g[f"flow/{path}/{mt}/mse"], rtol=5e-6, atol=1e-9)
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM: three operand layouts x {f32 generic, bf16 generic, bf16 MFMA fast} x epilogues
+# ------------------------------------------------------------------------------------------------
+def _gemm_ref(A, B, a_k, b_k):
+    Am = A.double() if a_k else A.double().t()
+    Bm = B.double().t() if b_k else B.double()
+    return Am @ Bm
+
+
+def _mk(M, N, K, a_k, b_k, dtype, seed, ints=False):
+    g = torch.Generator().manual_seed(seed)
+    def r(*s):
+        if ints:
+            return torch.randint(-3, 4, s, generator=g).float()
+        return torch.randn(*s, generator=g)
+    A = r(M, K) if a_k else r(K, M)
+    B = r(N, K) if b_k else r(K, N)
+    return A.to(dtype), B.to(dtype)
+
+
+@pytest.mark.parametrize("a_k,b_k", [(True, True), (True, False), (False, False), (False, True)])
+@pytest.mark.parametrize("mode", ["f32", "bf16_generic", "bf16_fast"])
+def test_gemm_layouts_exact_integers(a_k, b_k, mode):
+    """Small-integer operands are exact in bf16 and f32: any fragment-layout or swizzle error shows as a
+    wrong integer, with asymmetric data on both sides (a symmetric operand would hide a transpose)."""
+    dtype = torch.float32 if mode == "f32" else torch.bfloat16
+    shapes = [(256, 384, 192)] if mode == "bf16_fast" else [(256, 384, 192), (70, 45, 23), (129, 1, 17), (5, 200, 64)]
+    lib().vaw_debug_force_generic_gemm(1 if mode == "bf16_generic" else 0)
+    try:
+        for (M, N, K) in shapes:
+            A, B = _mk(M, N, K, a_k, b_k, dtype, seed=M + N + K, ints=True)
+            got = ops.gemm_t(A.to(DEV), B.to(DEV), a_kmajor=a_k, b_kmajor=b_k, out_dtype=torch.float32).cpu()
+            ref = _gemm_ref(A, B, a_k, b_k)
+            assert torch.equal(got.double(), ref), (mode, a_k, b_k, M, N, K, (got.double() - ref).abs().max())
+    finally:
+        lib().vaw_debug_force_generic_gemm(0)
+
+
+@pytest.mark.parametrize("a_k,b_k", [(True, True), (True, False), (False, False)])
+def test_gemm_bf16_fast_random_and_large_k(a_k, b_k):
+    for (M, N, K) in [(128, 128, 64), (512, 256, 768), (256, 128, 3072)]:
+        A, B = _mk(M, N, K, a_k, b_k, torch.bfloat16, seed=K)
+        got = ops.gemm_t(A.to(DEV), B.to(DEV), a_kmajor=a_k, b_kmajor=b_k, out_dtype=torch.float32).cpu()
+        ref = _gemm_ref(A, B, a_k, b_k)
+        torch.testing.assert_close(got.double(), ref, rtol=1e-4, atol=1e-3 * math.sqrt(K) * 0.05)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_epilogues(dtype):
+    tol = dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    Bt, T, N, K = 4, 32, 256, 128
+    M = Bt * T
+    A, W = _mk(M, N, K, True, True, dtype, seed=11)
+    bias, gate = _rand(N, seed=12), _rand(Bt, 3 * N, seed=13)
+    resid, rowadd = _rand(M, N, seed=14), _rand(T, N, seed=15)
+    acc = A.double() @ W.double().t() + bias.double()
+    d = lambda t: None if t is None else t.to(DEV)
+    # bias only, act-dtype output
+    got = ops.gemm_t(d(A), d(W), bias=d(bias))
+    torch.testing.assert_close(got.cpu().double(), acc, **tol)
+    # GELU(tanh) forward with saved pre-activation
+    got, pre = ops.gemm_t(d(A), d(W), bias=d(bias), act=1, want_aux=True)
+    torch.testing.assert_close(pre.cpu().double(), acc, **tol)
+    torch.testing.assert_close(got.cpu().double(), torch.nn.functional.gelu(pre.cpu().double(), approximate="tanh"), **tol)
+    # gated residual with saved branch output, f32 residual stream out
+    gsl = gate[:, N:2 * N].contiguous()
+    out = torch.empty(M, N, device=DEV)
+    aux = torch.empty(M, N, device=DEV, dtype=dtype)
+    gd, rd, Ad, Wd, bd = d(gate), d(resid), d(A), d(W), d(bias)     # keep the device copies alive across the launch
+    ops.gemm(ops.dt_of(A), 1, 1, M, N, K, ptr(Ad), K, ptr(Wd), K, ptr(out), N, bias=ptr(bd), aux_out=ptr(aux),
+             gate=ptr(gd) + 4 * N, gate_ld=3 * N, resid=ptr(rd), rows_per_batch=T, out_f32=True)
+    y = aux.cpu().double()
+    torch.testing.assert_close(y, acc, **tol)
+    ref = resid.double() + gsl.double().repeat_interleave(T, 0) * y
+    torch.testing.assert_close(out.cpu().double(), ref, **tol)
+    # pos-embed row add
+    got = ops.gemm_t(d(A), d(W), bias=d(bias), rowadd=d(rowadd), rows_per_batch=T, out_dtype=torch.float32)
+    torch.testing.assert_close(got.cpu().double(), acc + rowadd.double().repeat(Bt, 1), **tol)
+    # dgrad through GELU: multiply by gelu'(h)
+    h = _rand(M, N, seed=16).to(dtype)
+    got = ops.gemm_t(d(A), d(W), act=2, aux_in=d(h))
+    hh = h.double().requires_grad_(True)
+    torch.nn.functional.gelu(hh, approximate="tanh").sum().backward()
+    torch.testing.assert_close(got.cpu().double(), (A.double() @ W.double().t()) * hh.grad, **tol)
+    # wgrad accumulate: C = 1*C + A^T B
+    X, Y = _mk(N, K, M, False, False, dtype, seed=17)
+    c0 = _rand(N, K, seed=18)
+    got = ops.gemm_t(d(X), d(Y), a_kmajor=False, b_kmajor=False, beta=1.0, out=d(c0).clone())
+    torch.testing.assert_close(got.cpu().double(), c0.double() + X.double().t() @ Y.double(),
+                               **(tol if dtype == torch.float32 else dict(rtol=2e-2, atol=5e-2)))
+
+
+def test_gemm_rejects_bad_arguments():
+    A = torch.zeros(8, 8, device=DEV)
+    with pytest.raises(vaw_amd.VawError):
+        ops.gemm(F32, 1, 1, 8, 8, 8, ptr(A), 4, ptr(A), 8, ptr(A), 8)          # lda < K
+    with pytest.raises(vaw_amd.VawError):
+        ops.gemm(F32, 1, 1, 8, 8, 8, ptr(A), 8, ptr(A), 8, ptr(A), 8, act=2)   # act=2 without aux_in
+    with pytest.raises(vaw_amd.VawError):
+        ops.qsample(torch.zeros(2, 4), torch.zeros(2, 4), torch.zeros(2, dtype=torch.long), torch.zeros(10), torch.zeros(10))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_colsum(dtype):
+    for (M, N) in [(1000, 260), (3, 8), (2048, 768)]:
+        X = _rand(M, N, seed=M).to(dtype)
+        out = _rand(N, seed=1).to(DEV)
+        o0 = out.clone()
+        ops.colsum(ops.dt_of(X), ptr(X.to(DEV)), M, N, N, ptr(out), 0.0)
+        torch.testing.assert_close(out.cpu().double(), X.double().sum(0), rtol=1e-5, atol=1e-3)
+        out = o0.clone()
+        Xd = X.to(DEV)
+        ops.colsum(ops.dt_of(X), ptr(Xd), M, N, N, ptr(out), 1.0)
+        torch.testing.assert_close(out.cpu().double(), o0.cpu().double() + X.double().sum(0), rtol=1e-5, atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------------
+# LayerNorm + modulate, gated residual backward
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,T,D", [(3, 16, 64), (2, 64, 768), (2, 5, 1152), (1, 1, 8)])
+def test_ln_modulate_fwd_bwd(dtype, B, T, D):
+    tol = dict(rtol=1e-5, atol=2e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    x = _rand(B * T, D, seed=1) * 2 + 0.5
+    mod = _rand(B, 6 * D, seed=2) * 0.5
+    dout = _rand(B * T, D, seed=3).to(dtype)
+    dres = _rand(B * T, D, seed=4)
+    xr = x.double().requires_grad_(True)
+    modr = mod.double().requires_grad_(True)
+    shift, scale = modr[:, 3 * D:4 * D], modr[:, 4 * D:5 * D]
+    ref = torch.nn.functional.layer_norm(xr, (D,), eps=1e-6).view(B, T, D) * (1 + scale[:, None]) + shift[:, None]
+    (ref.reshape(B * T, D) * dout.double()).sum().backward()
+    xd, md = x.to(DEV), mod.to(DEV)
+    out = torch.empty(B * T, D, device=DEV, dtype=dtype)
+    mean, rstd = torch.empty(B * T, device=DEV), torch.empty(B * T, device=DEV)
+    dt = ops.dt_of(out)
+    ops.ln_modulate_fwd(dt, ptr(xd), ptr(md) + 4 * 3 * D, ptr(md) + 4 * 4 * D, 6 * D, ptr(out), ptr(mean), ptr(rstd), B, T, D)
+    torch.testing.assert_close(out.cpu().double(), ref.detach().reshape(B * T, D), **tol)
+    torch.testing.assert_close(mean.cpu().double(), x.double().mean(1), rtol=1e-5, atol=1e-6)
+    dmod = torch.zeros(B, 6 * D, device=DEV)
+    dx = dres.to(DEV).clone()
+    dod = dout.to(DEV)
+    ops.ln_modulate_bwd(dt, ptr(dod), ptr(xd), ptr(mean), ptr(rstd), ptr(md) + 4 * 4 * D, 6 * D, ptr(dx), ptr(dx),
+                        ptr(dmod) + 4 * 3 * D, ptr(dmod) + 4 * 4 * D, 6 * D, B, T, D)
+    torch.testing.assert_close(dx.cpu().double(), dres.double() + xr.grad, **tol)
+    torch.testing.assert_close(dmod.cpu().double(), modr.grad, rtol=tol["rtol"], atol=tol["atol"] * math.sqrt(T))
+    # no incoming residual gradient
+    dx2 = torch.empty(B * T, D, device=DEV)
+    ops.ln_modulate_bwd(dt, ptr(dod), ptr(xd), ptr(mean), ptr(rstd), ptr(md) + 4 * 4 * D, 6 * D, 0, ptr(dx2),
+                        ptr(dmod) + 4 * 3 * D, ptr(dmod) + 4 * 4 * D, 6 * D, B, T, D)
+    torch.testing.assert_close(dx2.cpu().double(), xr.grad, **tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gate_bwd(dtype):
+    B, T, D = 3, 20, 192
+    tol = dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    dres, y, gate = _rand(B * T, D, seed=1), _rand(B * T, D, seed=2).to(dtype), _rand(B, 2 * D, seed=3)
+    dy = torch.empty(B * T, D, device=DEV, dtype=dtype)
+    dg = torch.zeros(B, 2 * D, device=DEV)
+    gd, dr, yd = gate.to(DEV), dres.to(DEV), y.to(DEV)
+    ops.gate_bwd(ops.dt_of(dy), ptr(dr), ptr(yd), ptr(gd) + 4 * D, 2 * D, ptr(dy), ptr(dg) + 4 * D, 2 * D, B, T, D)
+    g = gate[:, D:].double()
+    torch.testing.assert_close(dy.cpu().double(), dres.double() * g.repeat_interleave(T, 0), **tol)
+    torch.testing.assert_close(dg[:, D:].cpu().double(), (dres.double() * y.double()).view(B, T, D).sum(1), rtol=1e-4, atol=1e-4)
+    assert float(dg[:, :D].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------
+# attention: both memory layouts, forward + backward
+# ------------------------------------------------------------------------------------------------
+def _attn_ref(q, k, v, scale):
+    """q,k,v [B,H,T,hd] float64"""
+    p = torch.softmax(q @ k.transpose(-1, -2) * scale, dim=-1)
+    return p @ v
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,T,hd", [(2, 3, 64, 64), (1, 2, 16, 32), (2, 2, 100, 72), (1, 1, 256, 64)])
+def test_attention_token_major(dtype, B, H, T, hd):
+    tol = dict(rtol=1e-4, atol=2e-5) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2)
+    D = H * hd
+    qkv = (_rand(B * T, 3 * D, seed=T) * 0.7).to(dtype)
+    do = _rand(B * T, D, seed=T + 1).to(dtype)
+    qr = qkv.double().requires_grad_(True)
+    q, k, v = qr.view(B, T, 3, H, hd).permute(2, 0, 3, 1, 4).unbind(0)
+    ref = _attn_ref(q, k, v, hd ** -0.5).transpose(1, 2).reshape(B * T, D)
+    (ref * do.double()).sum().backward()
+    qd, dod = qkv.to(DEV), do.to(DEV)
+    o = torch.empty(B * T, D, device=DEV, dtype=dtype)
+    lse, delta = torch.empty(B * H * T, device=DEV), torch.empty(B * H * T, device=DEV)
+    dt, es = ops.dt_of(o), qkv.element_size()
+    desc = ops.attn_desc_token_major(B, H, T, hd)
+    ops.attn_fwd(dt, desc, ptr(qd), ptr(qd) + es * D, ptr(qd) + 2 * es * D, ptr(o), ptr(lse))
+    torch.testing.assert_close(o.cpu().double(), ref.detach(), **tol)
+    dqkv = torch.zeros_like(qd)
+    ops.attn_bwd(dt, desc, ptr(qd), ptr(qd) + es * D, ptr(qd) + 2 * es * D, ptr(o), ptr(dod), ptr(lse), ptr(delta),
+                 ptr(dqkv), ptr(dqkv) + es * D, ptr(dqkv) + 2 * es * D)
+    torch.testing.assert_close(dqkv.cpu().double(), qr.grad, **tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attention_channel_major_unet_layout(dtype):
+    """UNet QKVAttention (new order): qkv [B, 3*H*ch, T]; scale ch^-1/4 on q and on k == ch^-1/2 on the product."""
+    from oracle.unet import QKVAttention
+    B, H, T, ch = 2, 4, 64, 32
+    tol = dict(rtol=1e-4, atol=2e-5) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2)
+    qkv = (_rand(B, 3 * H * ch, T, seed=5) * 0.8).to(dtype)
+    do = _rand(B, H * ch, T, seed=6).to(dtype)
+    qr = qkv.double().requires_grad_(True)
+    ref = QKVAttention(H)(qr)
+    (ref * do.double()).sum().backward()
+    qd, dod = qkv.to(DEV), do.to(DEV)
+    o = torch.empty(B, H * ch, T, device=DEV, dtype=dtype)
+    lse, delta = torch.empty(B * H * T, device=DEV), torch.empty(B * H * T, device=DEV)
+    dt, es = ops.dt_of(o), qkv.element_size()
+    desc = ops.attn_desc_channel_major(B, H, T, ch)
+    koff, voff = es * H * ch * T, 2 * es * H * ch * T
+    ops.attn_fwd(dt, desc, ptr(qd), ptr(qd) + koff, ptr(qd) + voff, ptr(o), ptr(lse))
+    torch.testing.assert_close(o.cpu().double(), ref.detach(), **tol)
+    dqkv = torch.zeros_like(qd)
+    ops.attn_bwd(dt, desc, ptr(qd), ptr(qd) + koff, ptr(qd) + voff, ptr(o), ptr(dod), ptr(lse), ptr(delta), ptr(dqkv),
+                 ptr(dqkv) + koff, ptr(dqkv) + voff)
+    torch.testing.assert_close(dqkv.cpu().double(), qr.grad, **tol)
+
+
+# ------------------------------------------------------------------------------------------------
+# small conditioning kernels, patch shuffles
+# ------------------------------------------------------------------------------------------------
+def test_timestep_embedding_vs_golden():
+    g = load_pt("unet_tiny.pt")
+    t = g["temb/t"].to(DEV)
+    torch.testing.assert_close(ops.timestep_embedding(t, 64).cpu(), g["temb/out64"], rtol=1e-5, atol=2e-6)
+    torch.testing.assert_close(ops.timestep_embedding(t, 33).cpu(), g["temb/out33"], rtol=1e-5, atol=2e-6)
+
+
+def test_patchify_unpatchify_roundtrip_and_order():
+    B, C, H, p = 3, 4, 16, 4
+    x = _rand(B, C, H, H, seed=1)
+    xd = x.to(DEV)
+    tok = torch.empty(B * (H // p) ** 2, C * p * p, device=DEV)
+    st = stream_ptr()
+    assert lib().vaw_patchify(F32, ptr(xd), ptr(tok), B, C, H, H, p, st) == 0
+    ref = torch.nn.functional.unfold(x, kernel_size=p, stride=p).transpose(1, 2).reshape(-1, C * p * p)   # (c,i,j) order
+    assert torch.equal(tok.cpu(), ref)
+    back = torch.empty_like(xd)
+    assert lib().vaw_patchify_bwd(ptr(tok), ptr(back), B, C, H, H, p, st) == 0
+    assert torch.equal(back.cpu(), x)
+    # final-layer order (i,j,c): oracle unpatchify
+    from oracle.dit import DiT
+    m = DiT(image_size=H, patch_size=p, in_channels=C, hidden_size=32, depth=1, num_heads=2, num_classes=3)
+    tk = _rand(B, (H // p) ** 2, p * p * C, seed=2)
+    img = torch.empty(B, C, H, H, device=DEV)
+    tkd = tk.to(DEV).reshape(-1, p * p * C).contiguous()
+    assert lib().vaw_unpatchify(F32, ptr(tkd), ptr(img), B, C, H, H, p, st) == 0
+    assert torch.equal(img.cpu(), m.unpatchify(tk))
+    tk2 = torch.empty_like(tkd)
+    assert lib().vaw_unpatchify_bwd(F32, ptr(img), ptr(tk2), B, C, H, H, p, st) == 0
+    assert torch.equal(tk2, tkd)
+
+
+# ------------------------------------------------------------------------------------------------
+# optimizer kernels
+# ------------------------------------------------------------------------------------------------
+def test_fused_adamw_ema_matches_torch_adamw():
+    n = 10007
+    p0, = [_rand(n, seed=1)]
+    ref_p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref_p], lr=1e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.01)
+    ema_ref = p0.clone()
+    p, m, v, e = p0.to(DEV).clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV), p0.to(DEV).clone()
+    shadow = torch.empty(n, device=DEV, dtype=torch.bfloat16)
+    ss = torch.zeros(1, device=DEV)
+    for step in range(1, 6):
+        g = _rand(n, seed=10 + step) * (3.0 if step == 3 else 0.1)
+        ref_p.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_([ref_p], 1.0)
+        opt.step()
+        ema_ref = ema_ref * 0.999 + ref_p.detach() * (1 - 0.999)
+        gd = g.to(DEV)
+        ops.sumsq(gd, ss)
+        torch.testing.assert_close(ss.cpu().double(), (g.double() ** 2).sum().view(1), rtol=1e-5, atol=0)
+        ops.adamw_ema_step(p, gd, m, v, e, shadow, 1e-3, 0.9, 0.95, 1e-8, 0.01, step, 0.999, ss, 1.0, True)
+        assert float(gd.abs().max()) == 0.0
+    torch.testing.assert_close(p.cpu(), ref_p.detach(), rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(e.cpu(), ema_ref, rtol=1e-6, atol=1e-7)
+    assert torch.equal(shadow.cpu(), p.cpu().bfloat16())

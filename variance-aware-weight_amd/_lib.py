@@ -1,0 +1,107 @@
+"""ctypes binding of libvaw_hip.so (include/vaw_hip.h).  No fallback: if the library is missing,
+or a call is made without a GPU tensor, this raises."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvaw_hip.so")
+
+F32, BF16 = 0, 1
+TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16}
+
+_p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+
+class Epilogue(C.Structure):
+    _fields_ = [("bias", _p), ("act", _i), ("aux_in", _p), ("aux_out", _p), ("gate", _p), ("gate_ld", _l),
+                ("resid", _p), ("rowadd", _p), ("rows_per_batch", _i), ("alpha", _f), ("beta", _f), ("out_f32", _i)]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [("B", _i), ("H", _i), ("T", _i), ("hd", _i), ("q_sb", _l), ("q_sh", _l), ("q_st", _l), ("q_sd", _l),
+                ("o_sb", _l), ("o_sh", _l), ("o_st", _l), ("o_sd", _l), ("scale", _f)]
+
+
+# name -> argtypes (every function returns int status unless noted)
+_PROTOS = {
+    "vaw_qsample_fwd": [_p, _p, _p, _p, _p, _i, _p, _i, _l, _p],
+    "vaw_mix_rows": [_p, _p, _p, _p, _p, _i, _l, _p],
+    "vaw_wmse_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _l, _p],
+    "vaw_wmse_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _l, _p],
+    "vaw_gemm": [_i, _i, _i, _l, _l, _l, _p, _l, _p, _l, _p, _l, C.POINTER(Epilogue), _p],
+    "vaw_colsum": [_i, _p, _l, _l, _l, _p, _f, _p, _l, _p],
+    "vaw_ln_modulate_fwd": [_i, _p, _p, _p, _l, _p, _p, _p, _i, _i, _i, _f, _p],
+    "vaw_ln_modulate_bwd": [_i, _p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _l, _i, _i, _i, _p],
+    "vaw_gate_bwd": [_i, _p, _p, _p, _l, _p, _p, _l, _i, _i, _i, _p],
+    "vaw_patchify": [_i, _p, _p, _i, _i, _i, _i, _i, _p],
+    "vaw_patchify_bwd": [_p, _p, _i, _i, _i, _i, _i, _p],
+    "vaw_unpatchify": [_i, _p, _p, _i, _i, _i, _i, _i, _p],
+    "vaw_unpatchify_bwd": [_i, _p, _p, _i, _i, _i, _i, _i, _p],
+    "vaw_timestep_embedding": [_i, _p, _p, _i, _i, _f, _p],
+    "vaw_silu_fwd": [_i, _p, _p, _l, _p],
+    "vaw_silu_bwd": [_p, _p, _p, _l, _p],
+    "vaw_add_embedding": [_p, _p, _p, _p, _i, _i, _i, _p],
+    "vaw_embedding_bwd": [_p, _p, _p, _i, _i, _i, _f, _p],
+    "vaw_attn_fwd": [_i, C.POINTER(AttnDesc), _p, _p, _p, _p, _p, _p],
+    "vaw_attn_bwd": [_i, C.POINTER(AttnDesc), _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "vaw_sumsq": [_p, _l, _p, _i, _p, _p],
+    "vaw_adamw_ema_step": [_p, _p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _f, _f, _p, _f, _i, _p],
+    "vaw_ema_update": [_p, _p, _l, _f, _p],
+    "vaw_cast_bf16": [_p, _p, _l, _p],
+}
+
+_lib = None
+
+
+class VawError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the CDLL.  Raises if the HIP library was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VawError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback for the HIP path)")
+        L = C.CDLL(LIB_PATH)
+        for name, args in _PROTOS.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = _i
+        L.vaw_version.restype = _i
+        L.vaw_last_error_string.restype = C.c_char_p
+        L.vaw_colsum_workspace_floats.argtypes = [_l, _l]
+        L.vaw_colsum_workspace_floats.restype = _l
+        L.vaw_sumsq_workspace_floats.argtypes = []
+        L.vaw_sumsq_workspace_floats.restype = _l
+        L.vaw_debug_force_generic_gemm.argtypes = [_i]
+        L.vaw_debug_force_generic_gemm.restype = None
+        _lib = L
+    return _lib
+
+
+def exported_symbols():
+    return sorted(list(_PROTOS) + ["vaw_version", "vaw_last_error_string", "vaw_colsum_workspace_floats",
+                                   "vaw_sumsq_workspace_floats"])
+
+
+def check(rc, what):
+    if rc != 0:
+        raise VawError(f"{what} failed ({rc}): {lib().vaw_last_error_string().decode()}")
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def need_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise VawError("vaw_amd runs on the GPU only: got a CPU tensor (no CPU fallback exists by design)")

@@ -1,0 +1,313 @@
+// Dense contraction kernels (the >97 % of DiT FLOPs):  C[M,N] = epilogue(alpha * op(A) . op(B)).
+//
+//   gemm_bf16_kernel   bf16 operands, v_mfma_f32_16x16x32_bf16, 128x128x64 block tile, 4 waves (2x2) of
+//                      64x64, both operand tiles brought in by LDS-DMA (global_load_lds_dwordx4) into a
+//                      double-buffered, XOR-swizzled LDS image (swizzle on the per-lane SOURCE address;
+//                      the LDS side of an LDS-DMA is lane-linear), one barrier per K step.
+//                      k-major operands ([rows][K]) are read with ds_read_b128, mn-major operands
+//                      ([K][rows]: dgrad's W, wgrad's dY and X) with the ds_read_b64_tr_b16 hardware
+//                      transpose, so forward, dgrad and wgrad run the same loop with no transposed copies.
+//   gemm_generic_kernel any shape / alignment / dtype: register-staged, f32 LDS image, exact-f32
+//                      v_mfma_f32_16x16x4_f32.  Serves the f32 parity mode and the odd shapes
+//                      (N = p*p*C = 64 head, tiny test models).
+//
+// MFMA operand maps used (cdna_hip_programming.md §3):
+//   16x16x32 bf16: lane l holds A[row l&15][k = 8(l>>4)+j], B[k = 8(l>>4)+j][col l&15], j=0..7
+//   16x16x4  f32 : lane l holds A[row l&15][k = l>>4],       B[k = l>>4][col l&15]
+//   C/D (both)   : col = l&15, row = 4(l>>4) + reg
+#include "common.h"
+
+struct EpiDev {
+    const float* bias;
+    int act;
+    const void* aux_in;
+    void* aux_out;
+    const float* gate;
+    int64_t gate_ld;
+    const float* resid;
+    const float* rowadd;
+    int rpb;
+    float alpha, beta;
+    int out_f32;
+    int64_t M, N, ldc;
+    void* C;
+};
+
+// One accumulator fragment row: 4 consecutive rows (m..m+3) at one column n.
+template <typename TO>
+__device__ __forceinline__ void epi_store4(const EpiDev& e, int64_t m, int64_t n, f32x4 acc) {
+    if (n >= e.N) return;
+    const float bias = e.bias ? e.bias[n] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t mm = m + j;
+        if (mm >= e.M) break;
+        const int64_t off = mm * e.ldc + n;
+        float v = acc[j] * e.alpha + bias;
+        if (e.aux_out) {
+            TO r = from_f32<TO>(v);
+            ((TO*)e.aux_out)[off] = r;
+            v = to_f32(r);
+        }
+        if (e.act == 1) v = gelu_tanh_f(v);
+        else if (e.act == 2) v *= gelu_tanh_grad_f(to_f32(((const TO*)e.aux_in)[off]));
+        if (e.gate) v *= e.gate[(mm / e.rpb) * e.gate_ld + n];
+        if (e.resid) v += e.resid[off];
+        if (e.rowadd) v += e.rowadd[(mm % e.rpb) * e.N + n];
+        if (e.out_f32) {
+            float* c = (float*)e.C + off;
+            *c = (e.beta != 0.f ? e.beta * *c : 0.f) + v;
+        } else {
+            ((TO*)e.C)[off] = from_f32<TO>(v);
+        }
+    }
+}
+
+// =============================================================================================
+// Fast path: bf16, M%128==0, N%128==0, K%64==0, 16-byte aligned rows.
+// =============================================================================================
+#define BM 128
+#define BN 128
+#define BK 64
+#define TILE_BYTES (128 * 64 * 2)   // one operand tile, either orientation: 16 KiB
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+// k-major image: [128 rows][8 chunks of 16 B]; chunk' = chunk ^ ((row>>1)&7)  -> conflict-free ds_read_b128
+__device__ __forceinline__ int kmaj_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+// mn-major image: [64 k-rows][16 chunks of 16 B]; chunk' = chunk ^ (((row&3)<<2)|((row>>2)&3))
+//   (image (b) of cdna_hip_programming.md T10: conflict-free ds_read_b64_tr_b16 for the 16x16x32 operand)
+__device__ __forceinline__ int mnmaj_off(int row, int chunk) {
+    return row * 256 + ((chunk ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
+}
+
+// Stage one 128x64 (k-major) or 64x128 (mn-major) operand tile into LDS: 16 wave-instructions of 1 KiB,
+// 4 per wave.  g points at the tile's first element; ld = leading dimension in elements.
+template <bool KMAJOR>
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int64_t ld, char* lds_tile, int wid, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int inst = wid * 4 + i;
+        const bf16_t* src;
+        if (KMAJOR) {
+            const int row = inst * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+            src = g + (int64_t)row * ld + chunk * 8;
+        } else {
+            const int row = inst * 4 + (lane >> 4);
+            const int chunk = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
+            src = g + (int64_t)row * ld + chunk * 8;
+        }
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(lds_tile + inst * 1024), 16, 0, 0);
+    }
+}
+
+// Fragment of 16 (rows) x 32 (k) for k-substep s of the tile rows r0..r0+15.
+template <bool KMAJOR>
+__device__ __forceinline__ bf16x8 load_frag(const char* lds_tile, int r0, int s, int lane) {
+    if (KMAJOR) {
+        const int row = r0 + (lane & 15);
+        return *reinterpret_cast<const bf16x8*>(lds_tile + kmaj_off(row, 4 * s + (lane >> 4)));
+    } else {
+        const int li = lane & 15, q = li >> 2, p = li & 3;
+        const int kb = 32 * s + 8 * (lane >> 4) + q;
+        const int ch = (r0 >> 3) + (p >> 1);
+        const char* a0 = lds_tile + mnmaj_off(kb, ch) + 8 * (p & 1);
+        const char* a1 = lds_tile + mnmaj_off(kb + 4, ch) + 8 * (p & 1);
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)a0);
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)a1);
+        bf16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return r;
+    }
+}
+
+template <bool AK, bool BKM>
+__global__ void __launch_bounds__(256, 2)
+gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb, int K, int tiles_n,
+                 int n_wg, EpiDev e) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A tile | B tile]
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // XCD-aware remap (bijective for any grid): blocks b, b+8, ... share an XCD; give each XCD a contiguous
+    // run of tiles so A row-panels are re-read from that XCD's L2.
+    int wg;
+    {
+        const int orig = blockIdx.x, xcd = orig & 7, q = n_wg >> 3, r = n_wg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int tm = wg / tiles_n, tn = wg % tiles_n;
+    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+    const bf16_t* Ag = AK ? A + m0 * lda : A + m0;          // step along k: +BK (k-major) or +BK*lda
+    const bf16_t* Bg = BKM ? B + n0 * ldb : B + n0;
+    const int64_t a_step = AK ? BK : (int64_t)BK * lda;
+    const int64_t b_step = BKM ? BK : (int64_t)BK * ldb;
+    const int wm = (wid >> 1) * 64, wn = (wid & 1) * 64;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+
+    const int nk = K / BK;
+    stage_tile<AK>(Ag, lda, smem, wid, lane);
+    stage_tile<BKM>(Bg, ldb, smem + TILE_BYTES, wid, lane);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA for tile kt has landed
+        __syncthreads();                                    // everyone's has; and tile kt-1 is no longer read
+        char* cur = smem + (kt & 1) * 2 * TILE_BYTES;
+        if (kt + 1 < nk) {
+            char* nxt = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
+            stage_tile<AK>(Ag + (kt + 1) * a_step, lda, nxt, wid, lane);
+            stage_tile<BKM>(Bg + (kt + 1) * b_step, ldb, nxt + TILE_BYTES, wid, lane);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = load_frag<AK>(cur, wm + 16 * i, s, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = load_frag<BKM>(cur + TILE_BYTES, wn + 16 * j, s, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            epi_store4<bf16_t>(e, m0 + wm + 16 * i + 4 * (lane >> 4), n0 + wn + 16 * j + (lane & 15), acc[i][j]);
+}
+
+// =============================================================================================
+// Generic path: any shape; operands f32 or bf16 converted to an f32 LDS image [k][m], stride 144.
+// =============================================================================================
+#define GBM 128
+#define GBN 128
+#define GBK 16
+#define GLD 144   // 128 + 16: lanes l and l+16 (next k) land on disjoint bank halves for ds_read_b32
+
+template <typename T, bool KMAJOR>
+__device__ __forceinline__ void generic_stage(const T* __restrict__ g, int64_t ld, int64_t r0, int64_t rows, int64_t k0,
+                                              int64_t K, float* tile, int tid) {
+#pragma unroll
+    for (int i = 0; i < (GBM * GBK) / 256; ++i) {
+        const int e = tid + 256 * i;
+        int r, k;
+        if (KMAJOR) { r = e / GBK; k = e % GBK; } else { k = e / GBM; r = e % GBM; }
+        const int64_t gr = r0 + r, gk = k0 + k;
+        float v = 0.f;
+        if (gr < rows && gk < K) v = to_f32(KMAJOR ? g[gr * ld + gk] : g[gk * ld + gr]);
+        tile[k * GLD + r] = v;
+    }
+}
+
+template <typename T, bool AK, bool BKM>
+__global__ void __launch_bounds__(256)
+gemm_generic_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb, int64_t K, EpiDev e) {
+    __shared__ float As[GBK * GLD];
+    __shared__ float Bs[GBK * GLD];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t m0 = (int64_t)blockIdx.y * GBM, n0 = (int64_t)blockIdx.x * GBN;
+    const int wm = (wid >> 1) * 64, wn = (wid & 1) * 64;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+    for (int64_t k0 = 0; k0 < K; k0 += GBK) {
+        __syncthreads();
+        generic_stage<T, AK>(A, lda, m0, e.M, k0, K, As, tid);
+        generic_stage<T, BKM>(B, ldb, n0, e.N, k0, K, Bs, tid);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < GBK / 4; ++s) {
+            const int kk = 4 * s + (lane >> 4);
+            float af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = As[kk * GLD + wm + 16 * i + (lane & 15)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = Bs[kk * GLD + wn + 16 * j + (lane & 15)];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            epi_store4<T>(e, m0 + wm + 16 * i + 4 * (lane >> 4), n0 + wn + 16 * j + (lane & 15), acc[i][j]);
+}
+
+static int g_force_generic = 0;
+extern "C" void vaw_debug_force_generic_gemm(int on) { g_force_generic = on; }
+
+extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int64_t N, int64_t K, const void* A,
+                        int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const vaw_epilogue* ep,
+                        vaw_stream stream) {
+    VAW_CHECK_ARG(M > 0 && N > 0 && K > 0 && A && B && C, "gemm: bad sizes M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
+    VAW_CHECK_ARG(lda >= (a_kmajor ? K : M) && ldb >= (b_kmajor ? K : N) && ldc >= N, "gemm: leading dimension too small");
+    EpiDev e{};
+    e.alpha = 1.f;
+    if (ep) {
+        e.bias = ep->bias; e.act = ep->act; e.aux_in = ep->aux_in; e.aux_out = ep->aux_out; e.gate = ep->gate;
+        e.gate_ld = ep->gate_ld; e.resid = ep->resid; e.rowadd = ep->rowadd; e.rpb = ep->rows_per_batch;
+        e.alpha = ep->alpha; e.beta = ep->beta; e.out_f32 = ep->out_f32;
+    }
+    VAW_CHECK_ARG(e.act >= 0 && e.act <= 2, "gemm: unknown act %d", e.act);
+    VAW_CHECK_ARG(e.act != 2 || e.aux_in, "gemm: act=2 needs aux_in");
+    VAW_CHECK_ARG(!(e.gate || e.rowadd) || e.rpb > 0, "gemm: gate/rowadd need rows_per_batch");
+    VAW_CHECK_ARG(e.beta == 0.f || e.out_f32 || dt == VAW_F32, "gemm: beta needs f32 output");
+    if (e.rpb <= 0) e.rpb = 1;
+    if (dt == VAW_F32) e.out_f32 = 1;
+    e.M = M; e.N = N; e.ldc = ldc; e.C = C;
+    hipStream_t s = (hipStream_t)stream;
+
+    const bool fast = dt == VAW_BF16 && !g_force_generic && M % BM == 0 && N % BN == 0 && K % BK == 0 && lda % 8 == 0 &&
+                      ldb % 8 == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0;
+    if (fast) {
+        const int tiles_n = (int)(N / BN);
+        const int64_t n_wg = (M / BM) * tiles_n;
+        VAW_CHECK_ARG(n_wg < (1LL << 31), "gemm: grid too large");
+        const size_t lds = 4 * TILE_BYTES;
+        const bf16_t* a = (const bf16_t*)A;
+        const bf16_t* b = (const bf16_t*)B;
+#define LAUNCH_FAST(AKv, BKv)                                                                                        \
+    do {                                                                                                             \
+        static bool attr_done = false;                                                                               \
+        if (!attr_done) {                                                                                            \
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AKv, BKv>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)lds);                                                                           \
+            attr_done = true;                                                                                        \
+        }                                                                                                            \
+        gemm_bf16_kernel<AKv, BKv><<<(int)n_wg, 256, lds, s>>>(a, lda, b, ldb, (int)K, tiles_n, (int)n_wg, e);       \
+    } while (0)
+        if (a_kmajor && b_kmajor) LAUNCH_FAST(true, true);
+        else if (a_kmajor && !b_kmajor) LAUNCH_FAST(true, false);
+        else if (!a_kmajor && b_kmajor) LAUNCH_FAST(false, true);
+        else LAUNCH_FAST(false, false);
+        VAW_CHECK_LAUNCH("gemm_bf16");
+        return VAW_OK;
+    }
+    dim3 grid(ceil_div(N, GBN), ceil_div(M, GBM));
+#define LAUNCH_GEN(T, AKv, BKv) \
+    gemm_generic_kernel<T, AKv, BKv><<<grid, 256, 0, s>>>((const T*)A, lda, (const T*)B, ldb, K, e)
+#define LAUNCH_GEN_T(T)                                          \
+    do {                                                         \
+        if (a_kmajor && b_kmajor) LAUNCH_GEN(T, true, true);     \
+        else if (a_kmajor && !b_kmajor) LAUNCH_GEN(T, true, false); \
+        else if (!a_kmajor && b_kmajor) LAUNCH_GEN(T, false, true); \
+        else LAUNCH_GEN(T, false, false);                        \
+    } while (0)
+    if (dt == VAW_F32) LAUNCH_GEN_T(float);
+    else LAUNCH_GEN_T(bf16_t);
+    VAW_CHECK_LAUNCH("gemm_generic");
+    return VAW_OK;
+}

@@ -1,0 +1,272 @@
+// Row-statistics kernels of the DiT block: LayerNorm+adaLN-modulate forward/backward, gated-residual
+// backward, and column sums (bias gradients).  All HBM-bound: one wave owns one token row, the row lives
+// in registers between the statistics passes (one read of x, one write of the output), reductions are
+// wavefront shuffles, and per-sample sums over tokens are combined through LDS in a fixed wave order
+// (bitwise reproducible; no float atomics).
+#include "common.h"
+
+// NV = number of 256-column slabs a lane walks (D <= 256*NV), D % 4 == 0.
+template <typename T, int NV>
+__global__ void __launch_bounds__(256)
+ln_modulate_fwd_kernel(const float* __restrict__ x, const float* __restrict__ shift, const float* __restrict__ scale,
+                       int64_t mod_ld, T* __restrict__ out, float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                       int64_t M, int Tt, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int b = (int)(row / Tt);
+    const float* xr = x + row * D;
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        v[i] = c < D ? load4(xr + c) : f32x4{0, 0, 0, 0};
+        s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+            f32x4 d = v[i] - mean;
+            q += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    if (lane == 0) {
+        mean_out[row] = mean;
+        rstd_out[row] = rstd;
+    }
+    const float* sh = shift + (int64_t)b * mod_ld;
+    const float* sc = scale + (int64_t)b * mod_ld;
+    T* orow = out + row * D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+            f32x4 xh = (v[i] - mean) * rstd;
+            store4(orow + c, xh * (1.f + load4(sc + c)) + load4(sh + c));
+        }
+    }
+}
+
+// One block per sample; NW waves stride over that sample's T rows.
+template <typename T, int NV, bool GATE_ONLY>
+__global__ void __launch_bounds__(1024)
+row_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ x, const float* __restrict__ mean,
+               const float* __restrict__ rstd, const float* __restrict__ scale, int64_t mod_ld,
+               const float* __restrict__ dres_in, float* __restrict__ dx, float* __restrict__ dshift,
+               float* __restrict__ dscale, int64_t dmod_ld, int Tt, int D,
+               // GATE_ONLY operands
+               const float* __restrict__ dres, const T* __restrict__ y, const float* __restrict__ gate,
+               T* __restrict__ dy, float* __restrict__ dgate) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][D]
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int b = blockIdx.x;
+    f32x4 acc0[NV], acc1[NV], sc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        acc0[i] = f32x4{0, 0, 0, 0};
+        acc1[i] = f32x4{0, 0, 0, 0};
+        const int c = (i * 64 + lane) * 4;
+        const float* src = GATE_ONLY ? gate : scale;
+        sc[i] = c < D ? load4(src + (int64_t)b * mod_ld + c) : f32x4{0, 0, 0, 0};
+    }
+    for (int t = wid; t < Tt; t += nw) {
+        const int64_t row = (int64_t)b * Tt + t;
+        if (GATE_ONLY) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = (i * 64 + lane) * 4;
+                if (c < D) {
+                    f32x4 g = load4(dres + row * D + c);
+                    f32x4 yv = load4(y + row * D + c);
+                    store4(dy + row * D + c, g * sc[i]);
+                    acc0[i] += g * yv;
+                }
+            }
+        } else {
+            const float mu = mean[row], rs = rstd[row];
+            f32x4 g[NV], xh[NV];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = (i * 64 + lane) * 4;
+                if (c < D) {
+                    f32x4 d = load4(dout + row * D + c);
+                    xh[i] = (load4(x + row * D + c) - mu) * rs;
+                    acc0[i] += d;            // dshift
+                    acc1[i] += d * xh[i];    // dscale
+                    g[i] = d * (1.f + sc[i]);
+                    s1 += g[i][0] + g[i][1] + g[i][2] + g[i][3];
+                    f32x4 gx = g[i] * xh[i];
+                    s2 += gx[0] + gx[1] + gx[2] + gx[3];
+                } else {
+                    g[i] = xh[i] = f32x4{0, 0, 0, 0};
+                }
+            }
+            const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = (i * 64 + lane) * 4;
+                if (c < D) {
+                    f32x4 r = (g[i] - c1 - xh[i] * c2) * rs;
+                    if (dres_in) r += load4(dres_in + row * D + c);
+                    store4(dx + row * D + c, r);
+                }
+            }
+        }
+    }
+    // fixed-order combine of the per-wave column sums
+    float* s0 = lds;
+    float* s1p = lds + D;
+    for (int i = threadIdx.x; i < 2 * D; i += blockDim.x) lds[i] = 0.f;
+    __syncthreads();
+    for (int w = 0; w < nw; ++w) {
+        if (wid == w) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = (i * 64 + lane) * 4;
+                if (c < D) {
+                    store4(s0 + c, load4(s0 + c) + acc0[i]);
+                    if (!GATE_ONLY) store4(s1p + c, load4(s1p + c) + acc1[i]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
+        if (GATE_ONLY) {
+            dgate[(int64_t)b * dmod_ld + c] = s0[c];
+        } else {
+            dshift[(int64_t)b * dmod_ld + c] = s0[c];
+            dscale[(int64_t)b * dmod_ld + c] = s1p[c];
+        }
+    }
+}
+
+static int pick_nv(int D) { return (D + 255) / 256; }
+static int pick_block(int Tt) {
+    int nw = Tt < 16 ? Tt : 16;
+    if (nw < 1) nw = 1;
+    return nw * 64;
+}
+
+#define DISPATCH_NV(nv, CALL)                                       \
+    switch (nv) {                                                   \
+        case 1: { constexpr int NV = 1; CALL; } break;              \
+        case 2: { constexpr int NV = 2; CALL; } break;              \
+        case 3: { constexpr int NV = 3; CALL; } break;              \
+        case 4: { constexpr int NV = 4; CALL; } break;              \
+        case 5: { constexpr int NV = 5; CALL; } break;              \
+        case 6: { constexpr int NV = 6; CALL; } break;              \
+        default: { constexpr int NV = 8; CALL; } break;             \
+    }
+
+extern "C" int vaw_ln_modulate_fwd(vaw_dtype dt, const float* x, const float* shift, const float* scale, int64_t mod_ld,
+                                   void* out, float* mean, float* rstd, int B, int T, int D, float eps,
+                                   vaw_stream stream) {
+    VAW_CHECK_ARG(B > 0 && T > 0 && D > 0 && D % 4 == 0 && D <= 2048 && mod_ld % 4 == 0,
+                  "ln_modulate_fwd: need D%%4==0, D<=2048, mod_ld%%4==0 (D=%d)", D);
+    const int64_t M = (int64_t)B * T;
+    const int grid = ceil_div(M, 4);
+    hipStream_t s = (hipStream_t)stream;
+    if (dt == VAW_F32) {
+        DISPATCH_NV(pick_nv(D), (ln_modulate_fwd_kernel<float, NV><<<grid, 256, 0, s>>>(x, shift, scale, mod_ld, (float*)out, mean, rstd, M, T, D, eps)));
+    } else {
+        DISPATCH_NV(pick_nv(D), (ln_modulate_fwd_kernel<bf16_t, NV><<<grid, 256, 0, s>>>(x, shift, scale, mod_ld, (bf16_t*)out, mean, rstd, M, T, D, eps)));
+    }
+    VAW_CHECK_LAUNCH("ln_modulate_fwd");
+    return VAW_OK;
+}
+
+extern "C" int vaw_ln_modulate_bwd(vaw_dtype dt, const void* dout, const float* x, const float* mean, const float* rstd,
+                                   const float* scale, int64_t mod_ld, const float* dres_in, float* dx, float* dshift,
+                                   float* dscale, int64_t dmod_ld, int B, int T, int D, vaw_stream stream) {
+    VAW_CHECK_ARG(B > 0 && T > 0 && D > 0 && D % 4 == 0 && D <= 2048 && mod_ld % 4 == 0,
+                  "ln_modulate_bwd: need D%%4==0, D<=2048, mod_ld%%4==0 (D=%d)", D);
+    hipStream_t s = (hipStream_t)stream;
+    const int block = pick_block(T);
+    const size_t lds = 2 * (size_t)D * sizeof(float);
+    if (dt == VAW_F32) {
+        DISPATCH_NV(pick_nv(D), (row_bwd_kernel<float, NV, false><<<B, block, lds, s>>>((const float*)dout, x, mean, rstd, scale, mod_ld, dres_in, dx, dshift, dscale, dmod_ld, T, D, nullptr, nullptr, nullptr, nullptr, nullptr)));
+    } else {
+        DISPATCH_NV(pick_nv(D), (row_bwd_kernel<bf16_t, NV, false><<<B, block, lds, s>>>((const bf16_t*)dout, x, mean, rstd, scale, mod_ld, dres_in, dx, dshift, dscale, dmod_ld, T, D, nullptr, nullptr, nullptr, nullptr, nullptr)));
+    }
+    VAW_CHECK_LAUNCH("ln_modulate_bwd");
+    return VAW_OK;
+}
+
+extern "C" int vaw_gate_bwd(vaw_dtype dt, const float* dres, const void* y, const float* gate, int64_t mod_ld, void* dy,
+                            float* dgate, int64_t dmod_ld, int B, int T, int D, vaw_stream stream) {
+    VAW_CHECK_ARG(B > 0 && T > 0 && D > 0 && D % 4 == 0 && D <= 2048 && mod_ld % 4 == 0,
+                  "gate_bwd: need D%%4==0, D<=2048, mod_ld%%4==0 (D=%d)", D);
+    hipStream_t s = (hipStream_t)stream;
+    const int block = pick_block(T);
+    const size_t lds = 2 * (size_t)D * sizeof(float);
+    if (dt == VAW_F32) {
+        DISPATCH_NV(pick_nv(D), (row_bwd_kernel<float, NV, true><<<B, block, lds, s>>>(nullptr, nullptr, nullptr, nullptr, nullptr, mod_ld, nullptr, nullptr, nullptr, nullptr, dmod_ld, T, D, dres, (const float*)y, gate, (float*)dy, dgate)));
+    } else {
+        DISPATCH_NV(pick_nv(D), (row_bwd_kernel<bf16_t, NV, true><<<B, block, lds, s>>>(nullptr, nullptr, nullptr, nullptr, nullptr, mod_ld, nullptr, nullptr, nullptr, nullptr, dmod_ld, T, D, dres, (const bf16_t*)y, gate, (bf16_t*)dy, dgate)));
+    }
+    VAW_CHECK_LAUNCH("gate_bwd");
+    return VAW_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Column sums: out[n] = beta*out[n] + sum_m X[m,n].  Stage 1: 256 columns x 512 rows per block, four row
+// groups folded in LDS, one partial row per row-block written to the workspace.  Stage 2: the partial rows
+// are added in a fixed order.  No float atomics: bias gradients are bitwise reproducible.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+colsum_partial_kernel(const T* __restrict__ X, int64_t M, int64_t N, int64_t ldx, float* __restrict__ part_out) {
+    __shared__ __attribute__((aligned(16))) float part[4][256];
+    const int cg = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int64_t col = (int64_t)blockIdx.x * 256 + cg * 4;
+    const int64_t r0 = (int64_t)blockIdx.y * 512;
+    const int64_t r1 = r0 + 512 < M ? r0 + 512 : M;
+    f32x4 acc = {0, 0, 0, 0};
+    if (col < N) {
+        if (col + 4 <= N) {
+            for (int64_t r = r0 + rg; r < r1; r += 4) acc += load4(X + r * ldx + col);
+        } else {
+            for (int64_t r = r0 + rg; r < r1; r += 4)
+                for (int j = 0; j < 4 && col + j < N; ++j) acc[j] += to_f32(X[r * ldx + col + j]);
+        }
+    }
+    store4(&part[rg][cg * 4], acc);
+    __syncthreads();
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c < N)
+        part_out[(int64_t)blockIdx.y * N + c] =
+            ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, int64_t RB, int64_t N, float* __restrict__ out, float beta) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    float acc = 0.f;
+    for (int64_t r = 0; r < RB; ++r) acc += part[r * N + c];
+    out[c] = (beta != 0.f ? beta * out[c] : 0.f) + acc;
+}
+
+extern "C" int64_t vaw_colsum_workspace_floats(int64_t M, int64_t N) { return ((M + 511) / 512) * N; }
+
+extern "C" int vaw_colsum(vaw_dtype dt, const void* X, int64_t M, int64_t N, int64_t ldx, float* out, float beta,
+                          float* workspace, int64_t workspace_floats, vaw_stream stream) {
+    VAW_CHECK_ARG(M > 0 && N > 0 && ldx >= N, "colsum: bad sizes");
+    VAW_CHECK_ARG((ldx % 4 == 0) && (((uintptr_t)X & 15) == 0), "colsum: X must be 16-byte aligned with ldx%%4==0");
+    const int64_t RB = (M + 511) / 512;
+    VAW_CHECK_ARG(workspace && workspace_floats >= RB * N, "colsum: workspace too small (%ld < %ld floats)",
+                  (long)workspace_floats, (long)(RB * N));
+    VAW_CHECK_ARG(RB < 65536, "colsum: M too large");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(ceil_div(N, 256), (int)RB);
+    if (dt == VAW_F32) colsum_partial_kernel<float><<<grid, 256, 0, s>>>((const float*)X, M, N, ldx, workspace);
+    else colsum_partial_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)X, M, N, ldx, workspace);
+    colsum_final_kernel<<<ceil_div(N, 256), 256, 0, s>>>(workspace, RB, N, out, beta);
+    VAW_CHECK_LAUNCH("colsum");
+    return VAW_OK;
+}

@@ -1,0 +1,460 @@
+"""DiT denoiser on hand-written gfx950 kernels, drop-in for the reference's `models/dit.py`.
+
+Same constructor arguments, parameter names (state_dict keys), initialisation and call protocol as the
+reference (`DiT.forward(x, t, y) -> (out, None)`, models/dit.py:157-280; presets :361-375), but nothing in
+forward/backward is a torch op: the module owns a flat parameter buffer (flat.py) and drives libvaw_hip.so
+through one autograd node whose backward is written out by hand (no autograd graph over the blocks).
+
+Data layout in HBM (B images, T tokens, D hidden, M = B*T rows):
+  residual stream   f32 [M, D]            one buffer per LayerNorm input (2 per block), kept for backward
+  GEMM operands     act dtype [M, *]      bf16 in throughput mode, f32 in parity mode
+  adaLN modulation  f32 [B, (6L+2) D]     ONE GEMM for all blocks + final layer; kernels take (ptr, row stride)
+  weights           flat f32 master + flat bf16 shadow; all adaLN weights contiguous so that GEMM sees one matrix
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import ops
+from ._lib import BF16, F32, ptr
+from .flat import FlatModule
+
+__all__ = ["DiT", "DiT_S", "DiT_B", "DiT_L", "DiT_XL", "DiT_models"]
+
+
+def _sincos_1d(dim, pos):
+    omega = 1.0 / 10000 ** (np.arange(dim // 2, dtype=np.float64) / (dim / 2.0))
+    ang = np.einsum("m,d->md", pos.reshape(-1), omega)
+    return np.concatenate([np.sin(ang), np.cos(ang)], axis=1)
+
+
+def get_2d_sincos_pos_embed(dim, grid_size):
+    """Frozen 2-D sin-cos table, models/dit.py:307-354 (w index first, float32 grid, float64 angles)."""
+    gh = np.arange(grid_size, dtype=np.float32)
+    gw = np.arange(grid_size, dtype=np.float32)
+    grid = np.stack(np.meshgrid(gw, gh), axis=0).reshape([2, 1, grid_size, grid_size])
+    return np.concatenate([_sincos_1d(dim // 2, grid[0]), _sincos_1d(dim // 2, grid[1])], axis=1)
+
+
+class _Holder(nn.Module):
+    """Parameter container that is never called."""
+
+    def forward(self, *a, **k):
+        raise RuntimeError("parameter holder: the DiT engine runs the arithmetic")
+
+
+class _PatchEmbed(_Holder):
+    def __init__(self, img_size, patch_size, in_chans, embed_dim):
+        super().__init__()
+        self.patch_size = (patch_size, patch_size)
+        self.num_patches = (img_size // patch_size) ** 2
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size, bias=True)
+
+
+class _TimestepEmbedder(_Holder):
+    def __init__(self, hidden, freq=256):
+        super().__init__()
+        self.mlp = nn.Sequential(nn.Linear(freq, hidden), nn.SiLU(), nn.Linear(hidden, hidden))
+        self.frequency_embedding_size = freq
+
+
+class _LabelEmbedder(_Holder):
+    def __init__(self, num_classes, hidden, dropout_prob):
+        super().__init__()
+        self.embedding_table = nn.Embedding(num_classes + int(dropout_prob > 0), hidden)
+        self.num_classes, self.dropout_prob = num_classes, dropout_prob
+
+
+class _Attention(_Holder):
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.num_heads = heads
+        self.qkv = nn.Linear(dim, 3 * dim, bias=True)
+        self.proj = nn.Linear(dim, dim)
+
+
+class _Mlp(_Holder):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.act = nn.GELU(approximate="tanh")
+        self.fc2 = nn.Linear(hidden, dim)
+
+
+class _Block(_Holder):
+    def __init__(self, dim, heads, mlp_ratio):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, elementwise_affine=False, eps=1e-6)
+        self.attn = _Attention(dim, heads)
+        self.norm2 = nn.LayerNorm(dim, elementwise_affine=False, eps=1e-6)
+        self.mlp = _Mlp(dim, int(dim * mlp_ratio))
+        self.adaLN_modulation = nn.Sequential(nn.SiLU(), nn.Linear(dim, 6 * dim, bias=True))
+
+
+class _FinalLayer(_Holder):
+    def __init__(self, dim, patch, out_ch):
+        super().__init__()
+        self.norm_final = nn.LayerNorm(dim, elementwise_affine=False, eps=1e-6)
+        self.linear = nn.Linear(dim, patch * patch * out_ch, bias=True)
+        self.adaLN_modulation = nn.Sequential(nn.SiLU(), nn.Linear(dim, 2 * dim, bias=True))
+
+
+class _Workspace:
+    """Activation buffers for one batch size; reused every step (no allocator traffic in the loop)."""
+
+    def __init__(self, m, B, adt):
+        dev = m._flat.device
+        f32, T, D, Lyr = torch.float32, m.T, m.D, m.depth
+        M = B * T
+        e = lambda *s, dtype=adt: torch.empty(*s, device=dev, dtype=dtype)
+        self.B, self.adt, self.gen = B, adt, 0
+        self.tfreq, self.h1, self.h1s = e(B, 256), e(B, D, dtype=f32), e(B, D)
+        self.temb, self.c, self.cs = e(B, D, dtype=f32), e(B, D, dtype=f32), e(B, D)
+        self.mod = e(B, m.mod_cols, dtype=f32)
+        self.xp = e(M, m.Kp)
+        self.xres = [e(M, D, dtype=f32) for _ in range(2 * Lyr + 1)]   # inputs of LN1/LN2 of each block, + final
+        self.blk = [dict(xm=e(M, D), qkv=e(M, 3 * D), ao=e(M, D), lse=e(B * m.num_heads * T, dtype=f32), y1=e(M, D),
+                         xm2=e(M, D), hpre=e(M, m.Dm), a=e(M, m.Dm), y2=e(M, D),
+                         mean1=e(M, dtype=f32), rstd1=e(M, dtype=f32), mean2=e(M, dtype=f32), rstd2=e(M, dtype=f32))
+                    for _ in range(Lyr)]
+        self.xf, self.meanf, self.rstdf = e(M, D), e(M, dtype=f32), e(M, dtype=f32)
+        self.otok = e(M, m.No, dtype=f32)
+        # backward scratch (shared by all blocks)
+        self.dotok, self.dres, self.dD = e(M, m.No), e(M, D, dtype=f32), e(M, D)
+        self.dDm, self.dqkv, self.dao = e(M, m.Dm), e(M, 3 * D), e(M, D)
+        self.delta = e(B * m.num_heads * T, dtype=f32)
+        self.dmod, self.dmod_a = e(B, m.mod_cols, dtype=f32), e(B, m.mod_cols)
+        self.dcs, self.dc, self.dc_a = e(B, D, dtype=f32), e(B, D, dtype=f32), e(B, D)
+        self.dh1s, self.dh1, self.dh1_a = e(B, D, dtype=f32), e(B, D, dtype=f32), e(B, D)
+        self.dxp = e(M, m.Kp, dtype=f32)
+
+
+class _DiTFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, model, x, t, y):
+        out = model._forward_impl(x, t, y)
+        ctx.model, ctx.gen, ctx.need_dx = model, model._ws_cur.gen, x.requires_grad
+        ctx.x_shape = x.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        m = ctx.model
+        if m._ws_cur.gen != ctx.gen:
+            raise L.VawError("DiT backward: activations were overwritten by a later forward of the same batch size")
+        dx = m._backward_impl(dout.contiguous(), ctx.need_dx)
+        return torch.zeros_like(m._anchor), None, dx, None, None
+
+
+class DiT(FlatModule):
+    def __init__(self, image_size=32, patch_size=2, in_channels=4, hidden_size=1152, depth=28, num_heads=16,
+                 mlp_ratio=4.0, class_dropout_prob=0.1, num_classes=1000, learn_sigma=False, learn_align=False,
+                 encoder_depth=8, z_dims=768, projector_dim=2048, compute_dtype="bf16"):
+        super().__init__()
+        if learn_align:
+            raise NotImplementedError("learn_align (REPA feature alignment) is outside the hot path (SURVEY §2.1 row 12)")
+        assert hidden_size % num_heads == 0 and hidden_size % 4 == 0
+        self.learn_sigma, self.learn_align = learn_sigma, learn_align
+        self.in_channels = in_channels
+        self.out_channels = in_channels * 2 if learn_sigma else in_channels
+        self.patch_size, self.num_heads, self.depth = patch_size, num_heads, depth
+        self.image_size = image_size
+        self.encoder_depth = encoder_depth
+        # same registration order as the reference => same weights under the same torch seed
+        self.x_embedder = _PatchEmbed(image_size, patch_size, in_channels, hidden_size)
+        self.t_embedder = _TimestepEmbedder(hidden_size)
+        self.y_embedder = _LabelEmbedder(num_classes, hidden_size, class_dropout_prob)
+        self.pos_embed = nn.Parameter(torch.zeros(1, self.x_embedder.num_patches, hidden_size), requires_grad=False)
+        self.blocks = nn.ModuleList([_Block(hidden_size, num_heads, mlp_ratio) for _ in range(depth)])
+        self.projectors = None
+        self.final_layer = _FinalLayer(hidden_size, patch_size, self.out_channels)
+        self.initialize_weights()
+        # engine geometry
+        self.D, self.T = hidden_size, self.x_embedder.num_patches
+        self.Dm = int(hidden_size * mlp_ratio)
+        self.Kp = in_channels * patch_size * patch_size
+        self.No = patch_size * patch_size * self.out_channels
+        self.mod_cols = (6 * depth + 2) * hidden_size
+        self.set_compute_dtype(compute_dtype)
+        self._anchor = torch.zeros(1, requires_grad=True)
+        self._ws, self._ws_cur = {}, None
+        self.grad_ready_hook = None      # callable(stage:int) -> None; stage counts down from depth+1 to 0
+
+    # ---- reference surface -----------------------------------------------------------------
+    def initialize_weights(self):
+        """models/dit.py:206-241 (xavier on every Linear, adaLN-Zero, frozen sin-cos pos_embed)."""
+        def basic(mod):
+            if isinstance(mod, nn.Linear):
+                nn.init.xavier_uniform_(mod.weight)
+                if mod.bias is not None:
+                    nn.init.constant_(mod.bias, 0)
+        self.apply(basic)
+        pe = get_2d_sincos_pos_embed(self.pos_embed.shape[-1], int(self.x_embedder.num_patches ** 0.5))
+        self.pos_embed.data.copy_(torch.from_numpy(pe).float().unsqueeze(0))
+        w = self.x_embedder.proj.weight.data
+        nn.init.xavier_uniform_(w.view([w.shape[0], -1]))
+        nn.init.constant_(self.x_embedder.proj.bias, 0)
+        nn.init.normal_(self.y_embedder.embedding_table.weight, std=0.02)
+        nn.init.normal_(self.t_embedder.mlp[0].weight, std=0.02)
+        nn.init.normal_(self.t_embedder.mlp[2].weight, std=0.02)
+        for blk in self.blocks:
+            nn.init.constant_(blk.adaLN_modulation[-1].weight, 0)
+            nn.init.constant_(blk.adaLN_modulation[-1].bias, 0)
+        nn.init.constant_(self.final_layer.adaLN_modulation[-1].weight, 0)
+        nn.init.constant_(self.final_layer.adaLN_modulation[-1].bias, 0)
+        nn.init.constant_(self.final_layer.linear.weight, 0)
+        nn.init.constant_(self.final_layer.linear.bias, 0)
+
+    def set_compute_dtype(self, name):
+        """'bf16' (throughput: bf16 MFMA, f32 accumulate) or 'fp32' (parity with the CPU reference)."""
+        name = {"float32": "fp32", "f32": "fp32", "bfloat16": "bf16"}.get(name, name)
+        if name not in ("bf16", "fp32"):
+            raise ValueError(f"compute_dtype must be 'bf16' or 'fp32', got {name}")
+        self.compute_dtype = name
+        self._dt = BF16 if name == "bf16" else F32
+        self._ws = {}
+
+    def _flat_groups(self):
+        ada_w = [f"blocks.{i}.adaLN_modulation.1.weight" for i in range(self.depth)] + ["final_layer.adaLN_modulation.1.weight"]
+        ada_b = [f"blocks.{i}.adaLN_modulation.1.bias" for i in range(self.depth)] + ["final_layer.adaLN_modulation.1.bias"]
+        return [ada_w, ada_b]
+
+    def _apply(self, fn, recurse=True):
+        r = super()._apply(fn, recurse)
+        self._anchor = fn(self._anchor.detach()).requires_grad_(True)
+        self._ws = {}
+        return r
+
+    def grad_stage_bounds(self):
+        """stage -> [start, end) of the flat gradient buffer that is final when backward reports `stage`
+        (depth+1: head done; l+1: block l done; 0: embedders and adaLN done).  Used for all-reduce buckets."""
+        self.ensure_flat()
+        off = lambda n: self._flat_offsets[n][0]
+        first = [off(f"blocks.{l}.attn.qkv.weight") for l in range(self.depth)] + [off("final_layer.linear.weight")]
+        b = {self.depth + 1: (first[-1], self._flat_n_train), 0: (0, first[0])}
+        for l in range(self.depth):
+            b[l + 1] = (first[l], first[l + 1])
+        return b
+
+    def unpatchify(self, x):
+        c, p = self.out_channels, self.patch_size
+        h = w = int(x.shape[1] ** 0.5)
+        assert h * w == x.shape[1]
+        x = x.float().contiguous()
+        img = torch.empty(x.shape[0], c, h * p, w * p, device=x.device, dtype=torch.float32)
+        L.check(L.lib().vaw_unpatchify(F32, ptr(x), ptr(img), x.shape[0], c, h * p, w * p, p, L.stream_ptr()), "vaw_unpatchify")
+        return img
+
+    def forward(self, x, t, y, **kwargs):
+        """x [N,C,H,W] f32, t [N] (float timesteps, already rescaled), y [N] int64 -> (eps [N,C_out,H,W] f32, None)."""
+        L.need_cuda(x, t, y)
+        out = _DiTFn.apply(self._anchor, self, x, t, y)
+        return out, None
+
+    # ---- engine ----------------------------------------------------------------------------
+    def _w(self, name):
+        """device address of a parameter in the dtype the kernels read (bf16 shadow or f32 master)."""
+        o, _ = self._flat_offsets[name]
+        return self._wbase + o * self._wsize
+
+    def _g(self, name):
+        o, _ = self._flat_offsets[name]
+        return self._gbase + 4 * o
+
+    def _p32(self, name):
+        o, _ = self._flat_offsets[name]
+        return self._flat.data_ptr() + 4 * o
+
+    def _prepare(self, B):
+        self.ensure_flat()
+        if self._dt == BF16:
+            sh = self.shadow_bf16()
+            self._wbase, self._wsize = sh.data_ptr(), 2
+        else:
+            self._wbase, self._wsize = self._flat.data_ptr(), 4
+        adt = L.TORCH_DTYPE[self._dt]
+        key = (B, adt)
+        if key not in self._ws:
+            self._ws[key] = _Workspace(self, B, adt)
+        self._ws_cur = self._ws[key]
+        return self._ws_cur
+
+    def _forward_impl(self, x, t, y):
+        B, C, H, W = x.shape
+        assert C == self.in_channels and H == W == self.image_size, f"expected [N,{self.in_channels},{self.image_size},{self.image_size}], got {tuple(x.shape)}"
+        assert t.shape == (B,) and y.shape == (B,) and y.dtype == torch.int64
+        ws = self._prepare(B)
+        ws.gen += 1
+        dt, D, T, Dm, Lyr, ld = self._dt, self.D, self.T, self.Dm, self.depth, self.mod_cols
+        M, lib, st = B * T, L.lib(), L.stream_ptr()
+        x = x.float().contiguous()
+        tf = t.float().contiguous()
+        ye = self.y_embedder
+        if (self.training and ye.dropout_prob > 0):
+            drop = torch.rand(B, device=y.device) < ye.dropout_prob      # reference: dit.py:94-103
+            y = torch.where(drop, ye.num_classes, y)
+        ws.y = y.contiguous()
+        # conditioning vector c = t_emb + y_emb, then every block's modulation in one GEMM
+        L.check(lib.vaw_timestep_embedding(dt, ptr(tf), ptr(ws.tfreq), B, 256, 10000.0, st), "timestep_embedding")
+        ops.gemm(dt, 1, 1, B, D, 256, ptr(ws.tfreq), 256, self._w("t_embedder.mlp.0.weight"), 256, ptr(ws.h1), D,
+                 bias=self._p32("t_embedder.mlp.0.bias"), out_f32=True)
+        L.check(lib.vaw_silu_fwd(dt, ptr(ws.h1), ptr(ws.h1s), B * D, st), "silu")
+        ops.gemm(dt, 1, 1, B, D, D, ptr(ws.h1s), D, self._w("t_embedder.mlp.2.weight"), D, ptr(ws.temb), D,
+                 bias=self._p32("t_embedder.mlp.2.bias"), out_f32=True)
+        L.check(lib.vaw_add_embedding(ptr(ws.temb), self._p32("y_embedder.embedding_table.weight"), ptr(ws.y), ptr(ws.c),
+                                      B, D, ye.embedding_table.num_embeddings, st), "add_embedding")
+        L.check(lib.vaw_silu_fwd(dt, ptr(ws.c), ptr(ws.cs), B * D, st), "silu")
+        ops.gemm(dt, 1, 1, B, ld, D, ptr(ws.cs), D, self._w("blocks.0.adaLN_modulation.1.weight"), D, ptr(ws.mod), ld,
+                 bias=self._p32("blocks.0.adaLN_modulation.1.bias"), out_f32=True)
+        # tokens
+        L.check(lib.vaw_patchify(dt, ptr(x), ptr(ws.xp), B, C, H, W, self.patch_size, st), "patchify")
+        ops.gemm(dt, 1, 1, M, D, self.Kp, ptr(ws.xp), self.Kp, self._w("x_embedder.proj.weight"), self.Kp, ptr(ws.xres[0]), D,
+                 bias=self._p32("x_embedder.proj.bias"), rowadd=self._p32("pos_embed"), rows_per_batch=T, out_f32=True)
+        mod = ptr(ws.mod)
+        for l in range(Lyr):
+            b, pre = ws.blk[l], f"blocks.{l}."
+            mo = mod + 4 * (6 * l * D)
+            xin, xmid, xout = ptr(ws.xres[2 * l]), ptr(ws.xres[2 * l + 1]), ptr(ws.xres[2 * l + 2])
+            ops.ln_modulate_fwd(dt, xin, mo, mo + 4 * D, ld, ptr(b["xm"]), ptr(b["mean1"]), ptr(b["rstd1"]), B, T, D)
+            ops.gemm(dt, 1, 1, M, 3 * D, D, ptr(b["xm"]), D, self._w(pre + "attn.qkv.weight"), D, ptr(b["qkv"]), 3 * D,
+                     bias=self._p32(pre + "attn.qkv.bias"))
+            q = ptr(b["qkv"])
+            es = self._wsize
+            ops.attn_fwd(dt, self._attn_desc(B), q, q + es * D, q + 2 * es * D, ptr(b["ao"]), ptr(b["lse"]))
+            ops.gemm(dt, 1, 1, M, D, D, ptr(b["ao"]), D, self._w(pre + "attn.proj.weight"), D, xmid, D,
+                     bias=self._p32(pre + "attn.proj.bias"), aux_out=ptr(b["y1"]), gate=mo + 4 * 2 * D, gate_ld=ld,
+                     resid=xin, rows_per_batch=T, out_f32=True)
+            ops.ln_modulate_fwd(dt, xmid, mo + 4 * 3 * D, mo + 4 * 4 * D, ld, ptr(b["xm2"]), ptr(b["mean2"]), ptr(b["rstd2"]), B, T, D)
+            ops.gemm(dt, 1, 1, M, Dm, D, ptr(b["xm2"]), D, self._w(pre + "mlp.fc1.weight"), D, ptr(b["a"]), Dm,
+                     bias=self._p32(pre + "mlp.fc1.bias"), act=1, aux_out=ptr(b["hpre"]))
+            ops.gemm(dt, 1, 1, M, D, Dm, ptr(b["a"]), Dm, self._w(pre + "mlp.fc2.weight"), Dm, xout, D,
+                     bias=self._p32(pre + "mlp.fc2.bias"), aux_out=ptr(b["y2"]), gate=mo + 4 * 5 * D, gate_ld=ld,
+                     resid=xmid, rows_per_batch=T, out_f32=True)
+        mo = mod + 4 * (6 * Lyr * D)
+        ops.ln_modulate_fwd(dt, ptr(ws.xres[2 * Lyr]), mo, mo + 4 * D, ld, ptr(ws.xf), ptr(ws.meanf), ptr(ws.rstdf), B, T, D)
+        ops.gemm(dt, 1, 1, M, self.No, D, ptr(ws.xf), D, self._w("final_layer.linear.weight"), D, ptr(ws.otok), self.No,
+                 bias=self._p32("final_layer.linear.bias"), out_f32=True)
+        out = torch.empty(B, self.out_channels, H, W, device=x.device, dtype=torch.float32)
+        L.check(lib.vaw_unpatchify(dt, ptr(ws.otok), ptr(out), B, self.out_channels, H, W, self.patch_size, st), "unpatchify")
+        return out
+
+    def _attn_desc(self, B):
+        d = getattr(self, "_adesc", None)
+        if d is None or d.B != B:
+            d = self._adesc = ops.attn_desc_token_major(B, self.num_heads, self.T, self.D // self.num_heads)
+        return d
+
+    def _wgrad(self, dt, name, dy, x, Nw, Kw, M, beta):
+        """dW[Nw,Kw] (+)= dy[M,Nw]^T x[M,Kw];  db[Nw] (+)= colsum(dy).  name = '<module>.' prefix."""
+        ops.gemm(dt, 0, 0, Nw, Kw, M, dy, Nw, x, Kw, self._g(name + "weight"), Kw, beta=beta, out_f32=True)
+        ops.colsum(dt, dy, M, Nw, Nw, self._g(name + "bias"), beta)
+
+    def _backward_impl(self, dout, need_dx):
+        ws = self._ws_cur
+        B = ws.B
+        dt, D, T, Dm, Lyr, ld = self._dt, self.D, self.T, self.Dm, self.depth, self.mod_cols
+        M, lib, st = B * T, L.lib(), L.stream_ptr()
+        H = W = self.image_size
+        beta = 1.0 if self.grads_live() else 0.0
+        self._gbase = self.flat_grads().data_ptr()
+        hook = self.grad_ready_hook
+        dres, dD, dDm, dmod = ptr(ws.dres), ptr(ws.dD), ptr(ws.dDm), ptr(ws.dmod)
+        mod = ptr(ws.mod)
+        # head: unpatchify^T, final linear, final LN+modulate
+        L.check(lib.vaw_unpatchify_bwd(dt, ptr(dout), ptr(ws.dotok), B, self.out_channels, H, W, self.patch_size, st), "unpatchify_bwd")
+        self._wgrad(dt, "final_layer.linear.", ptr(ws.dotok), ptr(ws.xf), self.No, D, M, beta)
+        ops.gemm(dt, 1, 0, M, D, self.No, ptr(ws.dotok), self.No, self._w("final_layer.linear.weight"), D, dD, D)
+        mo, dmo = mod + 4 * (6 * Lyr * D), dmod + 4 * (6 * Lyr * D)
+        ops.ln_modulate_bwd(dt, dD, ptr(ws.xres[2 * Lyr]), ptr(ws.meanf), ptr(ws.rstdf), mo + 4 * D, ld, 0, dres, dmo, dmo + 4 * D, ld, B, T, D)
+        if hook:
+            hook(Lyr + 1)
+        es = self._wsize
+        for l in reversed(range(Lyr)):
+            b, pre = ws.blk[l], f"blocks.{l}."
+            mo, dmo = mod + 4 * (6 * l * D), dmod + 4 * (6 * l * D)
+            xin, xmid = ptr(ws.xres[2 * l]), ptr(ws.xres[2 * l + 1])
+            # MLP branch
+            ops.gate_bwd(dt, dres, ptr(b["y2"]), mo + 4 * 5 * D, ld, dD, dmo + 4 * 5 * D, ld, B, T, D)
+            self._wgrad(dt, pre + "mlp.fc2.", dD, ptr(b["a"]), D, Dm, M, beta)
+            ops.gemm(dt, 1, 0, M, Dm, D, dD, D, self._w(pre + "mlp.fc2.weight"), Dm, dDm, Dm, act=2, aux_in=ptr(b["hpre"]))
+            self._wgrad(dt, pre + "mlp.fc1.", dDm, ptr(b["xm2"]), Dm, D, M, beta)
+            ops.gemm(dt, 1, 0, M, D, Dm, dDm, Dm, self._w(pre + "mlp.fc1.weight"), D, dD, D)
+            ops.ln_modulate_bwd(dt, dD, xmid, ptr(b["mean2"]), ptr(b["rstd2"]), mo + 4 * 4 * D, ld, dres, dres,
+                                dmo + 4 * 3 * D, dmo + 4 * 4 * D, ld, B, T, D)
+            # attention branch
+            ops.gate_bwd(dt, dres, ptr(b["y1"]), mo + 4 * 2 * D, ld, dD, dmo + 4 * 2 * D, ld, B, T, D)
+            self._wgrad(dt, pre + "attn.proj.", dD, ptr(b["ao"]), D, D, M, beta)
+            ops.gemm(dt, 1, 0, M, D, D, dD, D, self._w(pre + "attn.proj.weight"), D, ptr(ws.dao), D)
+            q, dq = ptr(b["qkv"]), ptr(ws.dqkv)
+            ops.attn_bwd(dt, self._attn_desc(B), q, q + es * D, q + 2 * es * D, ptr(b["ao"]), ptr(ws.dao), ptr(b["lse"]),
+                         ptr(ws.delta), dq, dq + es * D, dq + 2 * es * D)
+            self._wgrad(dt, pre + "attn.qkv.", dq, ptr(b["xm"]), 3 * D, D, M, beta)
+            ops.gemm(dt, 1, 0, M, D, 3 * D, dq, 3 * D, self._w(pre + "attn.qkv.weight"), D, dD, D)
+            ops.ln_modulate_bwd(dt, dD, xin, ptr(b["mean1"]), ptr(b["rstd1"]), mo + 4 * D, ld, dres, dres, dmo, dmo + 4 * D,
+                                ld, B, T, D)
+            if hook:
+                hook(l + 1)
+        # patch embedding: d(x0) = dres
+        if dt == BF16:
+            ops.cast_bf16(ws.dres, ws.dD)
+            dx0 = dD
+        else:
+            dx0 = dres
+        self._wgrad(dt, "x_embedder.proj.", dx0, ptr(ws.xp), D, self.Kp, M, beta)
+        dx = None
+        if need_dx:
+            ops.gemm(dt, 1, 0, M, self.Kp, D, dx0, D, self._w("x_embedder.proj.weight"), self.Kp, ptr(ws.dxp), self.Kp, out_f32=True)
+            dx = torch.empty(B, self.in_channels, H, W, device=dout.device, dtype=torch.float32)
+            L.check(lib.vaw_patchify_bwd(ptr(ws.dxp), ptr(dx), B, self.in_channels, H, W, self.patch_size, st), "patchify_bwd")
+        # conditioning path: adaLN (all blocks at once), label table, timestep MLP
+        if dt == BF16:
+            ops.cast_bf16(ws.dmod, ws.dmod_a)
+            dmod_a = ptr(ws.dmod_a)
+        else:
+            dmod_a = dmod
+        ops.gemm(dt, 0, 0, ld, D, B, dmod_a, ld, ptr(ws.cs), D, self._g("blocks.0.adaLN_modulation.1.weight"), D, beta=beta, out_f32=True)
+        ops.colsum(dt, dmod_a, B, ld, ld, self._g("blocks.0.adaLN_modulation.1.bias"), beta)
+        ops.gemm(dt, 1, 0, B, D, ld, dmod_a, ld, self._w("blocks.0.adaLN_modulation.1.weight"), D, ptr(ws.dcs), D, out_f32=True)
+        L.check(lib.vaw_silu_bwd(ptr(ws.c), ptr(ws.dcs), ptr(ws.dc), B * D, st), "silu_bwd")
+        ye = self.y_embedder.embedding_table
+        L.check(lib.vaw_embedding_bwd(ptr(ws.dc), ptr(ws.y), self._g("y_embedder.embedding_table.weight"), B, D,
+                                      ye.num_embeddings, beta, st), "embedding_bwd")
+        if dt == BF16:
+            ops.cast_bf16(ws.dc, ws.dc_a)
+            dc_a = ptr(ws.dc_a)
+        else:
+            dc_a = ptr(ws.dc)
+        self._wgrad(dt, "t_embedder.mlp.2.", dc_a, ptr(ws.h1s), D, D, B, beta)
+        ops.gemm(dt, 1, 0, B, D, D, dc_a, D, self._w("t_embedder.mlp.2.weight"), D, ptr(ws.dh1s), D, out_f32=True)
+        L.check(lib.vaw_silu_bwd(ptr(ws.h1), ptr(ws.dh1s), ptr(ws.dh1), B * D, st), "silu_bwd")
+        if dt == BF16:
+            ops.cast_bf16(ws.dh1, ws.dh1_a)
+            dh1_a = ptr(ws.dh1_a)
+        else:
+            dh1_a = ptr(ws.dh1)
+        self._wgrad(dt, "t_embedder.mlp.0.", dh1_a, ptr(ws.tfreq), D, 256, B, beta)
+        self.attach_grads()
+        if hook:
+            hook(0)
+        return dx
+
+
+_PRESETS = {"DiT-S": (384, 12, 6), "DiT-B": (768, 12, 12), "DiT-L": (1024, 24, 16), "DiT-XL": (1152, 28, 16)}
+
+
+def _make(name):
+    hidden, depth, heads = _PRESETS[name]
+
+    def build(image_size, patch_size, in_channels, class_dropout_prob, num_classes, learn_sigma, **kwargs):
+        return DiT(image_size=image_size, patch_size=patch_size, in_channels=in_channels, hidden_size=hidden,
+                   depth=depth, num_heads=heads, class_dropout_prob=class_dropout_prob, num_classes=num_classes,
+                   learn_sigma=learn_sigma, **kwargs)
+    build.__name__ = name.replace("-", "_")
+    return build
+
+
+DiT_S, DiT_B, DiT_L, DiT_XL = (_make(n) for n in ("DiT-S", "DiT-B", "DiT-L", "DiT-XL"))
+DiT_models = {"DiT-S": DiT_S, "DiT-B": DiT_B, "DiT-L": DiT_L, "DiT-XL": DiT_XL}

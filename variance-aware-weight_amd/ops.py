@@ -1,0 +1,187 @@
+"""Tensor-level wrappers over the C ABI (include/vaw_hip.h).  Each takes torch CUDA tensors, checks what the
+kernel assumes about them (shape, dtype, contiguity) on the host, and launches on the current stream."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._lib import BF16, F32, AttnDesc, Epilogue, check, need_cuda, ptr, stream_ptr
+
+
+def dt_of(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise L.VawError(f"unsupported activation dtype {t.dtype}")
+
+
+def _f32c(*ts):
+    for t in ts:
+        if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
+            raise L.VawError(f"expected a contiguous float32 tensor, got {t.dtype} contiguous={t.is_contiguous()}")
+
+
+# ---- diffusion objective -----------------------------------------------------------------------
+def qsample(x0, noise, t, tab_a, tab_s):
+    need_cuda(x0, noise, t, tab_a, tab_s)
+    _f32c(x0, noise, tab_a, tab_s)
+    assert noise.shape == x0.shape and t.dtype == torch.int64 and t.shape == (x0.shape[0],)
+    out = torch.empty_like(x0)
+    B = x0.shape[0]
+    check(L.lib().vaw_qsample_fwd(ptr(x0), ptr(noise), ptr(t), ptr(tab_a), ptr(tab_s), tab_a.numel(), ptr(out), B,
+                                  x0.numel() // B, stream_ptr()), "vaw_qsample_fwd")
+    return out
+
+
+def mix_rows(x, y, ca, cb):
+    need_cuda(x, y, ca, cb)
+    _f32c(x, y, ca, cb)
+    assert x.shape == y.shape and ca.shape == cb.shape == (x.shape[0],)
+    out = torch.empty_like(x)
+    B = x.shape[0]
+    check(L.lib().vaw_mix_rows(ptr(x), ptr(y), ptr(ca), ptr(cb), ptr(out), B, x.numel() // B, stream_ptr()), "vaw_mix_rows")
+    return out
+
+
+class _WeightedMSE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model_out, x0, noise, ca, cb, w):
+        need_cuda(model_out, x0, noise, ca, cb, w)
+        model_out = model_out.contiguous()
+        _f32c(model_out, x0, noise, ca, cb, w)
+        B = x0.shape[0]
+        assert model_out.shape == x0.shape == noise.shape and ca.shape == cb.shape == w.shape == (B,)
+        mse = torch.empty(B, device=x0.device, dtype=torch.float32)
+        check(L.lib().vaw_wmse_fwd(ptr(model_out), ptr(x0), ptr(noise), ptr(ca), ptr(cb), ptr(w), ptr(mse), B,
+                                   x0.numel() // B, stream_ptr()), "vaw_wmse_fwd")
+        ctx.save_for_backward(model_out, x0, noise, ca, cb, w)
+        return mse
+
+    @staticmethod
+    def backward(ctx, gmse):
+        model_out, x0, noise, ca, cb, w = ctx.saved_tensors
+        gmse = gmse.contiguous().float()
+        dout = torch.empty_like(model_out)
+        B = x0.shape[0]
+        check(L.lib().vaw_wmse_bwd(ptr(model_out), ptr(x0), ptr(noise), ptr(ca), ptr(cb), ptr(w), ptr(gmse), ptr(dout),
+                                   B, x0.numel() // B, stream_ptr()), "vaw_wmse_bwd")
+        return dout, None, None, None, None, None
+
+
+def weighted_mse(model_out, x0, noise, ca, cb, w):
+    """mse[b] = w[b] * mean((ca[b]*x0 + cb[b]*noise - model_out)^2); differentiable in model_out."""
+    return _WeightedMSE.apply(model_out, x0, noise, ca, cb, w)
+
+
+# ---- dense -------------------------------------------------------------------------------------
+def gemm(dt, a_kmajor, b_kmajor, M, N, K, A, lda, B, ldb, Cp, ldc, *, bias=None, act=0, aux_in=None, aux_out=None,
+         gate=None, gate_ld=0, resid=None, rowadd=None, rows_per_batch=0, alpha=1.0, beta=0.0, out_f32=False):
+    """Raw-pointer GEMM; A, B, Cp, bias... are integers (device addresses).  See vaw_gemm in the header."""
+    e = Epilogue(bias or None, act, aux_in or None, aux_out or None, gate or None, gate_ld, resid or None,
+                 rowadd or None, rows_per_batch, alpha, beta, 1 if out_f32 else 0)
+    check(L.lib().vaw_gemm(dt, 1 if a_kmajor else 0, 1 if b_kmajor else 0, M, N, K, A, lda, B, ldb, Cp, ldc,
+                           C.byref(e), stream_ptr()), "vaw_gemm")
+
+
+def gemm_t(A, B, *, a_kmajor=True, b_kmajor=True, out_dtype=None, bias=None, act=0, aux_in=None, want_aux=False,
+           gate=None, resid=None, rowadd=None, rows_per_batch=0, alpha=1.0, beta=0.0, out=None):
+    """Tensor-level GEMM for tests and small call sites: A, B 2-D contiguous, same dtype."""
+    need_cuda(A, B)
+    assert A.dim() == 2 and B.dim() == 2 and A.is_contiguous() and B.is_contiguous() and A.dtype == B.dtype
+    dt = dt_of(A)
+    M, K = (A.shape if a_kmajor else A.shape[::-1])
+    N, Kb = (B.shape if b_kmajor else B.shape[::-1])
+    assert K == Kb, (A.shape, B.shape, a_kmajor, b_kmajor)
+    out_dtype = out_dtype or A.dtype
+    if out is None:
+        out = torch.empty(M, N, device=A.device, dtype=out_dtype)
+    aux = torch.empty(M, N, device=A.device, dtype=A.dtype) if want_aux else None
+    _f32c(bias, gate, resid, rowadd)
+    gemm(dt, a_kmajor, b_kmajor, M, N, K, ptr(A), A.shape[1], ptr(B), B.shape[1], ptr(out), N, bias=ptr(bias), act=act,
+         aux_in=ptr(aux_in), aux_out=ptr(aux), gate=ptr(gate), gate_ld=(gate.shape[-1] if gate is not None else 0),
+         resid=ptr(resid), rowadd=ptr(rowadd), rows_per_batch=rows_per_batch, alpha=alpha, beta=beta,
+         out_f32=(out.dtype == torch.float32))
+    return (out, aux) if want_aux else out
+
+
+_scratch = {}
+
+
+def scratch_f32(device, n):
+    """Grow-only f32 scratch per device for the fixed-order reductions (column sums, gradient norm)."""
+    t = _scratch.get(device)
+    if t is None or t.numel() < n:
+        t = _scratch[device] = torch.empty(max(n, 1 << 20), device=device, dtype=torch.float32)
+    return t
+
+
+def colsum(dt, X, M, N, ldx, out, beta=0.0, device=None):
+    need = L.lib().vaw_colsum_workspace_floats(M, N)
+    ws = scratch_f32(device or torch.device("cuda", torch.cuda.current_device()), need)
+    check(L.lib().vaw_colsum(dt, X, M, N, ldx, out, beta, ptr(ws), ws.numel(), stream_ptr()), "vaw_colsum")
+
+
+# ---- DiT pieces (raw pointers; shapes are checked by the caller that owns the buffers) ---------------
+def ln_modulate_fwd(dt, x, shift, scale, mod_ld, out, mean, rstd, B, T, D, eps=1e-6):
+    check(L.lib().vaw_ln_modulate_fwd(dt, x, shift, scale, mod_ld, out, mean, rstd, B, T, D, eps, stream_ptr()),
+          "vaw_ln_modulate_fwd")
+
+
+def ln_modulate_bwd(dt, dout, x, mean, rstd, scale, mod_ld, dres_in, dx, dshift, dscale, dmod_ld, B, T, D):
+    check(L.lib().vaw_ln_modulate_bwd(dt, dout, x, mean, rstd, scale, mod_ld, dres_in or None, dx, dshift, dscale,
+                                      dmod_ld, B, T, D, stream_ptr()), "vaw_ln_modulate_bwd")
+
+
+def gate_bwd(dt, dres, y, gate, mod_ld, dy, dgate, dmod_ld, B, T, D):
+    check(L.lib().vaw_gate_bwd(dt, dres, y, gate, mod_ld, dy, dgate, dmod_ld, B, T, D, stream_ptr()), "vaw_gate_bwd")
+
+
+def attn_desc_token_major(B, H, T, hd):
+    """qkv rows [B*T, 3*H*hd] (timm Attention); output rows [B*T, H*hd]."""
+    return AttnDesc(B, H, T, hd, T * 3 * H * hd, hd, 3 * H * hd, 1, T * H * hd, hd, H * hd, 1, hd ** -0.5)
+
+
+def attn_desc_channel_major(B, H, T, ch):
+    """qkv [B, 3*H*ch, T] (UNet QKVAttention, new order); output [B, H*ch, T]."""
+    return AttnDesc(B, H, T, ch, 3 * H * ch * T, ch * T, 1, T, H * ch * T, ch * T, 1, T, ch ** -0.5)
+
+
+def attn_fwd(dt, desc, q, k, v, o, lse):
+    check(L.lib().vaw_attn_fwd(dt, C.byref(desc), q, k, v, o, lse, stream_ptr()), "vaw_attn_fwd")
+
+
+def attn_bwd(dt, desc, q, k, v, o, d_o, lse, delta, dq, dk, dv):
+    check(L.lib().vaw_attn_bwd(dt, C.byref(desc), q, k, v, o, d_o, lse, delta, dq, dk, dv, stream_ptr()), "vaw_attn_bwd")
+
+
+def timestep_embedding(t, dim, dtype=torch.float32, max_period=10000.0):
+    """[cos | sin] embedding (tools/nn.py:103-121).  t: float tensor [B] on the GPU."""
+    need_cuda(t)
+    t = t.float().contiguous()
+    out = torch.empty(t.shape[0], dim, device=t.device, dtype=dtype)
+    check(L.lib().vaw_timestep_embedding(dt_of(out), ptr(t), ptr(out), t.shape[0], dim, max_period, stream_ptr()),
+          "vaw_timestep_embedding")
+    return out
+
+
+# ---- optimizer ---------------------------------------------------------------------------------
+def sumsq(g, out, accumulate=False):
+    ws = scratch_f32(g.device, L.lib().vaw_sumsq_workspace_floats())
+    check(L.lib().vaw_sumsq(ptr(g), g.numel(), ptr(out), 1 if accumulate else 0, ptr(ws), stream_ptr()), "vaw_sumsq")
+
+
+def adamw_ema_step(p, g, m, v, ema, shadow, lr, beta1, beta2, eps, wd, step, ema_decay, sumsq_t, clip, zero_grad):
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    check(L.lib().vaw_adamw_ema_step(ptr(p), ptr(g), ptr(m), ptr(v), ptr(ema), ptr(shadow), p.numel(), lr, beta1, beta2,
+                                     eps, wd, bc1, bc2, ema_decay, ptr(sumsq_t), clip or 0.0, 1 if zero_grad else 0,
+                                     stream_ptr()), "vaw_adamw_ema_step")
+
+
+def ema_update(ema, src, decay):
+    check(L.lib().vaw_ema_update(ptr(ema), ptr(src), ema.numel(), decay, stream_ptr()), "vaw_ema_update")
+
+
+def cast_bf16(src, dst):
+    check(L.lib().vaw_cast_bf16(ptr(src), ptr(dst), src.numel(), stream_ptr()), "vaw_cast_bf16")

@@ -1,0 +1,89 @@
+"""Fused AdamW (+EMA, +global-norm clip, +bf16 shadow refresh) over a FlatModule's flat buffers.
+
+Replaces, with ONE kernel launch per step (36 B/param + 2 B shadow):
+  torch.optim.AdamW.step            (reference main.py:354; single-tensor update rule of torch 2.x)
+  nn.utils.clip_grad_norm_          (reference tools/trainer.py:60-62) -- the norm is a second small kernel,
+                                    the scale is applied inside the update, nothing syncs with the host
+  ema(model, ema_model, decay)      (reference tools/trainer.py:12-18)
+  optimizer.zero_grad()
+It is a torch.optim.Optimizer, so LambdaLR (reference main.py:355) drives `param_groups[0]['lr']` as usual.
+"""
+import torch
+
+from . import ops
+from .flat import FlatModule
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        inner = getattr(model, "module", model)
+        if not isinstance(inner, FlatModule):
+            raise TypeError("FusedAdamW needs a vaw_amd FlatModule (e.g. vaw_amd.DiT); use torch.optim.AdamW otherwise")
+        inner.ensure_flat()
+        self.model = inner
+        super().__init__(inner._flat_params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+        n = inner._flat_n_train
+        dev = inner._flat.device
+        self.exp_avg = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.exp_avg_sq = torch.zeros(n, device=dev, dtype=torch.float32)
+        self._sumsq = torch.zeros(1, device=dev, dtype=torch.float32)
+        self.step_count = 0
+        self.ema_model, self.ema_decay = None, 0.0
+        self.max_grad_norm = None          # set per step by the trainer (args.grad_clip)
+        self._flat_ptr = inner._flat.data_ptr()
+
+    def attach_ema(self, ema_model, decay):
+        """Fold `ema(model, ema_model, decay)` into the update kernel.  Layouts must match (deepcopy does)."""
+        e = getattr(ema_model, "module", ema_model)
+        if not isinstance(e, FlatModule):
+            raise TypeError("attach_ema needs a FlatModule EMA copy")
+        e.ensure_flat()
+        if e._flat_offsets != self.model._flat_offsets:
+            raise ValueError("EMA model layout differs from the trained model")
+        self.ema_model, self.ema_decay = e, float(decay)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        assert closure is None
+        m = self.model
+        m.ensure_flat()
+        if m._flat.data_ptr() != self._flat_ptr:
+            raise RuntimeError("the model's flat buffer was rebuilt (moved device / deep-copied) after the optimizer was created")
+        g = m.flat_grads()
+        grp = self.param_groups[0]
+        self.step_count += 1
+        n = m._flat_n_train
+        clip = self.max_grad_norm
+        if clip:
+            ops.sumsq(g, self._sumsq)
+        ema_flat = None
+        if self.ema_model is not None:
+            self.ema_model.ensure_flat()
+            ema_flat = self.ema_model._flat
+        shadow = m._flat_shadow
+        ops.adamw_ema_step(m._flat[:n], g, self.exp_avg, self.exp_avg_sq, None if ema_flat is None else ema_flat[:n],
+                           None if shadow is None else shadow[:n], grp["lr"], grp["betas"][0], grp["betas"][1], grp["eps"],
+                           grp["weight_decay"], self.step_count, self.ema_decay, self._sumsq if clip else None, clip, False)
+        if ema_flat is not None and ema_flat.numel() > n:
+            ops.ema_update(ema_flat[n:], m._flat[n:], self.ema_decay)   # frozen entries (pos_embed) are EMA'd too
+        m.mark_shadow_fresh()
+        self.ema_done_in_step = ema_flat is not None
+
+    def zero_grad(self, set_to_none=True):
+        self.model.zero_grad_flat()
+
+    def state_dict(self):
+        sd = super().state_dict()
+        sd["vaw_flat"] = {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self.step_count}
+        return sd
+
+    def load_state_dict(self, sd):
+        flat = sd.get("vaw_flat")
+        if flat is not None:
+            self.exp_avg.copy_(flat["exp_avg"])
+            self.exp_avg_sq.copy_(flat["exp_avg_sq"])
+            self.step_count = int(flat["step"])
+        for g_new, g_old in zip(self.param_groups, sd["param_groups"]):
+            for k in ("lr", "betas", "eps", "weight_decay", "initial_lr"):
+                if k in g_old:
+                    g_new[k] = g_old[k]

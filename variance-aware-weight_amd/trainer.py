@@ -1,0 +1,137 @@
+"""One optimizer step of variance-aware-weighted diffusion training; same constructor and `train_step(step)`
+as the reference's tools/trainer.py:28-150, plus `ema` :12-18 and `sample_from_latent` :21-25.
+
+Differences that do not change results:
+  * `args.amp=True` selects the bf16 MFMA kernels (no GradScaler: bf16 keeps the f32 exponent range);
+    `args.amp=False` selects the f32 parity kernels.
+  * with `vaw_amd.FusedAdamW`, clip + AdamW + EMA + bf16 shadow refresh are one kernel; any other
+    torch optimizer is driven exactly as the reference drives it.
+  * the two `.item()` host syncs per micro-step become one per step (or none: `args.defer_loss_sync=True`
+    makes train_step return a 0-dim device tensor).
+"""
+from contextlib import nullcontext
+
+import torch
+import torch.nn as nn
+
+from . import dist_util, ops
+from .flat import FlatModule
+from .optim import FusedAdamW
+
+
+def ema(source, target, decay):
+    """target = target*decay + source*(1-decay) over EVERY state_dict entry (buffers and frozen params too)."""
+    s, t = getattr(source, "module", source), getattr(target, "module", target)
+    with torch.no_grad():
+        if isinstance(s, FlatModule) and isinstance(t, FlatModule):
+            s.ensure_flat(); t.ensure_flat()
+            if s._flat_offsets == t._flat_offsets and s._flat.is_cuda and not list(s.buffers()):
+                ops.ema_update(t._flat, s._flat, decay)
+                return
+        src, dst = source.state_dict(), target.state_dict()
+        for k in src:
+            dst[k].data.copy_(dst[k].data * decay + src[k].data * (1 - decay))
+
+
+def sample_from_latent(latent, latent_scale=1.0, cpu_rng=False):
+    """latent = cat[mean, std] of the VAE posterior -> scaled sample.  cpu_rng draws from the CPU generator
+    (the stream the CPU reference consumes) instead of the device generator."""
+    mean, std = torch.chunk(latent, 2, dim=1)
+    eps = torch.randn(mean.shape).to(mean.device) if cpu_rng else torch.randn_like(mean)
+    return (mean + std * eps) * latent_scale
+
+
+class Trainer:
+    def __init__(self, args, device, model, ema_model, optimizer, scheduler, diffusion, train_loader, pbar=None):
+        if getattr(args, "learn_align", False):
+            raise NotImplementedError("learn_align needs network-fetched teacher encoders: out of scope (SURVEY.md §2.1 row 12)")
+        self.args, self.device = args, device
+        self.model, self.ema_model = model, ema_model
+        self.optimizer, self.scheduler, self.diffusion = optimizer, scheduler, diffusion
+        self.train_loader = train_loader
+        self.datalooper = iter(train_loader)
+        self.pbar = pbar
+        self.scaler = None
+        inner = getattr(model, "module", model)
+        if hasattr(inner, "set_compute_dtype"):
+            want = "bf16" if args.amp else "fp32"
+            if inner.compute_dtype != want:
+                inner.set_compute_dtype(want)
+        self._fused = isinstance(optimizer, FusedAdamW)
+        if self._fused and ema_model is not None and dist_util.is_main_process():
+            optimizer.attach_ema(ema_model, args.ema_decay)
+        self.last_mse = None
+        self._cpu_rng = bool(getattr(args, "cpu_rng", False))
+
+    def _get_next_batch(self):
+        try:
+            images, labels = next(self.datalooper)
+        except StopIteration:
+            self.datalooper = iter(self.train_loader)
+            return self._get_next_batch()
+        return (images.to(self.device, non_blocking=True),
+                labels.to(self.device, non_blocking=True) if self.args.class_cond else None)
+
+    def _compute_loss(self, images, labels, features):
+        model_kwargs = {"y": labels} if self.args.class_cond else {}
+        if self._cpu_rng:
+            # parity runs: noise, then t, from the CPU generator, in the reference's order
+            # (tools/gaussian_diffusion.py:849-852); both are accepted keyword arguments there too
+            noise = torch.randn(images.shape).to(images.device)
+            t = torch.randint(0, self.diffusion.num_timesteps, (images.shape[0],)).to(images.device)
+            return self.diffusion.training_losses(self.model, images, features, t=t, model_kwargs=model_kwargs, noise=noise)
+        return self.diffusion.training_losses(self.model, images, features, model_kwargs=model_kwargs)
+
+    def _apply_gradient_clipping(self):
+        if self.args.grad_clip:
+            if self._fused:
+                self.optimizer.max_grad_norm = float(self.args.grad_clip)
+            else:
+                nn.utils.clip_grad_norm_(self.model.parameters(), self.args.grad_clip)
+
+    def _update_ema(self):
+        if dist_util.is_main_process() and self.ema_model is not None:
+            if self._fused and getattr(self.optimizer, "ema_done_in_step", False):
+                return
+            ema(self.model, self.ema_model, self.args.ema_decay)
+
+    def train_step(self, step):
+        a = self.args
+        self.model.train()
+        if a.parallel:
+            self.train_loader.sampler.set_epoch(step)
+        accum = max(1, a.grad_accumulation)
+        total, mse_avg = None, None
+        for i in range(accum):
+            images, labels = self._get_next_batch()
+            if a.in_chans == 4:
+                images = sample_from_latent(images, a.latent_scale, self._cpu_rng)
+            if a.parallel and accum > 1 and i < accum - 1:
+                ctx = self.model.no_sync()
+            else:
+                ctx = nullcontext()
+            with ctx:
+                loss_dict = self._compute_loss(images, labels, None)
+                loss = loss_dict["loss"].mean() / accum
+                loss.backward()
+            ld = loss.detach()
+            md = loss_dict["mse"].detach().mean() / accum
+            total = ld if total is None else total + ld
+            mse_avg = md if mse_avg is None else mse_avg + md
+            if (i + 1) % accum == 0:
+                self._apply_gradient_clipping()
+                self.optimizer.step()
+                self.optimizer.zero_grad()
+        self.scheduler.step()
+        if dist_util.is_main_process():
+            self._update_ema()
+        self.last_mse = mse_avg
+        if getattr(a, "defer_loss_sync", False):
+            if dist_util.is_main_process() and self.pbar is not None:
+                self.pbar.update(1)
+            return total
+        total_f = float(total.item())
+        if dist_util.is_main_process() and self.pbar is not None:
+            self.pbar.update(1)
+            self.pbar.set_postfix(mse=f"{float(mse_avg.item()):.4f}")
+        return total_f
