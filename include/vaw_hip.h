@@ -84,6 +84,11 @@ typedef struct {
 int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
              const void* B, int64_t ldb, void* C, int64_t ldc, const vaw_epilogue* epi_host, vaw_stream stream);
 
+/* 1 when vaw_gemm would run these operands on the bf16 MFMA kernel (M%128==0, N%128==0, K%64==0, 16-byte
+ * aligned rows), 0 when it takes the exact-f32 generic kernel.  For measurement and tests. */
+int vaw_gemm_uses_bf16_mfma(vaw_dtype dt, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
+                            int64_t ldb);
+
 /* out[n] = beta*out[n] + sum_m X[m,n]  (bias gradients). X act dtype, out f32.  Two fixed-order stages through a
  * caller-provided f32 workspace of vaw_colsum_workspace_floats(M,N) elements: no atomics, bitwise reproducible. */
 int64_t vaw_colsum_workspace_floats(int64_t M, int64_t N);

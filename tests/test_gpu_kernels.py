@@ -270,10 +270,19 @@ def _attn_ref(q, k, v, scale):
     return p @ v
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B,H,T,hd", [(2, 3, 64, 64), (1, 2, 16, 32), (2, 2, 100, 72), (1, 1, 256, 64)])
-def test_attention_token_major(dtype, B, H, T, hd):
+@pytest.mark.parametrize("dtype,rowwise", [(torch.float32, True), (torch.bfloat16, True), (torch.bfloat16, False)])
+@pytest.mark.parametrize("B,H,T,hd", [(2, 3, 64, 64), (1, 2, 16, 32), (2, 2, 100, 72), (1, 1, 256, 64), (3, 2, 128, 64)])
+def test_attention_token_major(dtype, rowwise, B, H, T, hd):
+    """rowwise=False lets bf16 / hd 64 / T%64==0 shapes take the MFMA kernels; the others always run rowwise."""
     tol = dict(rtol=1e-4, atol=2e-5) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2)
+    lib().vaw_debug_force_rowwise_attention(1 if rowwise else 0)
+    try:
+        _attention_token_major(dtype, tol, B, H, T, hd)
+    finally:
+        lib().vaw_debug_force_rowwise_attention(0)
+
+
+def _attention_token_major(dtype, tol, B, H, T, hd):
     D = H * hd
     qkv = (_rand(B * T, 3 * D, seed=T) * 0.7).to(dtype)
     do = _rand(B * T, D, seed=T + 1).to(dtype)

@@ -31,6 +31,7 @@ _PROTOS = {
     "vaw_wmse_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _l, _p],
     "vaw_wmse_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _l, _p],
     "vaw_gemm": [_i, _i, _i, _l, _l, _l, _p, _l, _p, _l, _p, _l, C.POINTER(Epilogue), _p],
+    "vaw_gemm_uses_bf16_mfma": [_i, _l, _l, _l, _p, _l, _p, _l],
     "vaw_colsum": [_i, _p, _l, _l, _l, _p, _f, _p, _l, _p],
     "vaw_ln_modulate_fwd": [_i, _p, _p, _p, _l, _p, _p, _p, _i, _i, _i, _f, _p],
     "vaw_ln_modulate_bwd": [_i, _p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _l, _i, _i, _i, _p],
@@ -77,6 +78,8 @@ def lib():
         L.vaw_colsum_workspace_floats.restype = _l
         L.vaw_sumsq_workspace_floats.argtypes = []
         L.vaw_sumsq_workspace_floats.restype = _l
+        L.vaw_debug_force_rowwise_attention.argtypes = [_i]
+        L.vaw_debug_force_rowwise_attention.restype = None
         L.vaw_debug_force_generic_gemm.argtypes = [_i]
         L.vaw_debug_force_generic_gemm.restype = None
         _lib = L

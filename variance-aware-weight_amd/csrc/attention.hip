@@ -177,6 +177,14 @@ attn_bwd_kv_rowwise(AttnDev a, const T* __restrict__ q, const T* __restrict__ k,
     }
 }
 
+// bf16 MFMA path (attention_mfma.hip)
+bool vaw_attn_mfma_ok(vaw_dtype dt, const vaw_attn_desc* d, const void* q, const void* k, const void* v, const void* o);
+int vaw_attn_fwd_mfma(const vaw_attn_desc* d, const void* q, const void* k, const void* v, void* o, float* lse, hipStream_t s);
+int vaw_attn_bwd_mfma(const vaw_attn_desc* d, const void* q, const void* k, const void* v, const void* d_o,
+                      const float* lse, float* delta, void* dq, void* dk, void* dv, hipStream_t s);
+static int g_force_rowwise = 0;
+extern "C" void vaw_debug_force_rowwise_attention(int on) { g_force_rowwise = on; }
+
 static int check_desc(const vaw_attn_desc* d, const char* who) {
     VAW_CHECK_ARG(d && d->B > 0 && d->H > 0 && d->T > 0 && d->hd > 0, "%s: bad descriptor", who);
     VAW_CHECK_ARG(d->T <= 64 * ATT_MAX_TILES, "%s: T=%d exceeds %d", who, d->T, 64 * ATT_MAX_TILES);
@@ -192,10 +200,11 @@ extern "C" int vaw_attn_fwd(vaw_dtype dt, const vaw_attn_desc* d, const void* q,
                             float* lse, vaw_stream stream) {
     int rc = check_desc(d, "attn_fwd");
     if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (!g_force_rowwise && vaw_attn_mfma_ok(dt, d, q, k, v, o)) return vaw_attn_fwd_mfma(d, q, k, v, o, lse, s);
     AttnDev a = to_dev(d);
     dim3 grid(ceil_div(a.T, 4), a.B * a.H);
     const size_t lds = 4 * (size_t)(a.hd + a.T) * sizeof(float);
-    hipStream_t s = (hipStream_t)stream;
     if (dt == VAW_F32)
         attn_fwd_rowwise<float><<<grid, 256, lds, s>>>(a, (const float*)q, (const float*)k, (const float*)v, (float*)o, lse);
     else
@@ -209,11 +218,13 @@ extern "C" int vaw_attn_bwd(vaw_dtype dt, const vaw_attn_desc* d, const void* q,
                             vaw_stream stream) {
     int rc = check_desc(d, "attn_bwd");
     if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (!g_force_rowwise && vaw_attn_mfma_ok(dt, d, q, k, v, d_o) && (((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 7) == 0)
+        return vaw_attn_bwd_mfma(d, q, k, v, d_o, lse, delta, dq, dk, dv, s);
     AttnDev a = to_dev(d);
     dim3 grid(ceil_div(a.T, 4), a.B * a.H);
     const size_t lds_q = 4 * (size_t)(2 * a.hd + a.T) * sizeof(float);
     const size_t lds_kv = 4 * (size_t)(2 * a.hd + 2 * a.T) * sizeof(float);
-    hipStream_t s = (hipStream_t)stream;
     if (dt == VAW_F32) {
         attn_bwd_q_rowwise<float><<<grid, 256, lds_q, s>>>(a, (const float*)q, (const float*)k, (const float*)v, (const float*)o, (const float*)d_o, lse, delta, (float*)dq);
         attn_bwd_kv_rowwise<float><<<grid, 256, lds_kv, s>>>(a, (const float*)q, (const float*)k, (const float*)v, (const float*)d_o, lse, delta, (float*)dk, (float*)dv);

@@ -249,6 +249,16 @@ gemm_generic_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ 
 static int g_force_generic = 0;
 extern "C" void vaw_debug_force_generic_gemm(int on) { g_force_generic = on; }
 
+static bool takes_fast_path(vaw_dtype dt, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
+                            int64_t ldb) {
+    return dt == VAW_BF16 && !g_force_generic && M % BM == 0 && N % BN == 0 && K % BK == 0 && lda % 8 == 0 &&
+           ldb % 8 == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0;
+}
+extern "C" int vaw_gemm_uses_bf16_mfma(vaw_dtype dt, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
+                                       const void* B, int64_t ldb) {
+    return takes_fast_path(dt, M, N, K, A, lda, B, ldb) ? 1 : 0;
+}
+
 extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int64_t N, int64_t K, const void* A,
                         int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const vaw_epilogue* ep,
                         vaw_stream stream) {
@@ -270,9 +280,7 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
     e.M = M; e.N = N; e.ldc = ldc; e.C = C;
     hipStream_t s = (hipStream_t)stream;
 
-    const bool fast = dt == VAW_BF16 && !g_force_generic && M % BM == 0 && N % BN == 0 && K % BK == 0 && lda % 8 == 0 &&
-                      ldb % 8 == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0;
-    if (fast) {
+    if (takes_fast_path(dt, M, N, K, A, lda, B, ldb)) {
         const int tiles_n = (int)(N / BN);
         const int64_t n_wg = (M / BM) * tiles_n;
         VAW_CHECK_ARG(n_wg < (1LL << 31), "gemm: grid too large");

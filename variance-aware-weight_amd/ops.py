@@ -80,8 +80,42 @@ def gemm(dt, a_kmajor, b_kmajor, M, N, K, A, lda, B, ldb, Cp, ldc, *, bias=None,
     """Raw-pointer GEMM; A, B, Cp, bias... are integers (device addresses).  See vaw_gemm in the header."""
     e = Epilogue(bias or None, act, aux_in or None, aux_out or None, gate or None, gate_ld, resid or None,
                  rowadd or None, rows_per_batch, alpha, beta, 1 if out_f32 else 0)
+    tr = gemm_trace
+    if tr is not None:
+        e0, e1 = tr.events()
+        e0.record()
     check(L.lib().vaw_gemm(dt, 1 if a_kmajor else 0, 1 if b_kmajor else 0, M, N, K, A, lda, B, ldb, Cp, ldc,
                            C.byref(e), stream_ptr()), "vaw_gemm")
+    if tr is not None:
+        e1.record()
+        tr.add(L.lib().vaw_gemm_uses_bf16_mfma(dt, M, N, K, A, lda, B, ldb), bool(a_kmajor), bool(b_kmajor), M, N, K, e0, e1)
+
+
+class GemmTrace:
+    """Measurement aid (bench.py): brackets every GEMM launch with HIP events on the launch stream."""
+
+    def __init__(self):
+        self.rows = []
+
+    def events(self):
+        return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def add(self, mfma, ak, bk, M, N, K, e0, e1):
+        self.rows.append((mfma, ak, bk, M, N, K, e0, e1))
+
+    def summarize(self):
+        """-> {variant: {launches, flop, ms}} after a device synchronize."""
+        out = {}
+        for mfma, ak, bk, M, N, K, e0, e1 in self.rows:
+            name = ("bf16_mfma" if mfma else "generic_f32mfma") + ("/fwd" if ak and bk else "/dgrad" if ak else "/wgrad")
+            d = out.setdefault(name, {"launches": 0, "flop": 0.0, "ms": 0.0})
+            d["launches"] += 1
+            d["flop"] += 2.0 * M * N * K
+            d["ms"] += e0.elapsed_time(e1)
+        return out
+
+
+gemm_trace = None
 
 
 def gemm_t(A, B, *, a_kmajor=True, b_kmajor=True, out_dtype=None, bias=None, act=0, aux_in=None, want_aux=False,
