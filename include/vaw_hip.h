@@ -80,9 +80,13 @@ typedef struct {
  *   a_kmajor=1: A stored [M][K] (lda = row stride);  0: stored [K][M]
  *   b_kmajor=1: B stored [N][K] (ldb = row stride);  0: stored [K][N]
  * forward  y = x W^T + b : (1,1)   dgrad dx = dy W : (1,0)   wgrad dW = dy^T x : (0,0)
- * A and B are act dtype.  value = acc*alpha + bias -> [aux_out] -> act -> *gate -> +resid -> +rowadd. */
+ * A and B are act dtype.  value = acc*alpha + bias -> [aux_out] -> act -> *gate -> +resid -> +rowadd.
+ * workspace (f32, may be NULL): lets launches with a plain f32 epilogue (weight gradients: K = B*T, few output
+ * tiles) run split-K -- partial slabs [split][M][N] summed in a fixed order by a second kernel, so results do
+ * not depend on scheduling.  A workspace of 8*M*N floats is always enough; smaller ones lower the split. */
 int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
-             const void* B, int64_t ldb, void* C, int64_t ldc, const vaw_epilogue* epi_host, vaw_stream stream);
+             const void* B, int64_t ldb, void* C, int64_t ldc, const vaw_epilogue* epi_host, float* workspace,
+             int64_t workspace_floats, vaw_stream stream);
 
 /* 1 when vaw_gemm would run these operands on the bf16 MFMA kernel (M%128==0, N%128==0, K%64==0, 16-byte
  * aligned rows), 0 when it takes the exact-f32 generic kernel.  For measurement and tests. */

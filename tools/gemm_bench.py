@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of vaw_gemm on the shapes of a workload (run on the GPU box).
+    python tools/gemm_bench.py [--shapes dit_b4|square] [--iters 20]
+Prints per-shape TFLOP/s for the forward (k-major x k-major), dgrad (k-major x mn-major) and wgrad
+(mn-major x mn-major) layouts, HIP-event timed, operands random (zeros would flatter the clock)."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import vaw_amd  # noqa: E402
+from vaw_amd import ops  # noqa: E402
+from vaw_amd._lib import BF16, ptr  # noqa: E402
+
+M = 16384
+DIT_B4 = [  # (name, layout, M, N, K, epilogue)
+    ("qkv fwd", "fwd", M, 2304, 768, "bias"), ("proj fwd", "fwd", M, 768, 768, "gate"), ("fc1 fwd", "fwd", M, 3072, 768, "gelu"),
+    ("fc2 fwd", "fwd", M, 768, 3072, "gate"),
+    ("qkv dgrad", "dgrad", M, 768, 2304, "none"), ("proj dgrad", "dgrad", M, 768, 768, "none"),
+    ("fc1 dgrad", "dgrad", M, 768, 3072, "none"), ("fc2 dgrad", "dgrad", M, 3072, 768, "dgelu"),
+    ("qkv wgrad", "wgrad", 2304, 768, M, "f32"), ("proj wgrad", "wgrad", 768, 768, M, "f32"),
+    ("fc1 wgrad", "wgrad", 3072, 768, M, "f32"), ("fc2 wgrad", "wgrad", 768, 3072, M, "f32"),
+]
+SQUARE = [("4096^3 fwd", "fwd", 4096, 4096, 4096, "none"), ("4096^3 dgrad", "dgrad", 4096, 4096, 4096, "none"),
+          ("4096^3 wgrad", "wgrad", 4096, 4096, 4096, "f32"), ("8192^3 fwd", "fwd", 8192, 8192, 8192, "none")]
+
+
+def run(name, layout, M, N, K, epi, iters):
+    dev = "cuda"
+    ak, bk = {"fwd": (1, 1), "dgrad": (1, 0), "wgrad": (0, 0)}[layout]
+    A = torch.randn((M, K) if ak else (K, M), device=dev).bfloat16()
+    B = torch.randn((N, K) if bk else (K, N), device=dev).bfloat16()
+    out_f32 = epi in ("f32", "gate")
+    C = torch.empty(M, N, device=dev, dtype=torch.float32 if out_f32 else torch.bfloat16)
+    kw = {}
+    keep = []
+    if epi in ("bias", "gelu", "gate"):
+        b = torch.randn(N, device=dev); keep.append(b); kw["bias"] = ptr(b)
+    if epi == "gelu":
+        aux = torch.empty(M, N, device=dev, dtype=torch.bfloat16); keep.append(aux); kw.update(act=1, aux_out=ptr(aux))
+    if epi == "dgelu":
+        aux = torch.randn(M, N, device=dev).bfloat16(); keep.append(aux); kw.update(act=2, aux_in=ptr(aux))
+    if epi == "gate":
+        g = torch.randn(M // 64, N, device=dev); r = torch.randn(M, N, device=dev)
+        aux = torch.empty(M, N, device=dev, dtype=torch.bfloat16); keep += [g, r, aux]
+        kw.update(gate=ptr(g), gate_ld=N, resid=ptr(r), rows_per_batch=64, aux_out=ptr(aux))
+    lda, ldb = A.shape[1], B.shape[1]
+    call = lambda: ops.gemm(BF16, ak, bk, M, N, K, ptr(A), lda, ptr(B), ldb, ptr(C), N, out_f32=out_f32, **kw)
+    for _ in range(3):
+        call()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    us = 1e3 * e0.elapsed_time(e1) / iters
+    print(f"{name:14s} {layout:6s} M={M:6d} N={N:5d} K={K:6d} epi={epi:6s} {us:9.1f} us  {2.0 * M * N * K / us / 1e6:8.1f} TFLOP/s", flush=True)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shapes", default="dit_b4")
+    ap.add_argument("--iters", type=int, default=20)
+    a = ap.parse_args()
+    for row in {"dit_b4": DIT_B4, "square": SQUARE, "all": DIT_B4 + SQUARE}[a.shapes]:
+        run(*row, a.iters)

@@ -30,7 +30,7 @@ _PROTOS = {
     "vaw_mix_rows": [_p, _p, _p, _p, _p, _i, _l, _p],
     "vaw_wmse_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _l, _p],
     "vaw_wmse_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _l, _p],
-    "vaw_gemm": [_i, _i, _i, _l, _l, _l, _p, _l, _p, _l, _p, _l, C.POINTER(Epilogue), _p],
+    "vaw_gemm": [_i, _i, _i, _l, _l, _l, _p, _l, _p, _l, _p, _l, C.POINTER(Epilogue), _p, _l, _p],
     "vaw_gemm_uses_bf16_mfma": [_i, _l, _l, _l, _p, _l, _p, _l],
     "vaw_colsum": [_i, _p, _l, _l, _l, _p, _f, _p, _l, _p],
     "vaw_ln_modulate_fwd": [_i, _p, _p, _p, _l, _p, _p, _p, _i, _i, _i, _f, _p],

@@ -31,6 +31,7 @@ struct EpiDev {
     int out_f32;
     int64_t M, N, ldc;
     void* C;
+    float* slab;   // split-K partial sums [n_split][M][N] f32 (workspace), or NULL
 };
 
 // One accumulator fragment row: 4 consecutive rows (m..m+3) at one column n.
@@ -51,15 +52,68 @@ __device__ __forceinline__ void epi_store4(const EpiDev& e, int64_t m, int64_t n
         }
         if (e.act == 1) v = gelu_tanh_f(v);
         else if (e.act == 2) v *= gelu_tanh_grad_f(to_f32(((const TO*)e.aux_in)[off]));
-        if (e.gate) v *= e.gate[(mm / e.rpb) * e.gate_ld + n];
+        const unsigned mu = (unsigned)mm, rpb = (unsigned)e.rpb;
+        if (e.gate) v *= e.gate[(int64_t)(mu / rpb) * e.gate_ld + n];
         if (e.resid) v += e.resid[off];
-        if (e.rowadd) v += e.rowadd[(mm % e.rpb) * e.N + n];
+        if (e.rowadd) v += e.rowadd[(int64_t)(mu % rpb) * e.N + n];
         if (e.out_f32) {
             float* c = (float*)e.C + off;
             *c = (e.beta != 0.f ? e.beta * *c : 0.f) + v;
         } else {
             ((TO*)e.C)[off] = from_f32<TO>(v);
         }
+    }
+}
+
+// Eight consecutive columns n..n+7 of row m, all operands 16-byte aligned (fast path, second epilogue phase).
+__device__ __forceinline__ void epi_row8(const EpiDev& e, unsigned m, int64_t n, f32x4 v0, f32x4 v1, f32x4 b0, f32x4 b1) {
+    const int64_t off = (int64_t)m * e.ldc + n;
+    v0 = v0 * e.alpha + b0;
+    v1 = v1 * e.alpha + b1;
+    if (e.aux_out) {
+        // the saved branch value is the bf16-rounded one, and so is what the activation sees (fwd/bwd consistent)
+        const bf16x8 r = {(bf16_t)v0[0], (bf16_t)v0[1], (bf16_t)v0[2], (bf16_t)v0[3],
+                          (bf16_t)v1[0], (bf16_t)v1[1], (bf16_t)v1[2], (bf16_t)v1[3]};
+        *reinterpret_cast<bf16x8*>((bf16_t*)e.aux_out + off) = r;
+        v0 = f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+        v1 = f32x4{(float)r[4], (float)r[5], (float)r[6], (float)r[7]};
+    }
+    if (e.act == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v0[j] = gelu_tanh_f(v0[j]); v1[j] = gelu_tanh_f(v1[j]); }
+    } else if (e.act == 2) {
+        const bf16_t* ai = (const bf16_t*)e.aux_in + off;
+        f32x4 h0 = load4(ai), h1 = load4(ai + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v0[j] *= gelu_tanh_grad_f(h0[j]); v1[j] *= gelu_tanh_grad_f(h1[j]); }
+    }
+    const unsigned rpb = (unsigned)e.rpb;
+    if (e.gate) {
+        const float* g = e.gate + (int64_t)(m / rpb) * e.gate_ld + n;
+        v0 *= load4(g);
+        v1 *= load4(g + 4);
+    }
+    if (e.resid) {
+        v0 += load4(e.resid + off);
+        v1 += load4(e.resid + off + 4);
+    }
+    if (e.rowadd) {
+        const float* ra = e.rowadd + (int64_t)(m % rpb) * e.N + n;
+        v0 += load4(ra);
+        v1 += load4(ra + 4);
+    }
+    if (e.out_f32) {
+        float* c = (float*)e.C + off;
+        if (e.beta != 0.f) {
+            v0 += e.beta * load4(c);
+            v1 += e.beta * load4(c + 4);
+        }
+        store4(c, v0);
+        store4(c + 4, v1);
+    } else {
+        bf16_t* c = (bf16_t*)e.C + off;
+        bf16x8 r = {(bf16_t)v0[0], (bf16_t)v0[1], (bf16_t)v0[2], (bf16_t)v0[3], (bf16_t)v1[0], (bf16_t)v1[1], (bf16_t)v1[2], (bf16_t)v1[3]};
+        *reinterpret_cast<bf16x8*>(c) = r;
     }
 }
 
@@ -70,6 +124,8 @@ __device__ __forceinline__ void epi_store4(const EpiDev& e, int64_t m, int64_t n
 #define BN 128
 #define BK 64
 #define TILE_BYTES (128 * 64 * 2)   // one operand tile, either orientation: 16 KiB
+#define CS_LD 132                   // f32 row stride of the epilogue staging image (128 + 4: conflict-free)
+#define FAST_LDS_BYTES (128 * CS_LD * 4)   // 67,584 B >= the 65,536 B of the two double-buffered operand tiles
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
@@ -124,9 +180,9 @@ __device__ __forceinline__ bf16x8 load_frag(const char* lds_tile, int r0, int s,
 
 template <bool AK, bool BKM>
 __global__ void __launch_bounds__(256, 2)
-gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb, int K, int tiles_n,
-                 int n_wg, EpiDev e) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A tile | B tile]
+gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb, int nk_total,
+                 int tiles_n, int n_wg, int n_split, EpiDev e) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A tile | B tile]; reused by the epilogue
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // XCD-aware remap (bijective for any grid): blocks b, b+8, ... share an XCD; give each XCD a contiguous
@@ -138,10 +194,14 @@ gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __rest
     }
     const int tm = wg / tiles_n, tn = wg % tiles_n;
     const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
-    const bf16_t* Ag = AK ? A + m0 * lda : A + m0;          // step along k: +BK (k-major) or +BK*lda
-    const bf16_t* Bg = BKM ? B + n0 * ldb : B + n0;
-    const int64_t a_step = AK ? BK : (int64_t)BK * lda;
+    const int64_t a_step = AK ? BK : (int64_t)BK * lda;       // step along k: +BK (k-major) or +BK*lda
     const int64_t b_step = BKM ? BK : (int64_t)BK * ldb;
+    // split-K: blockIdx.y owns k-tiles [kt0, kt0 + nk)
+    const int nk_per = (nk_total + n_split - 1) / n_split;
+    const int kt0 = blockIdx.y * nk_per;
+    const int nk = (kt0 + nk_per <= nk_total ? nk_per : nk_total - kt0);
+    const bf16_t* Ag = (AK ? A + m0 * lda : A + m0) + kt0 * a_step;
+    const bf16_t* Bg = (BKM ? B + n0 * ldb : B + n0) + kt0 * b_step;
     const int wm = (wid >> 1) * 64, wn = (wid & 1) * 64;
 
     f32x4 acc[4][4];
@@ -150,7 +210,6 @@ gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __rest
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
 
-    const int nk = K / BK;
     stage_tile<AK>(Ag, lda, smem, wid, lane);
     stage_tile<BKM>(Bg, ldb, smem + TILE_BYTES, wid, lane);
     for (int kt = 0; kt < nk; ++kt) {
@@ -176,11 +235,63 @@ gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __rest
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
     }
+    // ---- epilogue, phase 1: accumulators -> f32 staging image in LDS (the operand tiles are dead) ----
+    __syncthreads();
+    float* cs = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            epi_store4<bf16_t>(e, m0 + wm + 16 * i + 4 * (lane >> 4), n0 + wn + 16 * j + (lane & 15), acc[i][j]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                cs[(wm + 16 * i + 4 * (lane >> 4) + r) * CS_LD + wn + 16 * j + (lane & 15)] = acc[i][j][r];
+    __syncthreads();
+    // ---- phase 2: each thread owns 8 consecutive columns of one row per pass: 16-byte loads and stores ----
+    const int c8 = (threadIdx.x & 15) * 8, r0 = threadIdx.x >> 4;
+    if (n_split > 1) {
+        float* slab = e.slab + (int64_t)blockIdx.y * e.M * e.N;
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int row = pass * 16 + r0;
+            const float* src = cs + row * CS_LD + c8;
+            float* dst = slab + (m0 + row) * e.N + n0 + c8;
+            store4(dst, load4(src));
+            store4(dst + 4, load4(src + 4));
+        }
+        return;
+    }
+    f32x4 b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
+    if (e.bias) {
+        b0 = load4(e.bias + n0 + c8);
+        b1 = load4(e.bias + n0 + c8 + 4);
+    }
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+        const int row = pass * 16 + r0;
+        const float* src = cs + row * CS_LD + c8;
+        epi_row8(e, (unsigned)(m0 + row), n0 + c8, load4(src), load4(src + 4), b0, b1);
+    }
+}
+
+// out = beta*C + alpha * sum_s slab[s], fixed order (deterministic split-K).  N % 4 == 0.
+template <typename TO>
+__global__ void splitk_reduce_kernel(const float* __restrict__ slab, int S, int64_t M, int64_t N, int64_t ldc,
+                                     void* __restrict__ C, float alpha, float beta, int out_f32) {
+    const int64_t total4 = M * N / 4;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = (4 * i) / N, n = (4 * i) % N;
+        f32x4 acc = {0, 0, 0, 0};
+        for (int sidx = 0; sidx < S; ++sidx) acc += load4(slab + (int64_t)sidx * M * N + 4 * i);
+        acc *= alpha;
+        const int64_t off = m * ldc + n;
+        if (out_f32) {
+            float* c = (float*)C + off;
+            if (beta != 0.f) acc += beta * load4(c);
+            store4(c, acc);
+        } else {
+            store4((TO*)C + off, acc);
+        }
+    }
 }
 
 // =============================================================================================
@@ -208,7 +319,8 @@ __device__ __forceinline__ void generic_stage(const T* __restrict__ g, int64_t l
 
 template <typename T, bool AK, bool BKM>
 __global__ void __launch_bounds__(256)
-gemm_generic_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb, int64_t K, EpiDev e) {
+gemm_generic_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb, int64_t K, int64_t kchunk,
+                    EpiDev e) {
     __shared__ float As[GBK * GLD];
     __shared__ float Bs[GBK * GLD];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -219,10 +331,12 @@ gemm_generic_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ 
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
-    for (int64_t k0 = 0; k0 < K; k0 += GBK) {
+    const int64_t kbeg = (int64_t)blockIdx.z * kchunk;
+    const int64_t kend = kbeg + kchunk < K ? kbeg + kchunk : K;
+    for (int64_t k0 = kbeg; k0 < kend; k0 += GBK) {
         __syncthreads();
-        generic_stage<T, AK>(A, lda, m0, e.M, k0, K, As, tid);
-        generic_stage<T, BKM>(B, ldb, n0, e.N, k0, K, Bs, tid);
+        generic_stage<T, AK>(A, lda, m0, e.M, k0, kend, As, tid);
+        generic_stage<T, BKM>(B, ldb, n0, e.N, k0, kend, Bs, tid);
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < GBK / 4; ++s) {
@@ -238,6 +352,21 @@ gemm_generic_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ 
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
+    }
+    if (gridDim.z > 1) {   // split-K: raw partial sums to this split's slab
+        float* slab = e.slab + (int64_t)blockIdx.z * e.M * e.N;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t n = n0 + wn + 16 * j + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t m = m0 + wm + 16 * i + 4 * (lane >> 4) + r;
+                    if (m < e.M && n < e.N) slab[m * e.N + n] = acc[i][j][r];
+                }
+            }
+        return;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -259,10 +388,22 @@ extern "C" int vaw_gemm_uses_bf16_mfma(vaw_dtype dt, int64_t M, int64_t N, int64
     return takes_fast_path(dt, M, N, K, A, lda, B, ldb) ? 1 : 0;
 }
 
+// Split-K factor: only for plain f32-output epilogues (the weight gradients: long K = B*T, few output tiles),
+// sized so the launch has ~2 workgroups per CU, each split keeping >= 256 of K, within the workspace.
+static int pick_split(int64_t tiles, int64_t K, int64_t MN, int64_t ws_floats, bool plain_f32) {
+    if (!plain_f32 || ws_floats <= 0) return 1;
+    int64_t s = 512 / tiles;
+    if (s > K / 256) s = K / 256;
+    if (s > ws_floats / MN) s = ws_floats / MN;
+    if (s > 64) s = 64;
+    return s < 2 ? 1 : (int)s;
+}
+
 extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int64_t N, int64_t K, const void* A,
                         int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const vaw_epilogue* ep,
-                        vaw_stream stream) {
+                        float* workspace, int64_t workspace_floats, vaw_stream stream) {
     VAW_CHECK_ARG(M > 0 && N > 0 && K > 0 && A && B && C, "gemm: bad sizes M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
+    VAW_CHECK_ARG(M < (1LL << 31) && N < (1LL << 31), "gemm: M, N must fit 31 bits");
     VAW_CHECK_ARG(lda >= (a_kmajor ? K : M) && ldb >= (b_kmajor ? K : N) && ldc >= N, "gemm: leading dimension too small");
     EpiDev e{};
     e.alpha = 1.f;
@@ -277,36 +418,59 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
     VAW_CHECK_ARG(e.beta == 0.f || e.out_f32 || dt == VAW_F32, "gemm: beta needs f32 output");
     if (e.rpb <= 0) e.rpb = 1;
     if (dt == VAW_F32) e.out_f32 = 1;
-    e.M = M; e.N = N; e.ldc = ldc; e.C = C;
+    e.M = M; e.N = N; e.ldc = ldc; e.C = C; e.slab = workspace;
     hipStream_t s = (hipStream_t)stream;
+    const bool plain_f32 = e.out_f32 && !e.bias && !e.act && !e.aux_out && !e.gate && !e.resid && !e.rowadd && N % 4 == 0 &&
+                           ldc % 4 == 0 && ((uintptr_t)C & 15) == 0;
 
-    if (takes_fast_path(dt, M, N, K, A, lda, B, ldb)) {
+    // the vector epilogue of the fast path needs every epilogue operand 16-byte aligned
+    const bool epi_aligned = ldc % 8 == 0 && e.gate_ld % 4 == 0 &&
+                             ((((uintptr_t)C | (uintptr_t)e.bias | (uintptr_t)e.aux_in | (uintptr_t)e.aux_out |
+                                (uintptr_t)e.gate | (uintptr_t)e.resid | (uintptr_t)e.rowadd) & 15) == 0);
+    if (takes_fast_path(dt, M, N, K, A, lda, B, ldb) && epi_aligned) {
         const int tiles_n = (int)(N / BN);
         const int64_t n_wg = (M / BM) * tiles_n;
         VAW_CHECK_ARG(n_wg < (1LL << 31), "gemm: grid too large");
-        const size_t lds = 4 * TILE_BYTES;
+        const int nk_total = (int)(K / BK);
+        int split = pick_split(n_wg, K, M * N, workspace_floats, plain_f32);
+        if (split > 1) {   // no empty splits
+            const int per = (nk_total + split - 1) / split;
+            split = (nk_total + per - 1) / per;
+        }
+        const size_t lds = FAST_LDS_BYTES;
         const bf16_t* a = (const bf16_t*)A;
         const bf16_t* b = (const bf16_t*)B;
+        dim3 grid((unsigned)n_wg, (unsigned)split);
 #define LAUNCH_FAST(AKv, BKv)                                                                                        \
     do {                                                                                                             \
         static bool attr_done = false;                                                                               \
         if (!attr_done) {                                                                                            \
-            (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AKv, BKv>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                (int)lds);                                                                           \
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AKv, BKv>,                                       \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
             attr_done = true;                                                                                        \
         }                                                                                                            \
-        gemm_bf16_kernel<AKv, BKv><<<(int)n_wg, 256, lds, s>>>(a, lda, b, ldb, (int)K, tiles_n, (int)n_wg, e);       \
+        gemm_bf16_kernel<AKv, BKv><<<grid, 256, lds, s>>>(a, lda, b, ldb, nk_total, tiles_n, (int)n_wg, split, e);   \
     } while (0)
         if (a_kmajor && b_kmajor) LAUNCH_FAST(true, true);
         else if (a_kmajor && !b_kmajor) LAUNCH_FAST(true, false);
         else if (!a_kmajor && b_kmajor) LAUNCH_FAST(false, true);
         else LAUNCH_FAST(false, false);
+        if (split > 1)
+            splitk_reduce_kernel<float><<<ceil_div(M * N / 4, 256) > 2048 ? 2048 : ceil_div(M * N / 4, 256), 256, 0, s>>>(
+                workspace, split, M, N, ldc, C, e.alpha, e.beta, 1);
         VAW_CHECK_LAUNCH("gemm_bf16");
         return VAW_OK;
     }
-    dim3 grid(ceil_div(N, GBN), ceil_div(M, GBM));
+    const int64_t tiles = (int64_t)ceil_div(N, GBN) * ceil_div(M, GBM);
+    int split = pick_split(tiles, K, M * N, workspace_floats, plain_f32);
+    int64_t kchunk = K;
+    if (split > 1) {
+        kchunk = ((K + split - 1) / split + GBK - 1) / GBK * GBK;
+        split = (int)((K + kchunk - 1) / kchunk);
+    }
+    dim3 grid(ceil_div(N, GBN), ceil_div(M, GBM), split);
 #define LAUNCH_GEN(T, AKv, BKv) \
-    gemm_generic_kernel<T, AKv, BKv><<<grid, 256, 0, s>>>((const T*)A, lda, (const T*)B, ldb, K, e)
+    gemm_generic_kernel<T, AKv, BKv><<<grid, 256, 0, s>>>((const T*)A, lda, (const T*)B, ldb, K, kchunk, e)
 #define LAUNCH_GEN_T(T)                                          \
     do {                                                         \
         if (a_kmajor && b_kmajor) LAUNCH_GEN(T, true, true);     \
@@ -316,6 +480,9 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
     } while (0)
     if (dt == VAW_F32) LAUNCH_GEN_T(float);
     else LAUNCH_GEN_T(bf16_t);
+    if (split > 1)
+        splitk_reduce_kernel<float><<<ceil_div(M * N / 4, 256) > 2048 ? 2048 : ceil_div(M * N / 4, 256), 256, 0, s>>>(
+            workspace, split, M, N, ldc, C, e.alpha, e.beta, 1);
     VAW_CHECK_LAUNCH("gemm_generic");
     return VAW_OK;
 }

@@ -84,11 +84,20 @@ def gemm(dt, a_kmajor, b_kmajor, M, N, K, A, lda, B, ldb, Cp, ldc, *, bias=None,
     if tr is not None:
         e0, e1 = tr.events()
         e0.record()
+    ws_ptr, ws_n = 0, 0
+    if out_f32 and beta_or_plain(bias, act, aux_out, gate, resid, rowadd) and K >= 2048:
+        ws = scratch_f32(torch.device("cuda", torch.cuda.current_device()), 0)
+        ws_ptr, ws_n = ws.data_ptr(), ws.numel()
     check(L.lib().vaw_gemm(dt, 1 if a_kmajor else 0, 1 if b_kmajor else 0, M, N, K, A, lda, B, ldb, Cp, ldc,
-                           C.byref(e), stream_ptr()), "vaw_gemm")
+                           C.byref(e), ws_ptr, ws_n, stream_ptr()), "vaw_gemm")
     if tr is not None:
         e1.record()
         tr.add(L.lib().vaw_gemm_uses_bf16_mfma(dt, M, N, K, A, lda, B, ldb), bool(a_kmajor), bool(b_kmajor), M, N, K, e0, e1)
+
+
+def beta_or_plain(bias, act, aux_out, gate, resid, rowadd):
+    """True when the epilogue is alpha/beta only: the launches that may run split-K."""
+    return not (bias or act or aux_out or gate or resid or rowadd)
 
 
 class GemmTrace:
@@ -143,10 +152,11 @@ _scratch = {}
 
 
 def scratch_f32(device, n):
-    """Grow-only f32 scratch per device for the fixed-order reductions (column sums, gradient norm)."""
+    """Grow-only f32 scratch per device for the fixed-order reductions (column sums, gradient norm, split-K
+    slabs).  64 MiB to start with: 16 M floats hold 4 slabs of the largest DiT-XL weight gradient."""
     t = _scratch.get(device)
     if t is None or t.numel() < n:
-        t = _scratch[device] = torch.empty(max(n, 1 << 20), device=device, dtype=torch.float32)
+        t = _scratch[device] = torch.empty(max(n, 1 << 24), device=device, dtype=torch.float32)
     return t
 
 
