@@ -74,6 +74,10 @@ typedef struct {
     float alpha;           /* scales the accumulator first */
     float beta;            /* C = beta*C_old + value (f32 output only; 0 = overwrite, C_old not read) */
     int out_f32;           /* 1: C is f32 regardless of act dtype; 0: C has act dtype */
+    float* colsum_out;     /* f32[N] or NULL: colsum_out = colsum_beta*colsum_out + sum_m C[m,:] (values as stored),
+                            * i.e. the bias gradient of the layer whose output gradient this GEMM produces; taken in
+                            * the epilogue (no second pass over C); needs the workspace */
+    float colsum_beta;
 } vaw_epilogue;
 
 /* C[M,N] = epilogue( alpha * op(A)[M,K] . op(B)[K,N] )
@@ -98,6 +102,8 @@ int vaw_gemm_uses_bf16_mfma(vaw_dtype dt, int64_t M, int64_t N, int64_t K, const
 int64_t vaw_colsum_workspace_floats(int64_t M, int64_t N);
 int vaw_colsum(vaw_dtype dt, const void* X, int64_t M, int64_t N, int64_t ldx, float* out, float beta,
                float* workspace, int64_t workspace_floats, vaw_stream stream);
+/* out[n] = beta*out[n] + sum_{r<R} partial[r,n], r ascending (second stage of the fixed-order column sums) */
+int vaw_reduce_rows(const float* partial, int64_t R, int64_t N, float* out, float beta, vaw_stream stream);
 
 /* ---------------------------------------------------------------------------
  * DiT pieces  (models/dit.py)
@@ -116,9 +122,11 @@ int vaw_ln_modulate_bwd(vaw_dtype dt, const void* dout, const float* x, const fl
                         const float* scale, int64_t mod_ld, const float* dres_in, float* dx, float* dshift,
                         float* dscale, int64_t dmod_ld, int B, int T, int D, vaw_stream stream);
 /* Backward of `x + gate.unsqueeze(1) * y` :135-136 w.r.t. the branch:
- *   dy[b,t,:] = dres[b,t,:] * gate[b,:] (act dtype) ; dgate[b,:] = sum_t dres * y. */
+ *   dy[b,t,:] = dres[b,t,:] * gate[b,:] (act dtype) ; dgate[b,:] = sum_t dres * y ;
+ *   dy_colsum_partial (f32 [B, D] or NULL): per-sample sum_t dy -- reduce over B with vaw_reduce_rows to get the
+ *   bias gradient of the branch's last Linear without re-reading dy. */
 int vaw_gate_bwd(vaw_dtype dt, const float* dres, const void* y, const float* gate, int64_t mod_ld, void* dy,
-                 float* dgate, int64_t dmod_ld, int B, int T, int D, vaw_stream stream);
+                 float* dgate, int64_t dmod_ld, float* dy_colsum_partial, int B, int T, int D, vaw_stream stream);
 
 /* timm PatchEmbed (dit.py:192) input side: x f32 [B,C,H,W] -> tokens act dtype [B*(H/p)*(W/p), C*p*p],
  * column order (c, i, j) = Conv2d weight flattening. */

@@ -177,6 +177,10 @@ def test_gemm_epilogues(dtype):
     hh = h.double().requires_grad_(True)
     torch.nn.functional.gelu(hh, approximate="tanh").sum().backward()
     torch.testing.assert_close(got.cpu().double(), (A.double() @ W.double().t()) * hh.grad, **tol)
+    # column sums of the output taken in the epilogue (bias gradient of the producing layer)
+    cs = torch.full((N,), 2.0, device=DEV)
+    got = ops.gemm_t(d(A), d(W), act=2, aux_in=d(h), colsum_out=cs, colsum_beta=0.5)
+    torch.testing.assert_close(cs.cpu().double(), 1.0 + got.cpu().double().sum(0), rtol=1e-4, atol=1e-3)
     # wgrad accumulate: C = 1*C + A^T B
     X, Y = _mk(N, K, M, False, False, dtype, seed=17)
     c0 = _rand(N, K, seed=18)
@@ -259,6 +263,13 @@ def test_gate_bwd(dtype):
     torch.testing.assert_close(dy.cpu().double(), dres.double() * g.repeat_interleave(T, 0), **tol)
     torch.testing.assert_close(dg[:, D:].cpu().double(), (dres.double() * y.double()).view(B, T, D).sum(1), rtol=1e-4, atol=1e-4)
     assert float(dg[:, :D].abs().max()) == 0.0
+    # bias-gradient partials: per-sample column sums of dy as stored, then the fixed-order reduce over samples
+    part = torch.empty(B, D, device=DEV)
+    ops.gate_bwd(ops.dt_of(dy), ptr(dr), ptr(yd), ptr(gd) + 4 * D, 2 * D, ptr(dy), ptr(dg) + 4 * D, 2 * D, B, T, D, ptr(part))
+    torch.testing.assert_close(part.cpu().double(), dy.cpu().double().view(B, T, D).sum(1), rtol=1e-5, atol=1e-5)
+    out = torch.ones(D, device=DEV)
+    ops.reduce_rows(ptr(part), B, D, ptr(out), 1.0)
+    torch.testing.assert_close(out.cpu().double(), 1.0 + dy.cpu().double().sum(0), rtol=1e-5, atol=1e-4)
 
 
 # ------------------------------------------------------------------------------------------------

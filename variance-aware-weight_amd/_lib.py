@@ -16,7 +16,8 @@ _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
 class Epilogue(C.Structure):
     _fields_ = [("bias", _p), ("act", _i), ("aux_in", _p), ("aux_out", _p), ("gate", _p), ("gate_ld", _l),
-                ("resid", _p), ("rowadd", _p), ("rows_per_batch", _i), ("alpha", _f), ("beta", _f), ("out_f32", _i)]
+                ("resid", _p), ("rowadd", _p), ("rows_per_batch", _i), ("alpha", _f), ("beta", _f), ("out_f32", _i),
+                ("colsum_out", _p), ("colsum_beta", _f)]
 
 
 class AttnDesc(C.Structure):
@@ -35,7 +36,8 @@ _PROTOS = {
     "vaw_colsum": [_i, _p, _l, _l, _l, _p, _f, _p, _l, _p],
     "vaw_ln_modulate_fwd": [_i, _p, _p, _p, _l, _p, _p, _p, _i, _i, _i, _f, _p],
     "vaw_ln_modulate_bwd": [_i, _p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _l, _i, _i, _i, _p],
-    "vaw_gate_bwd": [_i, _p, _p, _p, _l, _p, _p, _l, _i, _i, _i, _p],
+    "vaw_gate_bwd": [_i, _p, _p, _p, _l, _p, _p, _l, _p, _i, _i, _i, _p],
+    "vaw_reduce_rows": [_p, _l, _l, _p, _f, _p],
     "vaw_patchify": [_i, _p, _p, _i, _i, _i, _i, _i, _p],
     "vaw_patchify_bwd": [_p, _p, _i, _i, _i, _i, _i, _p],
     "vaw_unpatchify": [_i, _p, _p, _i, _i, _i, _i, _i, _p],

@@ -80,19 +80,19 @@ __device__ __forceinline__ float silu_grad_f(float x) {
     float s = 1.f / (1.f + __expf(-x));
     return s * (1.f + x * (1.f - s));
 }
-// GELU, tanh approximation (nn.GELU(approximate="tanh"), reference models/dit.py:129)
+// GELU, tanh approximation (nn.GELU(approximate="tanh"), reference models/dit.py:129), written through
+// 0.5(1+tanh(u)) == sigmoid(2u): one v_exp_f32 + one reciprocal instead of a libm tanhf call per element.
 __device__ __forceinline__ float gelu_tanh_f(float x) {
     const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    float u = k0 * (x + k1 * x * x * x);
-    return 0.5f * x * (1.f + tanhf(u));
+    const float u2 = 2.f * k0 * (x + k1 * x * x * x);
+    return x / (1.f + __expf(-u2));
 }
 __device__ __forceinline__ float gelu_tanh_grad_f(float x) {
     const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    float x2 = x * x;
-    float u = k0 * (x + k1 * x * x2);
-    float t = tanhf(u);
-    float du = k0 * (1.f + 3.f * k1 * x2);
-    return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * du;
+    const float x2 = x * x;
+    const float u2 = 2.f * k0 * (x + k1 * x * x2);
+    const float s = 1.f / (1.f + __expf(-u2));
+    return s + x * s * (1.f - s) * (2.f * k0 * (1.f + 3.f * k1 * x2));
 }
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

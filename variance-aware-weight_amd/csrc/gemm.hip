@@ -32,6 +32,7 @@ struct EpiDev {
     int64_t M, N, ldc;
     void* C;
     float* slab;   // split-K partial sums [n_split][M][N] f32 (workspace), or NULL
+    float* colpart;   // [M/128][N] f32: per-row-tile column sums of the OUTPUT (bias gradient of the next layer), or NULL
 };
 
 // One accumulator fragment row: 4 consecutive rows (m..m+3) at one column n.
@@ -66,7 +67,7 @@ __device__ __forceinline__ void epi_store4(const EpiDev& e, int64_t m, int64_t n
 }
 
 // Eight consecutive columns n..n+7 of row m, all operands 16-byte aligned (fast path, second epilogue phase).
-__device__ __forceinline__ void epi_row8(const EpiDev& e, unsigned m, int64_t n, f32x4 v0, f32x4 v1, f32x4 b0, f32x4 b1) {
+__device__ __forceinline__ void epi_row8(const EpiDev& e, unsigned m, int64_t n, f32x4& v0, f32x4& v1, f32x4 b0, f32x4 b1) {
     const int64_t off = (int64_t)m * e.ldc + n;
     v0 = v0 * e.alpha + b0;
     v1 = v1 * e.alpha + b1;
@@ -114,6 +115,8 @@ __device__ __forceinline__ void epi_row8(const EpiDev& e, unsigned m, int64_t n,
         bf16_t* c = (bf16_t*)e.C + off;
         bf16x8 r = {(bf16_t)v0[0], (bf16_t)v0[1], (bf16_t)v0[2], (bf16_t)v0[3], (bf16_t)v1[0], (bf16_t)v1[1], (bf16_t)v1[2], (bf16_t)v1[3]};
         *reinterpret_cast<bf16x8*>(c) = r;
+        v0 = f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};   // what a later reader of C sees
+        v1 = f32x4{(float)r[4], (float)r[5], (float)r[6], (float)r[7]};
     }
 }
 
@@ -126,6 +129,7 @@ __device__ __forceinline__ void epi_row8(const EpiDev& e, unsigned m, int64_t n,
 #define TILE_BYTES (128 * 64 * 2)   // one operand tile, either orientation: 16 KiB
 #define CS_LD 132                   // f32 row stride of the epilogue staging image (128 + 4: conflict-free)
 #define FAST_LDS_BYTES (128 * CS_LD * 4)   // 67,584 B >= the 65,536 B of the two double-buffered operand tiles
+#define FAST_LDS_TOTAL (FAST_LDS_BYTES + 4 * 128 * 4)   // + column-sum scratch
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
@@ -265,11 +269,32 @@ gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __rest
         b0 = load4(e.bias + n0 + c8);
         b1 = load4(e.bias + n0 + c8 + 4);
     }
+    f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
 #pragma unroll
     for (int pass = 0; pass < 8; ++pass) {
         const int row = pass * 16 + r0;
         const float* src = cs + row * CS_LD + c8;
-        epi_row8(e, (unsigned)(m0 + row), n0 + c8, load4(src), load4(src + 4), b0, b1);
+        f32x4 v0 = load4(src), v1 = load4(src + 4);
+        epi_row8(e, (unsigned)(m0 + row), n0 + c8, v0, v1, b0, b1);
+        s0 += v0;
+        s1 += v1;
+    }
+    if (e.colpart) {
+        // fold the 16 row-threads of each 8-column group in a fixed order: 4 in-wave (xor 16, 32), then 4 waves via LDS
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s0[j] += __shfl_xor(s0[j], 16, 64); s0[j] += __shfl_xor(s0[j], 32, 64);
+            s1[j] += __shfl_xor(s1[j], 16, 64); s1[j] += __shfl_xor(s1[j], 32, 64);
+        }
+        float* cp = reinterpret_cast<float*>(smem + FAST_LDS_BYTES);   // [4 waves][128]
+        if (lane < 16) {
+            store4(cp + wid * 128 + c8, s0);
+            store4(cp + wid * 128 + c8 + 4, s1);
+        }
+        __syncthreads();
+        if (threadIdx.x < 128)
+            e.colpart[(int64_t)tm * e.N + n0 + threadIdx.x] =
+                ((cp[threadIdx.x] + cp[128 + threadIdx.x]) + cp[256 + threadIdx.x]) + cp[384 + threadIdx.x];
     }
 }
 
@@ -412,6 +437,8 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
         e.gate_ld = ep->gate_ld; e.resid = ep->resid; e.rowadd = ep->rowadd; e.rpb = ep->rows_per_batch;
         e.alpha = ep->alpha; e.beta = ep->beta; e.out_f32 = ep->out_f32;
     }
+    float* colsum_out = ep ? ep->colsum_out : nullptr;
+    const float colsum_beta = ep ? ep->colsum_beta : 0.f;
     VAW_CHECK_ARG(e.act >= 0 && e.act <= 2, "gemm: unknown act %d", e.act);
     VAW_CHECK_ARG(e.act != 2 || e.aux_in, "gemm: act=2 needs aux_in");
     VAW_CHECK_ARG(!(e.gate || e.rowadd) || e.rpb > 0, "gemm: gate/rowadd need rows_per_batch");
@@ -427,17 +454,21 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
     const bool epi_aligned = ldc % 8 == 0 && e.gate_ld % 4 == 0 &&
                              ((((uintptr_t)C | (uintptr_t)e.bias | (uintptr_t)e.aux_in | (uintptr_t)e.aux_out |
                                 (uintptr_t)e.gate | (uintptr_t)e.resid | (uintptr_t)e.rowadd) & 15) == 0);
+    VAW_CHECK_ARG(!colsum_out || (workspace && workspace_floats >= vaw_colsum_workspace_floats(M, N) &&
+                                  workspace_floats >= ((M + 127) / 128) * N),
+                  "gemm: colsum_out needs a workspace of max(ceil(M/128), ceil(M/512))*N floats");
     if (takes_fast_path(dt, M, N, K, A, lda, B, ldb) && epi_aligned) {
         const int tiles_n = (int)(N / BN);
         const int64_t n_wg = (M / BM) * tiles_n;
         VAW_CHECK_ARG(n_wg < (1LL << 31), "gemm: grid too large");
         const int nk_total = (int)(K / BK);
-        int split = pick_split(n_wg, K, M * N, workspace_floats, plain_f32);
+        int split = colsum_out ? 1 : pick_split(n_wg, K, M * N, workspace_floats, plain_f32);
+        if (colsum_out) e.colpart = workspace;
         if (split > 1) {   // no empty splits
             const int per = (nk_total + split - 1) / split;
             split = (nk_total + per - 1) / per;
         }
-        const size_t lds = FAST_LDS_BYTES;
+        const size_t lds = FAST_LDS_TOTAL;
         const bf16_t* a = (const bf16_t*)A;
         const bf16_t* b = (const bf16_t*)B;
         dim3 grid((unsigned)n_wg, (unsigned)split);
@@ -459,10 +490,11 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
             splitk_reduce_kernel<float><<<ceil_div(M * N / 4, 256) > 2048 ? 2048 : ceil_div(M * N / 4, 256), 256, 0, s>>>(
                 workspace, split, M, N, ldc, C, e.alpha, e.beta, 1);
         VAW_CHECK_LAUNCH("gemm_bf16");
+        if (colsum_out) return vaw_reduce_rows(workspace, M / BM, N, colsum_out, colsum_beta, stream);
         return VAW_OK;
     }
     const int64_t tiles = (int64_t)ceil_div(N, GBN) * ceil_div(M, GBM);
-    int split = pick_split(tiles, K, M * N, workspace_floats, plain_f32);
+    int split = colsum_out ? 1 : pick_split(tiles, K, M * N, workspace_floats, plain_f32);
     int64_t kchunk = K;
     if (split > 1) {
         kchunk = ((K + split - 1) / split + GBK - 1) / GBK * GBK;
@@ -484,5 +516,7 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
         splitk_reduce_kernel<float><<<ceil_div(M * N / 4, 256) > 2048 ? 2048 : ceil_div(M * N / 4, 256), 256, 0, s>>>(
             workspace, split, M, N, ldc, C, e.alpha, e.beta, 1);
     VAW_CHECK_LAUNCH("gemm_generic");
+    if (colsum_out)   // generic path: a separate pass over the output just written
+        return vaw_colsum(e.out_f32 ? VAW_F32 : dt, C, M, N, ldc, colsum_out, colsum_beta, workspace, workspace_floats, stream);
     return VAW_OK;
 }

@@ -61,7 +61,7 @@ row_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ x, const fl
                float* __restrict__ dscale, int64_t dmod_ld, int Tt, int D,
                // GATE_ONLY operands
                const float* __restrict__ dres, const T* __restrict__ y, const float* __restrict__ gate,
-               T* __restrict__ dy, float* __restrict__ dgate) {
+               T* __restrict__ dy, float* __restrict__ dgate, float* __restrict__ dy_colpart) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][D]
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int b = blockIdx.x;
@@ -83,8 +83,11 @@ row_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ x, const fl
                 if (c < D) {
                     f32x4 g = load4(dres + row * D + c);
                     f32x4 yv = load4(y + row * D + c);
-                    store4(dy + row * D + c, g * sc[i]);
+                    f32x4 d = g * sc[i];
+                    store4(dy + row * D + c, d);
                     acc0[i] += g * yv;
+                    f32x4 dr = {to_f32(from_f32<T>(d[0])), to_f32(from_f32<T>(d[1])), to_f32(from_f32<T>(d[2])), to_f32(from_f32<T>(d[3]))};
+                    acc1[i] += dr;                        // sum the values as stored (bf16-rounded in throughput mode)
                 }
             }
         } else {
@@ -131,7 +134,7 @@ row_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ x, const fl
                 const int c = (i * 64 + lane) * 4;
                 if (c < D) {
                     store4(s0 + c, load4(s0 + c) + acc0[i]);
-                    if (!GATE_ONLY) store4(s1p + c, load4(s1p + c) + acc1[i]);
+                    store4(s1p + c, load4(s1p + c) + acc1[i]);
                 }
             }
         }
@@ -140,6 +143,7 @@ row_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ x, const fl
     for (int c = threadIdx.x; c < D; c += blockDim.x) {
         if (GATE_ONLY) {
             dgate[(int64_t)b * dmod_ld + c] = s0[c];
+            if (dy_colpart) dy_colpart[(int64_t)b * D + c] = s1p[c];
         } else {
             dshift[(int64_t)b * dmod_ld + c] = s0[c];
             dscale[(int64_t)b * dmod_ld + c] = s1p[c];
@@ -191,25 +195,26 @@ extern "C" int vaw_ln_modulate_bwd(vaw_dtype dt, const void* dout, const float* 
     const int block = pick_block(T);
     const size_t lds = 2 * (size_t)D * sizeof(float);
     if (dt == VAW_F32) {
-        DISPATCH_NV(pick_nv(D), (row_bwd_kernel<float, NV, false><<<B, block, lds, s>>>((const float*)dout, x, mean, rstd, scale, mod_ld, dres_in, dx, dshift, dscale, dmod_ld, T, D, nullptr, nullptr, nullptr, nullptr, nullptr)));
+        DISPATCH_NV(pick_nv(D), (row_bwd_kernel<float, NV, false><<<B, block, lds, s>>>((const float*)dout, x, mean, rstd, scale, mod_ld, dres_in, dx, dshift, dscale, dmod_ld, T, D, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr)));
     } else {
-        DISPATCH_NV(pick_nv(D), (row_bwd_kernel<bf16_t, NV, false><<<B, block, lds, s>>>((const bf16_t*)dout, x, mean, rstd, scale, mod_ld, dres_in, dx, dshift, dscale, dmod_ld, T, D, nullptr, nullptr, nullptr, nullptr, nullptr)));
+        DISPATCH_NV(pick_nv(D), (row_bwd_kernel<bf16_t, NV, false><<<B, block, lds, s>>>((const bf16_t*)dout, x, mean, rstd, scale, mod_ld, dres_in, dx, dshift, dscale, dmod_ld, T, D, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr)));
     }
     VAW_CHECK_LAUNCH("ln_modulate_bwd");
     return VAW_OK;
 }
 
 extern "C" int vaw_gate_bwd(vaw_dtype dt, const float* dres, const void* y, const float* gate, int64_t mod_ld, void* dy,
-                            float* dgate, int64_t dmod_ld, int B, int T, int D, vaw_stream stream) {
+                            float* dgate, int64_t dmod_ld, float* dy_colsum_partial, int B, int T, int D,
+                            vaw_stream stream) {
     VAW_CHECK_ARG(B > 0 && T > 0 && D > 0 && D % 4 == 0 && D <= 2048 && mod_ld % 4 == 0,
                   "gate_bwd: need D%%4==0, D<=2048, mod_ld%%4==0 (D=%d)", D);
     hipStream_t s = (hipStream_t)stream;
     const int block = pick_block(T);
     const size_t lds = 2 * (size_t)D * sizeof(float);
     if (dt == VAW_F32) {
-        DISPATCH_NV(pick_nv(D), (row_bwd_kernel<float, NV, true><<<B, block, lds, s>>>(nullptr, nullptr, nullptr, nullptr, nullptr, mod_ld, nullptr, nullptr, nullptr, nullptr, dmod_ld, T, D, dres, (const float*)y, gate, (float*)dy, dgate)));
+        DISPATCH_NV(pick_nv(D), (row_bwd_kernel<float, NV, true><<<B, block, lds, s>>>(nullptr, nullptr, nullptr, nullptr, nullptr, mod_ld, nullptr, nullptr, nullptr, nullptr, dmod_ld, T, D, dres, (const float*)y, gate, (float*)dy, dgate, dy_colsum_partial)));
     } else {
-        DISPATCH_NV(pick_nv(D), (row_bwd_kernel<bf16_t, NV, true><<<B, block, lds, s>>>(nullptr, nullptr, nullptr, nullptr, nullptr, mod_ld, nullptr, nullptr, nullptr, nullptr, dmod_ld, T, D, dres, (const bf16_t*)y, gate, (bf16_t*)dy, dgate)));
+        DISPATCH_NV(pick_nv(D), (row_bwd_kernel<bf16_t, NV, true><<<B, block, lds, s>>>(nullptr, nullptr, nullptr, nullptr, nullptr, mod_ld, nullptr, nullptr, nullptr, nullptr, dmod_ld, T, D, dres, (const bf16_t*)y, gate, (bf16_t*)dy, dgate, dy_colsum_partial)));
     }
     VAW_CHECK_LAUNCH("gate_bwd");
     return VAW_OK;
@@ -244,15 +249,34 @@ colsum_partial_kernel(const T* __restrict__ X, int64_t M, int64_t N, int64_t ldx
         part_out[(int64_t)blockIdx.y * N + c] =
             ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
 }
-__global__ void colsum_final_kernel(const float* __restrict__ part, int64_t RB, int64_t N, float* __restrict__ out, float beta) {
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= N) return;
+// out[c] = beta*out[c] + sum_r part[r][c], r ascending within each of 32 interleaved row groups, groups folded in
+// ascending order: fixed summation tree.  32 columns x 32 row groups per 1024-thread block.
+__global__ void __launch_bounds__(1024)
+colsum_final_kernel(const float* __restrict__ part, int64_t RB, int64_t N, float* __restrict__ out, float beta) {
+    __shared__ float fold[32][33];
+    const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int64_t c = (int64_t)blockIdx.x * 32 + cl;
     float acc = 0.f;
-    for (int64_t r = 0; r < RB; ++r) acc += part[r * N + c];
-    out[c] = (beta != 0.f ? beta * out[c] : 0.f) + acc;
+    if (c < N)
+        for (int64_t r = grp; r < RB; r += 32) acc += part[r * N + c];
+    fold[grp][cl] = acc;
+    __syncthreads();
+    if (grp == 0 && c < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 32; ++g) t += fold[g][cl];
+        out[c] = (beta != 0.f ? beta * out[c] : 0.f) + t;
+    }
 }
 
 extern "C" int64_t vaw_colsum_workspace_floats(int64_t M, int64_t N) { return ((M + 511) / 512) * N; }
+
+extern "C" int vaw_reduce_rows(const float* partial, int64_t R, int64_t N, float* out, float beta, vaw_stream stream) {
+    VAW_CHECK_ARG(R > 0 && N > 0 && partial && out, "reduce_rows: bad arguments");
+    colsum_final_kernel<<<ceil_div(N, 32), 1024, 0, (hipStream_t)stream>>>(partial, R, N, out, beta);
+    VAW_CHECK_LAUNCH("reduce_rows");
+    return VAW_OK;
+}
 
 extern "C" int vaw_colsum(vaw_dtype dt, const void* X, int64_t M, int64_t N, int64_t ldx, float* out, float beta,
                           float* workspace, int64_t workspace_floats, vaw_stream stream) {
@@ -266,7 +290,7 @@ extern "C" int vaw_colsum(vaw_dtype dt, const void* X, int64_t M, int64_t N, int
     dim3 grid(ceil_div(N, 256), (int)RB);
     if (dt == VAW_F32) colsum_partial_kernel<float><<<grid, 256, 0, s>>>((const float*)X, M, N, ldx, workspace);
     else colsum_partial_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)X, M, N, ldx, workspace);
-    colsum_final_kernel<<<ceil_div(N, 256), 256, 0, s>>>(workspace, RB, N, out, beta);
+    colsum_final_kernel<<<ceil_div(N, 32), 1024, 0, s>>>(workspace, RB, N, out, beta);
     VAW_CHECK_LAUNCH("colsum");
     return VAW_OK;
 }

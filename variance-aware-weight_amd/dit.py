@@ -130,6 +130,7 @@ class _Workspace:
         self.dcs, self.dc, self.dc_a = e(B, D, dtype=f32), e(B, D, dtype=f32), e(B, D)
         self.dh1s, self.dh1, self.dh1_a = e(B, D, dtype=f32), e(B, D, dtype=f32), e(B, D)
         self.dxp = e(M, m.Kp, dtype=f32)
+        self.colpart = e(B, D, dtype=f32)
 
 
 class _DiTFn(torch.autograd.Function):
@@ -347,10 +348,12 @@ class DiT(FlatModule):
             d = self._adesc = ops.attn_desc_token_major(B, self.num_heads, self.T, self.D // self.num_heads)
         return d
 
-    def _wgrad(self, dt, name, dy, x, Nw, Kw, M, beta):
-        """dW[Nw,Kw] (+)= dy[M,Nw]^T x[M,Kw];  db[Nw] (+)= colsum(dy).  name = '<module>.' prefix."""
+    def _wgrad(self, dt, name, dy, x, Nw, Kw, M, beta, bias=True):
+        """dW[Nw,Kw] (+)= dy[M,Nw]^T x[M,Kw];  db[Nw] (+)= colsum(dy) unless the producer of dy already
+        delivered it (bias=False).  name = '<module>.' prefix."""
         ops.gemm(dt, 0, 0, Nw, Kw, M, dy, Nw, x, Kw, self._g(name + "weight"), Kw, beta=beta, out_f32=True)
-        ops.colsum(dt, dy, M, Nw, Nw, self._g(name + "bias"), beta)
+        if bias:
+            ops.colsum(dt, dy, M, Nw, Nw, self._g(name + "bias"), beta)
 
     def _backward_impl(self, dout, need_dx):
         ws = self._ws_cur
@@ -362,6 +365,7 @@ class DiT(FlatModule):
         self._gbase = self.flat_grads().data_ptr()
         hook = self.grad_ready_hook
         dres, dD, dDm, dmod = ptr(ws.dres), ptr(ws.dD), ptr(ws.dDm), ptr(ws.dmod)
+        colpart = ptr(ws.colpart)
         mod = ptr(ws.mod)
         # head: unpatchify^T, final linear, final LN+modulate
         L.check(lib.vaw_unpatchify_bwd(dt, ptr(dout), ptr(ws.dotok), B, self.out_channels, H, W, self.patch_size, st), "unpatchify_bwd")
@@ -377,16 +381,20 @@ class DiT(FlatModule):
             mo, dmo = mod + 4 * (6 * l * D), dmod + 4 * (6 * l * D)
             xin, xmid = ptr(ws.xres[2 * l]), ptr(ws.xres[2 * l + 1])
             # MLP branch
-            ops.gate_bwd(dt, dres, ptr(b["y2"]), mo + 4 * 5 * D, ld, dD, dmo + 4 * 5 * D, ld, B, T, D)
-            self._wgrad(dt, pre + "mlp.fc2.", dD, ptr(b["a"]), D, Dm, M, beta)
-            ops.gemm(dt, 1, 0, M, Dm, D, dD, D, self._w(pre + "mlp.fc2.weight"), Dm, dDm, Dm, act=2, aux_in=ptr(b["hpre"]))
-            self._wgrad(dt, pre + "mlp.fc1.", dDm, ptr(b["xm2"]), Dm, D, M, beta)
+            # bias gradients ride on the kernels that produce dy (per-sample partials / GEMM epilogue): no re-read
+            ops.gate_bwd(dt, dres, ptr(b["y2"]), mo + 4 * 5 * D, ld, dD, dmo + 4 * 5 * D, ld, B, T, D, colpart)
+            ops.reduce_rows(colpart, B, D, self._g(pre + "mlp.fc2.bias"), beta)
+            self._wgrad(dt, pre + "mlp.fc2.", dD, ptr(b["a"]), D, Dm, M, beta, bias=False)
+            ops.gemm(dt, 1, 0, M, Dm, D, dD, D, self._w(pre + "mlp.fc2.weight"), Dm, dDm, Dm, act=2, aux_in=ptr(b["hpre"]),
+                     colsum_out=self._g(pre + "mlp.fc1.bias"), colsum_beta=beta)
+            self._wgrad(dt, pre + "mlp.fc1.", dDm, ptr(b["xm2"]), Dm, D, M, beta, bias=False)
             ops.gemm(dt, 1, 0, M, D, Dm, dDm, Dm, self._w(pre + "mlp.fc1.weight"), D, dD, D)
             ops.ln_modulate_bwd(dt, dD, xmid, ptr(b["mean2"]), ptr(b["rstd2"]), mo + 4 * 4 * D, ld, dres, dres,
                                 dmo + 4 * 3 * D, dmo + 4 * 4 * D, ld, B, T, D)
             # attention branch
-            ops.gate_bwd(dt, dres, ptr(b["y1"]), mo + 4 * 2 * D, ld, dD, dmo + 4 * 2 * D, ld, B, T, D)
-            self._wgrad(dt, pre + "attn.proj.", dD, ptr(b["ao"]), D, D, M, beta)
+            ops.gate_bwd(dt, dres, ptr(b["y1"]), mo + 4 * 2 * D, ld, dD, dmo + 4 * 2 * D, ld, B, T, D, colpart)
+            ops.reduce_rows(colpart, B, D, self._g(pre + "attn.proj.bias"), beta)
+            self._wgrad(dt, pre + "attn.proj.", dD, ptr(b["ao"]), D, D, M, beta, bias=False)
             ops.gemm(dt, 1, 0, M, D, D, dD, D, self._w(pre + "attn.proj.weight"), D, ptr(ws.dao), D)
             q, dq = ptr(b["qkv"]), ptr(ws.dqkv)
             ops.attn_bwd(dt, self._attn_desc(B), q, q + es * D, q + 2 * es * D, ptr(b["ao"]), ptr(ws.dao), ptr(b["lse"]),

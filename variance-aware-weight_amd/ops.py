@@ -76,16 +76,17 @@ def weighted_mse(model_out, x0, noise, ca, cb, w):
 
 # ---- dense -------------------------------------------------------------------------------------
 def gemm(dt, a_kmajor, b_kmajor, M, N, K, A, lda, B, ldb, Cp, ldc, *, bias=None, act=0, aux_in=None, aux_out=None,
-         gate=None, gate_ld=0, resid=None, rowadd=None, rows_per_batch=0, alpha=1.0, beta=0.0, out_f32=False):
+         gate=None, gate_ld=0, resid=None, rowadd=None, rows_per_batch=0, alpha=1.0, beta=0.0, out_f32=False,
+         colsum_out=None, colsum_beta=0.0):
     """Raw-pointer GEMM; A, B, Cp, bias... are integers (device addresses).  See vaw_gemm in the header."""
     e = Epilogue(bias or None, act, aux_in or None, aux_out or None, gate or None, gate_ld, resid or None,
-                 rowadd or None, rows_per_batch, alpha, beta, 1 if out_f32 else 0)
+                 rowadd or None, rows_per_batch, alpha, beta, 1 if out_f32 else 0, colsum_out or None, colsum_beta)
     tr = gemm_trace
     if tr is not None:
         e0, e1 = tr.events()
         e0.record()
     ws_ptr, ws_n = 0, 0
-    if out_f32 and beta_or_plain(bias, act, aux_out, gate, resid, rowadd) and K >= 2048:
+    if colsum_out or (out_f32 and beta_or_plain(bias, act, aux_out, gate, resid, rowadd) and K >= 2048):
         ws = scratch_f32(torch.device("cuda", torch.cuda.current_device()), 0)
         ws_ptr, ws_n = ws.data_ptr(), ws.numel()
     check(L.lib().vaw_gemm(dt, 1 if a_kmajor else 0, 1 if b_kmajor else 0, M, N, K, A, lda, B, ldb, Cp, ldc,
@@ -128,7 +129,8 @@ gemm_trace = None
 
 
 def gemm_t(A, B, *, a_kmajor=True, b_kmajor=True, out_dtype=None, bias=None, act=0, aux_in=None, want_aux=False,
-           gate=None, resid=None, rowadd=None, rows_per_batch=0, alpha=1.0, beta=0.0, out=None):
+           gate=None, resid=None, rowadd=None, rows_per_batch=0, alpha=1.0, beta=0.0, out=None, colsum_out=None,
+           colsum_beta=0.0):
     """Tensor-level GEMM for tests and small call sites: A, B 2-D contiguous, same dtype."""
     need_cuda(A, B)
     assert A.dim() == 2 and B.dim() == 2 and A.is_contiguous() and B.is_contiguous() and A.dtype == B.dtype
@@ -144,7 +146,7 @@ def gemm_t(A, B, *, a_kmajor=True, b_kmajor=True, out_dtype=None, bias=None, act
     gemm(dt, a_kmajor, b_kmajor, M, N, K, ptr(A), A.shape[1], ptr(B), B.shape[1], ptr(out), N, bias=ptr(bias), act=act,
          aux_in=ptr(aux_in), aux_out=ptr(aux), gate=ptr(gate), gate_ld=(gate.shape[-1] if gate is not None else 0),
          resid=ptr(resid), rowadd=ptr(rowadd), rows_per_batch=rows_per_batch, alpha=alpha, beta=beta,
-         out_f32=(out.dtype == torch.float32))
+         out_f32=(out.dtype == torch.float32), colsum_out=ptr(colsum_out), colsum_beta=colsum_beta)
     return (out, aux) if want_aux else out
 
 
@@ -177,8 +179,13 @@ def ln_modulate_bwd(dt, dout, x, mean, rstd, scale, mod_ld, dres_in, dx, dshift,
                                       dmod_ld, B, T, D, stream_ptr()), "vaw_ln_modulate_bwd")
 
 
-def gate_bwd(dt, dres, y, gate, mod_ld, dy, dgate, dmod_ld, B, T, D):
-    check(L.lib().vaw_gate_bwd(dt, dres, y, gate, mod_ld, dy, dgate, dmod_ld, B, T, D, stream_ptr()), "vaw_gate_bwd")
+def gate_bwd(dt, dres, y, gate, mod_ld, dy, dgate, dmod_ld, B, T, D, dy_colpart=0):
+    check(L.lib().vaw_gate_bwd(dt, dres, y, gate, mod_ld, dy, dgate, dmod_ld, dy_colpart or None, B, T, D, stream_ptr()),
+          "vaw_gate_bwd")
+
+
+def reduce_rows(partial, R, N, out, beta):
+    check(L.lib().vaw_reduce_rows(partial, R, N, out, beta, stream_ptr()), "vaw_reduce_rows")
 
 
 def attn_desc_token_major(B, H, T, hd):
