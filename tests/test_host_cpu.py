@@ -1,0 +1,230 @@
+"""CPU-only checks of the product package: the C ABI loads and exports what include/vaw_hip.h declares, the
+host-side mirror of the reference interface (schedules, weight tables, samplers, LR schedule, flat parameter
+storage, checkpoints) matches the golden fixtures, and the HIP path refuses to run without a GPU instead of
+falling back.  No kernel is launched here."""
+import copy
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from conftest import GOLDEN, REPO, base_args, load_json, load_pt
+
+import vaw_amd
+from vaw_amd import gaussian_diffusion as gd
+from oracle import diffusion as od
+from oracle import dit as odit
+
+
+def test_c_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(REPO, "include", "vaw_hip.h")).read()
+    declared = set(re.findall(r"\b(vaw_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"vaw_epilogue", "vaw_attn_desc"}
+    assert len(declared) >= 30
+    lib = vaw_amd.lib()
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, f"libvaw_hip.so does not export {missing}"
+    assert set(vaw_amd.exported_symbols()) <= declared | {"vaw_version", "vaw_last_error_string"}
+    assert lib.vaw_version() >= 100 and isinstance(lib.vaw_last_error_string(), bytes)
+
+
+def test_no_cpu_fallback():
+    m = vaw_amd.DiT(image_size=8, patch_size=2, in_channels=4, hidden_size=64, depth=1, num_heads=2, num_classes=10)
+    with pytest.raises(vaw_amd.VawError):
+        m(torch.zeros(2, 4, 8, 8), torch.zeros(2), torch.zeros(2, dtype=torch.long))
+    d = _prod()
+    with pytest.raises(vaw_amd.VawError):
+        d.q_sample(torch.zeros(2, 3, 4, 4), torch.zeros(2, dtype=torch.long))
+    with pytest.raises(vaw_amd.VawError):
+        vaw_amd.ops.timestep_embedding(torch.zeros(3), 8)
+
+
+def _prod(sched="cosine", mt="EPSILON", wt="lambda", **kw):
+    return vaw_amd.GaussianDiffusion(args=base_args(weight_type=wt, **kw), betas=vaw_amd.get_named_beta_schedule(sched, 1000),
+                                     model_mean_type=vaw_amd.ModelMeanType[mt], model_var_type=vaw_amd.ModelVarType.FIXED_LARGE,
+                                     loss_type=vaw_amd.LossType.MSE, rescale_timesteps=True)
+
+
+def test_schedule_tables_bit_exact():
+    g = np.load(os.path.join(GOLDEN, "diffusion_tables.npz"))
+    for sched in ("linear", "cosine", "linear_logsnr"):
+        d = _prod(sched)
+        for k in g.files:
+            if k.startswith(sched + "."):
+                np.testing.assert_array_equal(getattr(d, k.split(".", 1)[1]), g[k], err_msg=k)
+    np.testing.assert_array_equal(vaw_amd.get_named_beta_schedule("linear", 250), g["linear250.betas"])
+    with pytest.raises(NotImplementedError):
+        vaw_amd.get_named_beta_schedule("nope", 10)
+    assert _prod()._scale_timesteps(torch.tensor([3])).dtype == torch.float32
+
+
+def test_loss_weight_function_and_device_table():
+    rec = load_json("loss_weight.json")
+    t = torch.tensor(rec["t"])
+    d0 = _prod()
+    for key, exp in rec["diffusion"].items():
+        mt, wt = key.split("/")
+        a = gd._extract_into_tensor(d0.sqrt_alphas_cumprod, t, t.shape).clone()
+        s = gd._extract_into_tensor(d0.sqrt_one_minus_alphas_cumprod, t, t.shape).clone()
+        if "error" in exp:
+            with pytest.raises(ValueError):
+                vaw_amd.compute_mse_loss_weight(vaw_amd.ModelMeanType[mt], wt, t, a, s, 1, 1)
+            continue
+        w = vaw_amd.compute_mse_loss_weight(vaw_amd.ModelMeanType[mt], wt, t, a, s, 1, 1)
+        assert str(w.dtype) == exp["dtype"]
+        np.testing.assert_array_equal(w.double().numpy(), np.array(exp["w"]), err_msg=key)
+        if mt != "VECTOR":
+            # the resident f32 weight table the kernels gather from == the reference's per-batch arithmetic
+            tb = _prod(mt=mt, wt=wt)._tables("cpu")
+            np.testing.assert_array_equal(tb["w"][t].double().numpy(), np.array(exp["w"], dtype=np.float64), err_msg=key)
+    tf = torch.tensor(rec["flow_t"], dtype=torch.float32)
+    for key, exp in rec["flow"].items():
+        parts = key.split("/")
+        fm = vaw_amd.FlowMatching(args=base_args(path_type=parts[0]), model_mean_type=vaw_amd.ModelMeanType.VECTOR)
+        if parts[1] == "interpolant":
+            for n, v in zip(("a", "s", "da", "ds"), fm.interpolant(tf)):
+                np.testing.assert_array_equal(v.double().numpy(), np.array(exp[n]), err_msg=key + n)
+    # oracle and product agree on every table entry for the recipe used by run.sh
+    o = od.GaussianDiffusion(args=base_args(), betas=od.get_named_beta_schedule("cosine", 1000),
+                             model_mean_type=od.ModelMeanType.EPSILON, model_var_type=od.ModelVarType.FIXED_LARGE,
+                             loss_type=od.LossType.MSE, rescale_timesteps=True)
+    tall = torch.arange(1000)
+    w_ref = od.compute_mse_loss_weight(od.ModelMeanType.EPSILON, "lambda", tall, od.extract(o.sqrt_alphas_cumprod, tall, tall.shape).clone(),
+                                       od.extract(o.sqrt_one_minus_alphas_cumprod, tall, tall.shape).clone())
+    assert torch.equal(_prod()._tables("cpu")["w"], w_ref)
+
+
+def test_unsupported_objectives_raise():
+    x = torch.zeros(2, 3, 4, 4)
+    d = vaw_amd.GaussianDiffusion(args=base_args(), betas=vaw_amd.get_named_beta_schedule("cosine", 10),
+                                  model_mean_type=vaw_amd.ModelMeanType.EPSILON,
+                                  model_var_type=vaw_amd.ModelVarType.LEARNED_RANGE, loss_type=vaw_amd.LossType.MSE)
+    with pytest.raises(NotImplementedError):
+        d.training_losses(lambda *a, **k: x, x, t=torch.zeros(2, dtype=torch.long), noise=x)
+    d = vaw_amd.GaussianDiffusion(args=base_args(), betas=vaw_amd.get_named_beta_schedule("cosine", 10),
+                                  model_mean_type=vaw_amd.ModelMeanType.EPSILON,
+                                  model_var_type=vaw_amd.ModelVarType.FIXED_LARGE, loss_type=vaw_amd.LossType.KL)
+    with pytest.raises(NotImplementedError):
+        d.training_losses(lambda *a, **k: x, x, t=torch.zeros(2, dtype=torch.long), noise=x)
+    with pytest.raises(NotImplementedError):
+        _prod(time_dist=["lognorm", 0, 1]).sample_t(x)
+    with pytest.raises(NotImplementedError):
+        vaw_amd.DiT(image_size=8, patch_size=2, hidden_size=64, depth=1, num_heads=2, learn_align=True)
+
+
+def test_lr_schedule_samplers_latent_sampling():
+    rec = load_json("misc.json")
+    for s, a, b, c in rec["lr"]:
+        assert vaw_amd.warmup_cosine_lr(s, 5, 50, 1e-4, 1e-6, True) == a
+        assert vaw_amd.warmup_cosine_lr(s, 5, 50, 1e-4, 1e-6, False) == b
+        assert vaw_amd.warmup_cosine_lr(s, 0, 50, 1e-4, 0.0, True) == c
+    from types import SimpleNamespace
+    diff = SimpleNamespace(num_timesteps=20)
+    s = vaw_amd.create_named_schedule_sampler("loss-second-moment", diff)
+    assert s.weights().tolist() == rec["lsm_weights_before"]
+    rng = np.random.RandomState(0)
+    for _ in range(15):
+        s.update_with_all_losses(list(range(20)), (rng.rand(20) * (1 + np.arange(20))).tolist())
+    np.testing.assert_allclose(s.weights(), rec["lsm_weights_after"], rtol=1e-14)
+    np.random.seed(3)
+    idx, w = s.sample(16, "cpu")
+    assert idx.tolist() == rec["lsm_sample_idx"]
+    np.testing.assert_allclose(w.double().numpy(), rec["lsm_sample_w"], rtol=1e-6)
+    s.update_with_local_losses(torch.tensor([1, 2]), torch.tensor([0.5, 0.25]))     # single-process branch
+    u = vaw_amd.create_named_schedule_sampler("uniform", diff)
+    np.random.seed(3)
+    idx, w = u.sample(8, "cpu")
+    assert idx.tolist() == rec["uni_sample_idx"] and w.double().tolist() == rec["uni_sample_w"]
+    with pytest.raises(NotImplementedError):
+        vaw_amd.create_named_schedule_sampler("nope", diff)
+    lat = torch.tensor(rec["sfl_in"], dtype=torch.float32)
+    torch.manual_seed(1)
+    assert vaw_amd.sample_from_latent(lat, 0.18215, cpu_rng=True).double().tolist() == rec["sfl_out"]
+
+
+def test_dit_same_seed_same_weights_and_keys_as_reference():
+    g = load_pt("dit_tiny.pt")
+    for tag in ("p2", "p4"):
+        torch.manual_seed(11)
+        p = vaw_amd.DiT(in_channels=4, class_dropout_prob=0.0, num_classes=10, learn_sigma=False, **g[f"{tag}/kw"])
+        torch.manual_seed(11)
+        o = odit.DiT(in_channels=4, class_dropout_prob=0.0, num_classes=10, learn_sigma=False, **g[f"{tag}/kw"])
+        sp, so = p.state_dict(), o.state_dict()
+        assert list(sp.keys()) == list(so.keys())
+        for k in sp:
+            assert torch.equal(sp[k], so[k]), k
+    b = vaw_amd.DiT_B(image_size=32, patch_size=4, in_channels=4, class_dropout_prob=0.1, num_classes=1000, learn_sigma=False)
+    ob = odit.DiT_B(image_size=32, patch_size=4, in_channels=4, class_dropout_prob=0.1, num_classes=1000, learn_sigma=False)
+    assert sum(p.numel() for p in b.parameters()) == sum(p.numel() for p in ob.parameters()) == 130_426_432
+    assert b.y_embedder.embedding_table.num_embeddings == 1001
+
+
+def test_flat_storage_views_groups_deepcopy_state_dict():
+    m = vaw_amd.DiT(image_size=8, patch_size=2, in_channels=4, hidden_size=64, depth=2, num_heads=2, num_classes=10)
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    m.ensure_flat()
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, before[k])
+    off = m._flat_offsets
+    # all adaLN weights are one contiguous [(6L+2)D, D] matrix, biases likewise
+    D = 64
+    assert off["blocks.1.adaLN_modulation.1.weight"][0] == off["blocks.0.adaLN_modulation.1.weight"][0] + 6 * D * D
+    assert off["final_layer.adaLN_modulation.1.weight"][0] == off["blocks.0.adaLN_modulation.1.weight"][0] + 12 * D * D
+    assert off["final_layer.adaLN_modulation.1.bias"][0] == off["blocks.0.adaLN_modulation.1.bias"][0] + 12 * D
+    p = m.blocks[0].attn.qkv.weight
+    assert p.data_ptr() == m._flat.data_ptr() + 4 * off["blocks.0.attn.qkv.weight"][0]
+    with torch.no_grad():
+        p.add_(1.0)
+    o0 = off["blocks.0.attn.qkv.weight"][0]
+    assert torch.equal(m._flat[o0:o0 + p.numel()].view_as(p), p)           # in-place updates land in the buffer
+    assert off["pos_embed"][0] >= m._flat_n_train                          # frozen entries sit after the trainable range
+    bounds = m.grad_stage_bounds()
+    covered = sorted(bounds.values())
+    assert covered[0][0] == 0 and covered[-1][1] == m._flat_n_train
+    assert all(a[1] == b[0] for a, b in zip(covered, covered[1:]))          # buckets tile the gradient buffer exactly
+    e = copy.deepcopy(m)
+    e.ensure_flat()
+    assert e._flat.data_ptr() != m._flat.data_ptr() and e._flat_offsets == m._flat_offsets
+    assert all(torch.equal(a, b) for a, b in zip(e.state_dict().values(), m.state_dict().values()))
+    e.load_state_dict(before)
+    assert torch.equal(e.blocks[0].attn.qkv.weight, before["blocks.0.attn.qkv.weight"])
+    m.attach_grads()
+    assert m.grads_live() and p.grad.data_ptr() == m.flat_grads().data_ptr() + 4 * o0
+    m.zero_grad_flat()
+    assert not m.grads_live()
+
+
+def test_checkpoint_roundtrip_and_module_prefix(tmp_path):
+    args = base_args(logdir=str(tmp_path), model="DiT-B", mean_type="EPSILON")
+    net = nn.Linear(4, 3)
+    ema_net = copy.deepcopy(net)
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-3)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=vaw_amd.get_lr_lambda(args))
+    net(torch.ones(2, 4)).sum().backward()
+    opt.step(); sched.step()
+    path = vaw_amd.save_checkpoint(args, 7, net, opt, ema_model=ema_net, scheduler=sched)
+    assert path.endswith("DiT-B_EPSILON_cosine_7.pth")
+    ck = torch.load(path, weights_only=True)
+    assert set(ck) == {"model", "optimizer", "step", "ema_model", "scheduler"} and ck["step"] == 7
+
+    class Wrapped(nn.Module):          # what a data-parallel wrapper looks like: keys get a 'module.' prefix
+        def __init__(self, m):
+            super().__init__()
+            self.module = m
+    net2, ema2 = Wrapped(nn.Linear(4, 3)), nn.Linear(4, 3)
+    opt2 = torch.optim.AdamW(net2.parameters(), lr=1e-3)
+    got = vaw_amd.load_checkpoint(path, model=net2, optimizer=opt2, ema_model=ema2)
+    assert got["step"] == 7 and torch.equal(net2.module.weight, net.weight) and torch.equal(ema2.weight, ema_net.weight)
+    path2 = vaw_amd.save_checkpoint(args, 8, net2, opt2)
+    assert all(k.startswith("module.") for k in torch.load(path2, weights_only=True)["model"])
+    net3 = nn.Linear(4, 3)
+    vaw_amd.load_checkpoint(path2, model=net3)                      # prefixed checkpoint into a bare model
+    assert torch.equal(net3.weight, net.weight)
+    args.parallel = False
+    vaw_amd.set_random_seed(args, 5)
+    a = torch.rand(3)
+    vaw_amd.set_random_seed(args, 5)
+    assert torch.equal(a, torch.rand(3))

@@ -65,6 +65,8 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", default="dit_b4")
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--only", default=None, help="substring of the shape name")
     a = ap.parse_args()
     for row in {"dit_b4": DIT_B4, "square": SQUARE, "all": DIT_B4 + SQUARE}[a.shapes]:
-        run(*row, a.iters)
+        if a.only is None or a.only in row[0]:
+            run(*row, a.iters)

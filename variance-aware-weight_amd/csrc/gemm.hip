@@ -15,6 +15,8 @@
 //   16x16x32 bf16: lane l holds A[row l&15][k = 8(l>>4)+j], B[k = 8(l>>4)+j][col l&15], j=0..7
 //   16x16x4  f32 : lane l holds A[row l&15][k = l>>4],       B[k = l>>4][col l&15]
 //   C/D (both)   : col = l&15, row = 4(l>>4) + reg
+#include <stdlib.h>
+
 #include "common.h"
 
 struct EpiDev {
@@ -32,6 +34,7 @@ struct EpiDev {
     int64_t M, N, ldc;
     void* C;
     float* slab;   // split-K partial sums [n_split][M][N] f32 (workspace), or NULL
+    int debug;        // measurement only (VAW_GEMM_DEBUG): 1 = skip the epilogue, 2 = skip the K loop
     float* colpart;   // [M/128][N] f32: per-row-tile column sums of the OUTPUT (bias gradient of the next layer), or NULL
 };
 
@@ -122,37 +125,54 @@ __device__ __forceinline__ void epi_row8(const EpiDev& e, unsigned m, int64_t n,
 
 // =============================================================================================
 // Fast path: bf16, M%128==0, N%128==0, K%64==0, 16-byte aligned rows.
+// Template BKT = K depth of one pipeline stage:
+//   64: 2 x 32 KiB of operand tiles, 2 workgroups per CU -- long-K launches (weight gradients)
+//   32: 2 x 16 KiB, epilogue staged in two 64-row halves (33 KiB) -> up to 4 workgroups per CU, so that the
+//       HBM-bound epilogue of one workgroup overlaps the MFMA loop of the others -- short-K launches (K = 768)
 // =============================================================================================
 #define BM 128
 #define BN 128
-#define BK 64
-#define TILE_BYTES (128 * 64 * 2)   // one operand tile, either orientation: 16 KiB
+#define BK 64                       // granularity the dispatcher requires of K
 #define CS_LD 132                   // f32 row stride of the epilogue staging image (128 + 4: conflict-free)
-#define FAST_LDS_BYTES (128 * CS_LD * 4)   // 67,584 B >= the 65,536 B of the two double-buffered operand tiles
-#define FAST_LDS_TOTAL (FAST_LDS_BYTES + 4 * 128 * 4)   // + column-sum scratch
+#define CS_BYTES (64 * CS_LD * 4)   // one 64-row half: 33,792 B
+#define CP_BYTES (4 * 128 * 4)      // column-sum scratch
+
+template <int BKT> struct FastCfg {
+    static constexpr int tile_bytes = 128 * BKT * 2;
+    static constexpr int stage_bytes = 2 * tile_bytes;
+    static constexpr int main_bytes = 2 * stage_bytes;
+    static constexpr int lds_bytes = (main_bytes > CS_BYTES ? main_bytes : CS_BYTES) + CP_BYTES;
+};
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
-// k-major image: [128 rows][8 chunks of 16 B]; chunk' = chunk ^ ((row>>1)&7)  -> conflict-free ds_read_b128
-__device__ __forceinline__ int kmaj_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
-// mn-major image: [64 k-rows][16 chunks of 16 B]; chunk' = chunk ^ (((row&3)<<2)|((row>>2)&3))
+// k-major image [128 rows][BKT/8 chunks of 16 B].  The XOR keeps every 16-lane group of a ds_read_b128 of the
+// 16x16x32 fragment (row = l&15, chunk = 4s + (l>>4)) on 16 distinct 16-byte slots of the 256-byte bank row:
+//   BKT=64 (128-B rows): chunk' = chunk ^ ((row>>1)&7);   BKT=32 (64-B rows): chunk' = chunk ^ ((-(row>>2))&3)
+template <int BKT>
+__device__ __forceinline__ int kmaj_swz(int row) { return BKT == 64 ? ((row >> 1) & 7) : ((-(row >> 2)) & 3); }
+template <int BKT>
+__device__ __forceinline__ int kmaj_off(int row, int chunk) { return row * (2 * BKT) + ((chunk ^ kmaj_swz<BKT>(row)) << 4); }
+// mn-major image: [BKT k-rows][16 chunks of 16 B]; chunk' = chunk ^ (((row&3)<<2)|((row>>2)&3))
 //   (image (b) of cdna_hip_programming.md T10: conflict-free ds_read_b64_tr_b16 for the 16x16x32 operand)
 __device__ __forceinline__ int mnmaj_off(int row, int chunk) {
     return row * 256 + ((chunk ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
 }
 
-// Stage one 128x64 (k-major) or 64x128 (mn-major) operand tile into LDS: 16 wave-instructions of 1 KiB,
-// 4 per wave.  g points at the tile's first element; ld = leading dimension in elements.
-template <bool KMAJOR>
+// Stage one 128 x BKT (k-major) or BKT x 128 (mn-major) operand tile into LDS by LDS-DMA: BKT/4 wave-instructions
+// of 1 KiB, BKT/16 per wave.  g points at the tile's first element; ld = leading dimension in elements.
+template <bool KMAJOR, int BKT>
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int64_t ld, char* lds_tile, int wid, int lane) {
+    constexpr int PER_WAVE = BKT / 16;
+    constexpr int CPR = BKT / 8;             // 16-byte chunks per k-major row
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int inst = wid * 4 + i;
+    for (int i = 0; i < PER_WAVE; ++i) {
+        const int inst = wid * PER_WAVE + i;
         const bf16_t* src;
         if (KMAJOR) {
-            const int row = inst * 8 + (lane >> 3);
-            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+            const int row = inst * (64 / CPR) + lane / CPR;
+            const int chunk = (lane % CPR) ^ kmaj_swz<BKT>(row);
             src = g + (int64_t)row * ld + chunk * 8;
         } else {
             const int row = inst * 4 + (lane >> 4);
@@ -164,11 +184,11 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int64_t
 }
 
 // Fragment of 16 (rows) x 32 (k) for k-substep s of the tile rows r0..r0+15.
-template <bool KMAJOR>
+template <bool KMAJOR, int BKT>
 __device__ __forceinline__ bf16x8 load_frag(const char* lds_tile, int r0, int s, int lane) {
     if (KMAJOR) {
         const int row = r0 + (lane & 15);
-        return *reinterpret_cast<const bf16x8*>(lds_tile + kmaj_off(row, 4 * s + (lane >> 4)));
+        return *reinterpret_cast<const bf16x8*>(lds_tile + kmaj_off<BKT>(row, 4 * s + (lane >> 4)));
     } else {
         const int li = lane & 15, q = li >> 2, p = li & 3;
         const int kb = 32 * s + 8 * (lane >> 4) + q;
@@ -182,11 +202,12 @@ __device__ __forceinline__ bf16x8 load_frag(const char* lds_tile, int r0, int s,
     }
 }
 
-template <bool AK, bool BKM>
-__global__ void __launch_bounds__(256, 2)
+template <bool AK, bool BKM, int BKT>
+__global__ void __launch_bounds__(256, BKT == 64 ? 2 : 3)
 gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb, int nk_total,
                  int tiles_n, int n_wg, int n_split, EpiDev e) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A tile | B tile]; reused by the epilogue
+    using Cfg = FastCfg<BKT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A tile | B tile]; reused by the epilogue
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // XCD-aware remap (bijective for any grid): blocks b, b+8, ... share an XCD; give each XCD a contiguous
@@ -196,14 +217,24 @@ gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __rest
         const int orig = blockIdx.x, xcd = orig & 7, q = n_wg >> 3, r = n_wg & 7;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     }
-    const int tm = wg / tiles_n, tn = wg % tiles_n;
+    // Within an XCD's run, walk the tiles in groups of 8 row panels (row fastest): the workgroups resident on
+    // an XCD then touch ~8 A panels + ~8 B panels (3 MB at K=768), which stay in its 4 MiB L2.
+    int tm, tn;
+    {
+        const int tiles_m = n_wg / tiles_n, per_group = 8 * tiles_n;
+        const int group = wg / per_group, first_m = group * 8;
+        const int gsize = tiles_m - first_m < 8 ? tiles_m - first_m : 8;
+        const int in_group = wg - group * per_group;
+        tm = first_m + in_group % gsize;
+        tn = in_group / gsize;
+    }
     const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
-    const int64_t a_step = AK ? BK : (int64_t)BK * lda;       // step along k: +BK (k-major) or +BK*lda
-    const int64_t b_step = BKM ? BK : (int64_t)BK * ldb;
-    // split-K: blockIdx.y owns k-tiles [kt0, kt0 + nk)
+    const int64_t a_step = AK ? BKT : (int64_t)BKT * lda;       // step along k: +BKT (k-major) or +BKT*lda
+    const int64_t b_step = BKM ? BKT : (int64_t)BKT * ldb;
+    // split-K: blockIdx.y owns k-tiles [kt0, kt0 + nk)   (nk_total counts BKT-deep tiles)
     const int nk_per = (nk_total + n_split - 1) / n_split;
     const int kt0 = blockIdx.y * nk_per;
-    const int nk = (kt0 + nk_per <= nk_total ? nk_per : nk_total - kt0);
+    const int nk = e.debug == 2 ? 1 : (kt0 + nk_per <= nk_total ? nk_per : nk_total - kt0);
     const bf16_t* Ag = (AK ? A + m0 * lda : A + m0) + kt0 * a_step;
     const bf16_t* Bg = (BKM ? B + n0 * ldb : B + n0) + kt0 * b_step;
     const int wm = (wid >> 1) * 64, wn = (wid & 1) * 64;
@@ -214,24 +245,24 @@ gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __rest
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
 
-    stage_tile<AK>(Ag, lda, smem, wid, lane);
-    stage_tile<BKM>(Bg, ldb, smem + TILE_BYTES, wid, lane);
+    stage_tile<AK, BKT>(Ag, lda, smem, wid, lane);
+    stage_tile<BKM, BKT>(Bg, ldb, smem + Cfg::tile_bytes, wid, lane);
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA for tile kt has landed
         __syncthreads();                                    // everyone's has; and tile kt-1 is no longer read
-        char* cur = smem + (kt & 1) * 2 * TILE_BYTES;
+        char* cur = smem + (kt & 1) * Cfg::stage_bytes;
         if (kt + 1 < nk) {
-            char* nxt = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
-            stage_tile<AK>(Ag + (kt + 1) * a_step, lda, nxt, wid, lane);
-            stage_tile<BKM>(Bg + (kt + 1) * b_step, ldb, nxt + TILE_BYTES, wid, lane);
+            char* nxt = smem + ((kt + 1) & 1) * Cfg::stage_bytes;
+            stage_tile<AK, BKT>(Ag + (kt + 1) * a_step, lda, nxt, wid, lane);
+            stage_tile<BKM, BKT>(Bg + (kt + 1) * b_step, ldb, nxt + Cfg::tile_bytes, wid, lane);
         }
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < BKT / 32; ++s) {
             bf16x8 af[4], bfr[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = load_frag<AK>(cur, wm + 16 * i, s, lane);
+            for (int i = 0; i < 4; ++i) af[i] = load_frag<AK, BKT>(cur, wm + 16 * i, s, lane);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[j] = load_frag<BKM>(cur + TILE_BYTES, wn + 16 * j, s, lane);
+            for (int j = 0; j < 4; ++j) bfr[j] = load_frag<BKM, BKT>(cur + Cfg::tile_bytes, wn + 16 * j, s, lane);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -239,54 +270,68 @@ gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __rest
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
     }
-    // ---- epilogue, phase 1: accumulators -> f32 staging image in LDS (the operand tiles are dead) ----
-    __syncthreads();
-    float* cs = reinterpret_cast<float*>(smem);
+    if (e.debug == 1) {   // keep the accumulators alive with one store per wave-quadrant
+        float t = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                cs[(wm + 16 * i + 4 * (lane >> 4) + r) * CS_LD + wn + 16 * j + (lane & 15)] = acc[i][j][r];
-    __syncthreads();
-    // ---- phase 2: each thread owns 8 consecutive columns of one row per pass: 16-byte loads and stores ----
-    const int c8 = (threadIdx.x & 15) * 8, r0 = threadIdx.x >> 4;
-    if (n_split > 1) {
-        float* slab = e.slab + (int64_t)blockIdx.y * e.M * e.N;
-#pragma unroll
-        for (int pass = 0; pass < 8; ++pass) {
-            const int row = pass * 16 + r0;
-            const float* src = cs + row * CS_LD + c8;
-            float* dst = slab + (m0 + row) * e.N + n0 + c8;
-            store4(dst, load4(src));
-            store4(dst + 4, load4(src + 4));
-        }
+            for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (t == 12345.678f) ((float*)e.C)[0] = t;
         return;
     }
+    // ---- epilogue in two 64-row halves: accumulators -> f32 staging image in LDS (the operand tiles are dead),
+    //      then each thread owns 8 consecutive columns of one row per pass: 16-byte loads and stores ----
+    float* cs = reinterpret_cast<float*>(smem);
+    const int c8 = (threadIdx.x & 15) * 8, r0 = threadIdx.x >> 4;
     f32x4 b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
-    if (e.bias) {
+    if (e.bias && n_split == 1) {
         b0 = load4(e.bias + n0 + c8);
         b1 = load4(e.bias + n0 + c8 + 4);
     }
     f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
 #pragma unroll
-    for (int pass = 0; pass < 8; ++pass) {
-        const int row = pass * 16 + r0;
-        const float* src = cs + row * CS_LD + c8;
-        f32x4 v0 = load4(src), v1 = load4(src + 4);
-        epi_row8(e, (unsigned)(m0 + row), n0 + c8, v0, v1, b0, b1);
-        s0 += v0;
-        s1 += v1;
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();
+        if ((wid >> 1) == half) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        cs[(16 * i + 4 * (lane >> 4) + r) * CS_LD + wn + 16 * j + (lane & 15)] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (n_split > 1) {
+            float* slab = e.slab + (int64_t)blockIdx.y * e.M * e.N;
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int row = pass * 16 + r0;
+                const float* src = cs + row * CS_LD + c8;
+                float* dst = slab + (m0 + 64 * half + row) * e.N + n0 + c8;
+                store4(dst, load4(src));
+                store4(dst + 4, load4(src + 4));
+            }
+        } else {
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int row = pass * 16 + r0;
+                const float* src = cs + row * CS_LD + c8;
+                f32x4 v0 = load4(src), v1 = load4(src + 4);
+                epi_row8(e, (unsigned)(m0 + 64 * half + row), n0 + c8, v0, v1, b0, b1);
+                s0 += v0;
+                s1 += v1;
+            }
+        }
     }
-    if (e.colpart) {
+    if (e.colpart && n_split == 1) {
         // fold the 16 row-threads of each 8-column group in a fixed order: 4 in-wave (xor 16, 32), then 4 waves via LDS
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             s0[j] += __shfl_xor(s0[j], 16, 64); s0[j] += __shfl_xor(s0[j], 32, 64);
             s1[j] += __shfl_xor(s1[j], 16, 64); s1[j] += __shfl_xor(s1[j], 32, 64);
         }
-        float* cp = reinterpret_cast<float*>(smem + FAST_LDS_BYTES);   // [4 waves][128]
+        float* cp = reinterpret_cast<float*>(smem + Cfg::lds_bytes - CP_BYTES);   // [4 waves][128]
         if (lane < 16) {
             store4(cp + wid * 128 + c8, s0);
             store4(cp + wid * 128 + c8 + 4, s1);
@@ -446,6 +491,11 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
     if (e.rpb <= 0) e.rpb = 1;
     if (dt == VAW_F32) e.out_f32 = 1;
     e.M = M; e.N = N; e.ldc = ldc; e.C = C; e.slab = workspace;
+    {
+        static int dbg = -1;
+        if (dbg < 0) { const char* v = getenv("VAW_GEMM_DEBUG"); dbg = v ? atoi(v) : 0; }
+        e.debug = dbg;
+    }
     hipStream_t s = (hipStream_t)stream;
     const bool plain_f32 = e.out_f32 && !e.bias && !e.act && !e.aux_out && !e.gate && !e.resid && !e.rowadd && N % 4 == 0 &&
                            ldc % 4 == 0 && ((uintptr_t)C & 15) == 0;
@@ -461,31 +511,42 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
         const int tiles_n = (int)(N / BN);
         const int64_t n_wg = (M / BM) * tiles_n;
         VAW_CHECK_ARG(n_wg < (1LL << 31), "gemm: grid too large");
-        const int nk_total = (int)(K / BK);
+        // stage depth: 64 for long K (weight gradients), 32 for the K <= 1024 forward / input-gradient launches
+        static int bk_env = -1;
+        if (bk_env < 0) { const char* v = getenv("VAW_GEMM_BK"); bk_env = v ? atoi(v) : 0; }
+        // measured on MI355X (tools/gemm_bench.py, DiT-B/4 shapes): the 32-deep stage (3 workgroups per CU) wins for
+        // the input-gradient layout (k-major x mn-major, 768 output tiles = exactly 3 per CU), the 64-deep one elsewhere
+        const int bkt = bk_env == 32 || bk_env == 64 ? bk_env : ((a_kmajor && !b_kmajor && K <= 4096) ? 32 : 64);
+        const int nk_total = (int)(K / bkt);
         int split = colsum_out ? 1 : pick_split(n_wg, K, M * N, workspace_floats, plain_f32);
         if (colsum_out) e.colpart = workspace;
         if (split > 1) {   // no empty splits
             const int per = (nk_total + split - 1) / split;
             split = (nk_total + per - 1) / per;
         }
-        const size_t lds = FAST_LDS_TOTAL;
         const bf16_t* a = (const bf16_t*)A;
         const bf16_t* b = (const bf16_t*)B;
         dim3 grid((unsigned)n_wg, (unsigned)split);
-#define LAUNCH_FAST(AKv, BKv)                                                                                        \
-    do {                                                                                                             \
-        static bool attr_done = false;                                                                               \
-        if (!attr_done) {                                                                                            \
-            (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AKv, BKv>,                                       \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
-            attr_done = true;                                                                                        \
-        }                                                                                                            \
-        gemm_bf16_kernel<AKv, BKv><<<grid, 256, lds, s>>>(a, lda, b, ldb, nk_total, tiles_n, (int)n_wg, split, e);   \
+#define LAUNCH_FAST(AKv, BKv, BKTv)                                                                                   \
+    do {                                                                                                              \
+        static bool attr_done = false;                                                                                \
+        const int lds = FastCfg<BKTv>::lds_bytes;                                                                     \
+        if (!attr_done) {                                                                                             \
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AKv, BKv, BKTv>,                                  \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);                               \
+            attr_done = true;                                                                                         \
+        }                                                                                                             \
+        gemm_bf16_kernel<AKv, BKv, BKTv><<<grid, 256, lds, s>>>(a, lda, b, ldb, nk_total, tiles_n, (int)n_wg, split, e); \
     } while (0)
-        if (a_kmajor && b_kmajor) LAUNCH_FAST(true, true);
-        else if (a_kmajor && !b_kmajor) LAUNCH_FAST(true, false);
-        else if (!a_kmajor && b_kmajor) LAUNCH_FAST(false, true);
-        else LAUNCH_FAST(false, false);
+#define LAUNCH_FAST_BK(BKTv)                                         \
+    do {                                                             \
+        if (a_kmajor && b_kmajor) LAUNCH_FAST(true, true, BKTv);     \
+        else if (a_kmajor && !b_kmajor) LAUNCH_FAST(true, false, BKTv); \
+        else if (!a_kmajor && b_kmajor) LAUNCH_FAST(false, true, BKTv); \
+        else LAUNCH_FAST(false, false, BKTv);                        \
+    } while (0)
+        if (bkt == 32) LAUNCH_FAST_BK(32);
+        else LAUNCH_FAST_BK(64);
         if (split > 1)
             splitk_reduce_kernel<float><<<ceil_div(M * N / 4, 256) > 2048 ? 2048 : ceil_div(M * N / 4, 256), 256, 0, s>>>(
                 workspace, split, M, N, ldc, C, e.alpha, e.beta, 1);
