@@ -86,7 +86,9 @@ def cpu_baseline(wl, budget_s=25.0):
     """The CPU oracle (torch restatement of the reference path, pinned by tests/golden) on this host."""
     from oracle import diffusion as od, dit as odit, trainer as otr
     torch.manual_seed(42)
-    B = 16
+    # a one-GPU box gives this job a 16-core CPU share; more threads than that only thrash
+    torch.set_num_threads(int(os.environ.get("VAW_CPU_THREADS", "16")))
+    B = 32
     args = make_args(amp=False, defer_loss_sync=False)
     model = odit.DiT_models[wl["model"]](image_size=32, patch_size=wl["patch"], in_channels=4, class_dropout_prob=0.0,
                                          num_classes=1000, learn_sigma=False)
