@@ -68,7 +68,7 @@ typedef struct {
     void* aux_out;         /* act dtype [M,N] (ld = ldc): value BEFORE act/gate/residual is stored here, or NULL */
     const float* gate;     /* f32: gate[(m / rows_per_batch) * gate_ld + n], or NULL */
     int64_t gate_ld;
-    const float* resid;    /* f32 [M,N] (ld = ldc) residual stream added AFTER the gate, or NULL */
+    const void* resid;     /* [M,N] (ld = ldc) residual added AFTER the gate, or NULL; f32 unless resid_is_act */
     const float* rowadd;   /* f32 [rows_per_batch, N] added by (m % rows_per_batch): frozen pos_embed, or NULL */
     int rows_per_batch;    /* tokens per sample (T); required when gate/rowadd is set */
     float alpha;           /* scales the accumulator first */
@@ -78,6 +78,7 @@ typedef struct {
                             * i.e. the bias gradient of the layer whose output gradient this GEMM produces; taken in
                             * the epilogue (no second pass over C); needs the workspace */
     float colsum_beta;
+    int resid_is_act;      /* 1: resid has the act dtype (UNet skip connections), 0: f32 (DiT residual stream) */
 } vaw_epilogue;
 
 /* C[M,N] = epilogue( alpha * op(A)[M,K] . op(B)[K,N] )
@@ -171,6 +172,39 @@ int vaw_attn_fwd(vaw_dtype dt, const vaw_attn_desc* d_host, const void* q, const
 int vaw_attn_bwd(vaw_dtype dt, const vaw_attn_desc* d_host, const void* q, const void* k, const void* v,
                  const void* o, const void* d_o, const float* lse, float* delta, void* dq, void* dk, void* dv,
                  vaw_stream stream);
+
+/* ---------------------------------------------------------------------------
+ * UNet pieces  (models/unet.py, tools/nn.py) -- activations are NHWC: [B*H*W pixels, C channels], act dtype
+ * ------------------------------------------------------------------------- */
+
+/* GroupNorm32 (tools/nn.py:17-19,93-100; G groups, eps) fused with what follows it in ResBlock._forward
+ * (unet.py:236-256):  y = act( GN(x)*gamma + beta [ *(1 + scale[b,c]) + shift[b,c] ] ), act = SiLU if silu else id.
+ * scale/shift: f32 rows with stride film_ld (the emb_layers output), or both NULL.  mean/rstd: f32 [B*G] saved.
+ * workspace: vaw_groupnorm_workspace_floats(B, C) f32. */
+int64_t vaw_groupnorm_workspace_floats(int B, int C);
+int vaw_groupnorm_fwd(vaw_dtype dt, const void* x, const float* gamma, const float* beta, const float* scale,
+                      const float* shift, int64_t film_ld, int silu, void* y, float* mean, float* rstd, int B, int HW,
+                      int C, int G, float eps, float* workspace, vaw_stream stream);
+/* dx = GN'(...) (+ dx_add, act dtype, may be NULL); dgamma/dbeta = grad_beta*old + sum; dscale/dshift rows (stride
+ * dfilm_ld) when FiLM.  Fixed-order reductions. */
+int vaw_groupnorm_bwd(vaw_dtype dt, const void* dout, const void* x, const float* mean, const float* rstd,
+                      const float* gamma, const float* beta, const float* scale, const float* shift, int64_t film_ld,
+                      int silu, const void* dx_add, void* dx, float* dgamma, float* dbeta, float grad_beta, float* dscale,
+                      float* dshift, int64_t dfilm_ld, int B, int HW, int C, int G, float* workspace, vaw_stream stream);
+/* conv3x3 stride 1 pad 1 as GEMM (round 1: explicit patch matrix).  col[m, tap*C + c] = x[pixel(m)+tap offset, c];
+ * vaw_col2im3x3 is the transposed map written as a gather (deterministic): the input gradient from d(col). */
+int vaw_im2col3x3(vaw_dtype dt, const void* x, void* col, int B, int H, int W, int C, vaw_stream stream);
+int vaw_col2im3x3(vaw_dtype dt, const void* dcol, void* dx, int B, int H, int W, int C, vaw_stream stream);
+/* mode 0: out[Ho,Wo] = s * sum of the 2x2 block of in[2Ho,2Wo] (avg_pool2d with s=1/4; nearest-upsample^T with s=1)
+ * mode 1: out[Ho,Wo] = s * in[Ho/2,Wo/2]                        (nearest x2 with s=1; avg_pool2d^T with s=1/4) */
+int vaw_resample2(vaw_dtype dt, const void* in, void* out, int B, int Ho, int Wo, int C, int mode, float s,
+                  vaw_stream stream);
+/* cat[m,:] = [a[m,:Ca] | b[m,:Cb]] (torch.cat(dim=1) of unet.py:684 in NHWC); split=1 copies cat back into a and b */
+int vaw_concat_channels(vaw_dtype dt, void* a, void* b, void* cat, int64_t M, int Ca, int Cb, int split,
+                        vaw_stream stream);
+int vaw_add_inplace(vaw_dtype dt, void* dst, const void* src, int64_t n, vaw_stream stream);
+int vaw_nchw_to_nhwc(vaw_dtype dt, const float* nchw, void* nhwc, int B, int C, int HW, vaw_stream stream);
+int vaw_nhwc_to_nchw(vaw_dtype dt, const void* nhwc, float* nchw, int B, int C, int HW, vaw_stream stream);
 
 /* ---------------------------------------------------------------------------
  * Optimizer side  (torch.optim.AdamW at main.py:354, ema() tools/trainer.py:12-18,

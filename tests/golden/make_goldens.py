@@ -253,6 +253,9 @@ def gen_unet_tiny():
         "new": dict(image_size=16, in_channels=3, model_channels=32, out_channels=3, num_res_blocks=1,
                     attention_resolutions=(2,), channel_mult=(1, 2), num_classes=10, num_heads=2,
                     use_scale_shift_norm=True, resblock_updown=True, use_new_attention_order=True),
+        "legacy_ss": dict(image_size=16, in_channels=3, model_channels=32, out_channels=3, num_res_blocks=1,
+                          attention_resolutions=(1, 2), channel_mult=(1, 2), num_classes=0, num_heads=1, num_head_channels=16,
+                          use_scale_shift_norm=True, resblock_updown=True, use_new_attention_order=False),
         "legacy": dict(image_size=16, in_channels=3, model_channels=32, out_channels=6, num_res_blocks=1,
                        attention_resolutions=(1, 2), channel_mult=(1, 3), num_classes=0, num_heads=1,
                        num_head_channels=16, use_scale_shift_norm=False, resblock_updown=False,

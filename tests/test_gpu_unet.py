@@ -1,0 +1,223 @@
+"""Parity of the HIP UNet path: each UNet-side kernel against a float64 torch statement, the tiny UNets against
+the reference's golden fixtures (forward, input gradient, every parameter gradient), and the cfg1 `Trainer`
+trajectories of the reference.  Run on the MI355X box: pytest -m gpu."""
+import copy
+import random
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import Pbar, assert_fingerprints, base_args, load_json, load_pt, perturb_, synth_loader
+
+pytestmark = pytest.mark.gpu
+
+import vaw_amd
+from vaw_amd import ops
+from vaw_amd._lib import BF16, F32, lib, ptr, stream_ptr
+
+DEV = "cuda"
+
+
+def _rand(*shape, seed=0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+def _nhwc(x):   # [B,C,H,W] -> [B*H*W, C]
+    return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous()
+
+
+def _nchw(m, B, H, W):
+    return m.reshape(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,C,H,film,silu", [(2, 64, 8, True, True), (3, 96, 5, False, True), (2, 32, 4, False, False), (1, 192, 16, True, True)])
+def test_groupnorm_film_silu_fwd_bwd(dtype, B, C, H, film, silu):
+    tol = dict(rtol=2e-5, atol=2e-5) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2)
+    HW = H * H
+    x = (_rand(B, C, H, H, seed=1) * 1.5 + 0.3).to(dtype)
+    gamma, beta = _rand(C, seed=2) * 0.5 + 1, _rand(C, seed=3) * 0.2
+    emb = _rand(B, 3 * C, seed=4) * 0.3
+    dout = _rand(B, C, H, H, seed=5).to(dtype)
+    dadd = _rand(B, C, H, H, seed=6).to(dtype)
+    xr = x.double().requires_grad_(True)
+    gr, br, er = gamma.double().requires_grad_(True), beta.double().requires_grad_(True), emb.double().requires_grad_(True)
+    ref = F.group_norm(xr, 32, gr, br, eps=1e-5)
+    if film:
+        ref = ref * (1 + er[:, C:2 * C, None, None]) + er[:, 2 * C:, None, None]
+    if silu:
+        ref = F.silu(ref)
+    (ref * dout.double()).sum().backward()
+    dt = F32 if dtype == torch.float32 else BF16
+    xd, gd, bd, ed = _nhwc(x).to(DEV), gamma.to(DEV), beta.to(DEV), emb.to(DEV)
+    y = torch.empty(B * HW, C, device=DEV, dtype=dtype)
+    mean, rstd = torch.empty(B * 32, device=DEV), torch.empty(B * 32, device=DEV)
+    ws = torch.empty(lib().vaw_groupnorm_workspace_floats(B, C), device=DEV)
+    sc = ptr(ed) + 4 * C if film else None
+    sh = ptr(ed) + 8 * C if film else None
+    assert lib().vaw_groupnorm_fwd(dt, ptr(xd), ptr(gd), ptr(bd), sc, sh, 3 * C, int(silu), ptr(y), ptr(mean), ptr(rstd), B, HW, C, 32,
+                                   1e-5, ptr(ws), stream_ptr()) == 0
+    torch.testing.assert_close(_nchw(y.cpu().double(), B, H, H), ref.detach(), **tol)
+    dod, dad = _nhwc(dout).to(DEV), _nhwc(dadd).to(DEV)
+    dx = torch.empty_like(xd)
+    dg, db = torch.ones(C, device=DEV), torch.ones(C, device=DEV)
+    demb = torch.zeros(B, 3 * C, device=DEV)
+    assert lib().vaw_groupnorm_bwd(dt, ptr(dod), ptr(xd), ptr(mean), ptr(rstd), ptr(gd), ptr(bd), sc, sh, 3 * C, int(silu), ptr(dad),
+                                   ptr(dx), ptr(dg), ptr(db), 1.0, (ptr(demb) + 4 * C) if film else None,
+                                   (ptr(demb) + 8 * C) if film else None, 3 * C, B, HW, C, 32, ptr(ws), stream_ptr()) == 0
+    torch.testing.assert_close(_nchw(dx.cpu().double(), B, H, H), xr.grad + dadd.double(), **tol)
+    rt = tol["rtol"]
+    torch.testing.assert_close(dg.cpu().double(), 1 + gr.grad, rtol=rt, atol=tol["atol"] * 10)   # grad_beta=1 accumulates
+    torch.testing.assert_close(db.cpu().double(), 1 + br.grad, rtol=rt, atol=tol["atol"] * 10)
+    if film:
+        torch.testing.assert_close(demb.cpu().double(), er.grad, rtol=rt, atol=tol["atol"] * 10)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,C,H,W", [(2, 8, 5, 7), (1, 3, 6, 6), (2, 64, 8, 8)])
+def test_im2col_col2im_match_unfold_fold(dtype, B, C, H, W):
+    x = _rand(B, C, H, W, seed=1).to(dtype)
+    dt = F32 if dtype == torch.float32 else BF16
+    xd = _nhwc(x).to(DEV)
+    col = torch.empty(B * H * W, 9 * C, device=DEV, dtype=dtype)
+    assert lib().vaw_im2col3x3(dt, ptr(xd), ptr(col), B, H, W, C, stream_ptr()) == 0
+    # F.unfold orders columns (c, kh, kw); ours (kh, kw, c)
+    ref = F.unfold(x.float(), 3, padding=1).view(B, C, 9, H * W).permute(0, 3, 2, 1).reshape(B * H * W, 9 * C)
+    assert torch.equal(col.cpu().float(), ref)
+    dcol = _rand(B * H * W, 9 * C, seed=2).to(dtype)
+    dx = torch.empty(B * H * W, C, device=DEV, dtype=dtype)
+    dcd = dcol.to(DEV)
+    assert lib().vaw_col2im3x3(dt, ptr(dcd), ptr(dx), B, H, W, C, stream_ptr()) == 0
+    folded = F.fold(dcol.double().view(B, H * W, 9, C).permute(0, 3, 2, 1).reshape(B, C * 9, H * W), (H, W), 3, padding=1)
+    tol = dict(rtol=1e-6, atol=1e-6) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(_nchw(dx.cpu().double(), B, H, W), folded, **tol)
+
+
+def test_conv3x3_via_gemm_matches_torch_and_weight_layout():
+    """conv = im2col + GEMM against the weight stored channels-last ([Co][3][3][Ci])."""
+    B, Ci, Co, H = 2, 16, 24, 6
+    x, w, b = _rand(B, Ci, H, H, seed=1), _rand(Co, Ci, 3, 3, seed=2) * 0.2, _rand(Co, seed=3)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    xd = _nhwc(x).to(DEV)
+    col = torch.empty(B * H * H, 9 * Ci, device=DEV)
+    lib().vaw_im2col3x3(F32, ptr(xd), ptr(col), B, H, H, Ci, stream_ptr())
+    wk = w.permute(0, 2, 3, 1).reshape(Co, 9 * Ci).contiguous().to(DEV)
+    y = ops.gemm_t(col, wk, bias=b.to(DEV))
+    torch.testing.assert_close(_nchw(y.cpu().double(), B, H, H), ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_resample_concat_layout(dtype):
+    B, C, H = 2, 8, 6
+    dt = F32 if dtype == torch.float32 else BF16
+    x = _rand(B, C, H, H, seed=1).to(dtype)
+    xd = _nhwc(x).to(DEV)
+    dn = torch.empty(B * (H // 2) ** 2, C, device=DEV, dtype=dtype)
+    assert lib().vaw_resample2(dt, ptr(xd), ptr(dn), B, H // 2, H // 2, C, 0, 0.25, stream_ptr()) == 0
+    torch.testing.assert_close(_nchw(dn.cpu().float(), B, H // 2, H // 2), F.avg_pool2d(x.float(), 2), rtol=1e-2, atol=1e-2)
+    up = torch.empty(B * (2 * H) ** 2, C, device=DEV, dtype=dtype)
+    assert lib().vaw_resample2(dt, ptr(xd), ptr(up), B, 2 * H, 2 * H, C, 1, 1.0, stream_ptr()) == 0
+    assert torch.equal(_nchw(up.cpu().float(), B, 2 * H, 2 * H), F.interpolate(x.float(), scale_factor=2, mode="nearest"))
+    a, b = _rand(10, 8, seed=2).to(dtype).to(DEV), _rand(10, 12, seed=3).to(dtype).to(DEV)
+    cat = torch.empty(10, 20, device=DEV, dtype=dtype)
+    assert lib().vaw_concat_channels(dt, ptr(a), ptr(b), ptr(cat), 10, 8, 12, 0, stream_ptr()) == 0
+    assert torch.equal(cat, torch.cat([a, b], 1))
+    a2, b2 = torch.empty_like(a), torch.empty_like(b)
+    assert lib().vaw_concat_channels(dt, ptr(a2), ptr(b2), ptr(cat), 10, 8, 12, 1, stream_ptr()) == 0
+    assert torch.equal(a2, a) and torch.equal(b2, b)
+    xin = _rand(B, 3, H, H, seed=4).to(DEV)
+    nh = torch.empty(B * H * H, 3, device=DEV, dtype=dtype)
+    assert lib().vaw_nchw_to_nhwc(dt, ptr(xin), ptr(nh), B, 3, H * H, stream_ptr()) == 0
+    back = torch.empty_like(xin)
+    assert lib().vaw_nhwc_to_nchw(dt, ptr(nh), ptr(back), B, 3, H * H, stream_ptr()) == 0
+    torch.testing.assert_close(back, xin, rtol=1e-2 if dtype == torch.bfloat16 else 0, atol=1e-2 if dtype == torch.bfloat16 else 0)
+
+
+@pytest.mark.parametrize("tag", ["new", "legacy_ss"])
+def test_unet_tiny_fp32_matches_reference_golden(tag):
+    g = load_pt("unet_tiny.pt")
+    torch.manual_seed(21)
+    m = vaw_amd.UNetModel(compute_dtype="fp32", **g[f"{tag}/kw"])
+    assert_fingerprints(m.state_dict(), g[f"{tag}/init_sd"], 1e-6, 1e-9, "same seed => the reference's initial weights")
+    m = m.to(DEV).train()
+    perturb_(m, 77, std=0.03)
+    x, t, gout = (g[f"{tag}/{k}"].to(DEV) for k in ("x", "t", "gout"))
+    y = g[f"{tag}/y"].to(DEV) if g[f"{tag}/y"].numel() else None
+    xr = x.clone().requires_grad_(True)
+    out = m(xr, t, y=y) if y is not None else m(xr, t)
+    (out * gout).sum().backward()
+    torch.testing.assert_close(out.detach().cpu(), g[f"{tag}/out"], rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(xr.grad.cpu(), g[f"{tag}/gx"], rtol=1e-4, atol=2e-5)
+    grads = {k: p.grad.cpu() for k, p in m.named_parameters() if p.grad is not None}
+    assert_fingerprints(grads, g[f"{tag}/grads"], 1e-4, 2e-5, "parameter gradients")
+    # second backward accumulates (torch convention)
+    g1 = {k: v.clone() for k, v in grads.items()}
+    out = m(xr, t, y=y) if y is not None else m(xr, t)
+    (out * gout).sum().backward()
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            torch.testing.assert_close(p.grad.cpu(), 2 * g1[k], rtol=1e-5, atol=1e-6)
+
+
+def test_unet_tiny_bf16_close_to_reference():
+    g = load_pt("unet_tiny.pt")
+    tag = "new"
+    torch.manual_seed(21)
+    m = vaw_amd.UNetModel(compute_dtype="bf16", **g[f"{tag}/kw"]).to(DEV).train()
+    perturb_(m, 77, std=0.03)
+    x, t, gout, y = (g[f"{tag}/{k}"].to(DEV) for k in ("x", "t", "gout", "y"))
+    out = m(x, t, y=y)
+    (out * gout).sum().backward()
+    ref = g[f"{tag}/out"]
+    assert float((out.detach().cpu() - ref).norm() / ref.norm()) < 4e-2
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            gl2 = float(g[f"{tag}/grads"][k]["stats"][2])
+            if gl2 < 1e-2:
+                continue      # e.g. a conv bias feeding GroupNorm: its exact gradient is 0, bf16 leaves rounding noise
+            assert abs(float(p.grad.double().norm()) - gl2) <= 8e-2 * gl2 + 1e-3, k
+
+
+def _run_trainer(model, args, batches, steps, fused):
+    ema_model = copy.deepcopy(model)
+    if fused:
+        opt = vaw_amd.FusedAdamW(model, lr=args.lr, betas=(0.9, 0.95), weight_decay=0.0, eps=1e-8)
+    else:
+        opt = torch.optim.AdamW(model.parameters(), lr=args.lr, betas=(0.9, 0.95), weight_decay=0.0, eps=1e-8)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=vaw_amd.get_lr_lambda(args))
+    diff = vaw_amd.GaussianDiffusion(args=args, betas=vaw_amd.get_named_beta_schedule(args.path_type, 1000),
+                                     model_mean_type=vaw_amd.ModelMeanType.EPSILON,
+                                     model_var_type=vaw_amd.ModelVarType.FIXED_LARGE, loss_type=vaw_amd.LossType.MSE,
+                                     rescale_timesteps=True)
+    tr = vaw_amd.Trainer(args, torch.device(DEV), model, ema_model, opt, sched, diff, batches, Pbar())
+    losses = [tr.train_step(s) for s in range(1, steps + 1)]
+    psum = float(sum(p.double().abs().sum() for p in model.parameters()))
+    esum = float(sum(v.double().abs().sum() for v in ema_model.state_dict().values()))
+    return losses, psum, esum
+
+
+CFG1 = lambda: vaw_amd.UNetModel(32, 3, 64, 3, 2, attention_resolutions=(), channel_mult=(1, 2, 2, 2), num_heads=4,
+                                 use_scale_shift_norm=True, resblock_updown=True, use_new_attention_order=True,
+                                 compute_dtype="fp32")
+
+
+@pytest.mark.parametrize("name,args,steps,fused", [
+    ("cfg1", base_args(cpu_rng=True), 5, True),
+    ("cfg1", base_args(cpu_rng=True), 5, False),
+    ("cfg1_accum2_clip", base_args(grad_accumulation=2, grad_clip=1.0, cpu_rng=True), 3, True),
+    ("cfg1_warmup_cosine_minsnr", base_args(weight_type="min_snr_5", warmup_steps=2, cosine_decay=True, total_steps=10,
+                                            final_lr=1e-5, cpu_rng=True), 4, True),
+])
+def test_trainer_trajectory_cfg1_unet_fp32_vs_reference(name, args, steps, fused):
+    """BASELINE config 1 (CIFAR-10-shaped UNet, 10.4 M parameters, batch 16): the reference's CPU Trainer
+    trajectories (tests/golden/trainer.json; cfg1 is the trajectory quoted in BASELINE.md §2) vs the HIP path in
+    f32 parity mode with the CPU RNG stream injected.  Tolerance: north_star's 1e-4 relative per step."""
+    exp = load_json("trainer.json")[name]
+    random.seed(42); np.random.seed(42); torch.manual_seed(42)
+    model = CFG1().to(DEV)
+    losses, psum, esum = _run_trainer(model, args, synth_loader(16, 3, 32, 4, 0), steps, fused)
+    np.testing.assert_allclose(losses, exp["losses"], rtol=1e-4)
+    assert psum == pytest.approx(exp["param_abs_sum"], rel=1e-5)
+    assert esum == pytest.approx(exp["ema_abs_sum"], rel=1e-6)

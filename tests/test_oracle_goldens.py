@@ -131,7 +131,7 @@ def test_dit_tiny_matches_reference(tag):
     assert torch.equal(m.unpatchify(tok), x)
 
 
-@pytest.mark.parametrize("tag", ["new", "legacy"])
+@pytest.mark.parametrize("tag", ["new", "legacy", "legacy_ss"])
 def test_unet_tiny_matches_reference(tag):
     g = load_pt("unet_tiny.pt")
     torch.manual_seed(21)

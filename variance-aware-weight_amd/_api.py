@@ -3,6 +3,8 @@ from . import dist_util, gaussian_diffusion, ops, resample, utils  # noqa: F401
 from ._lib import LIB_PATH, VawError, exported_symbols, lib  # noqa: F401
 from .dit import DiT, DiT_B, DiT_L, DiT_S, DiT_XL, DiT_models  # noqa: F401
 from .flat import FlatModule  # noqa: F401
+from .unet import (ADM_32, ADM_64, ADM_128, ADM_256, ADM_512, LDM, UNet_32, UNet_64, UNet_models, UNetModel,  # noqa: F401
+                   create_unet_model)
 from .gaussian_diffusion import (FlowMatching, GaussianDiffusion, LossType, ModelMeanType, ModelVarType,  # noqa: F401
                                  compute_mse_loss_weight, get_named_beta_schedule, mean_flat)
 from .optim import FusedAdamW  # noqa: F401

@@ -17,7 +17,7 @@ _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 class Epilogue(C.Structure):
     _fields_ = [("bias", _p), ("act", _i), ("aux_in", _p), ("aux_out", _p), ("gate", _p), ("gate_ld", _l),
                 ("resid", _p), ("rowadd", _p), ("rows_per_batch", _i), ("alpha", _f), ("beta", _f), ("out_f32", _i),
-                ("colsum_out", _p), ("colsum_beta", _f)]
+                ("colsum_out", _p), ("colsum_beta", _f), ("resid_is_act", _i)]
 
 
 class AttnDesc(C.Structure):
@@ -49,6 +49,15 @@ _PROTOS = {
     "vaw_embedding_bwd": [_p, _p, _p, _i, _i, _i, _f, _p],
     "vaw_attn_fwd": [_i, C.POINTER(AttnDesc), _p, _p, _p, _p, _p, _p],
     "vaw_attn_bwd": [_i, C.POINTER(AttnDesc), _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "vaw_groupnorm_fwd": [_i, _p, _p, _p, _p, _p, _l, _i, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p],
+    "vaw_groupnorm_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _l, _i, _p, _p, _p, _p, _f, _p, _p, _l, _i, _i, _i, _i, _p, _p],
+    "vaw_im2col3x3": [_i, _p, _p, _i, _i, _i, _i, _p],
+    "vaw_col2im3x3": [_i, _p, _p, _i, _i, _i, _i, _p],
+    "vaw_resample2": [_i, _p, _p, _i, _i, _i, _i, _i, _f, _p],
+    "vaw_concat_channels": [_i, _p, _p, _p, _l, _i, _i, _i, _p],
+    "vaw_add_inplace": [_i, _p, _p, _l, _p],
+    "vaw_nchw_to_nhwc": [_i, _p, _p, _i, _i, _i, _p],
+    "vaw_nhwc_to_nchw": [_i, _p, _p, _i, _i, _i, _p],
     "vaw_sumsq": [_p, _l, _p, _i, _p, _p],
     "vaw_adamw_ema_step": [_p, _p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _f, _f, _p, _f, _i, _p],
     "vaw_ema_update": [_p, _p, _l, _f, _p],
@@ -78,6 +87,8 @@ def lib():
         L.vaw_last_error_string.restype = C.c_char_p
         L.vaw_colsum_workspace_floats.argtypes = [_l, _l]
         L.vaw_colsum_workspace_floats.restype = _l
+        L.vaw_groupnorm_workspace_floats.argtypes = [_i, _i]
+        L.vaw_groupnorm_workspace_floats.restype = _l
         L.vaw_sumsq_workspace_floats.argtypes = []
         L.vaw_sumsq_workspace_floats.restype = _l
         L.vaw_debug_force_rowwise_attention.argtypes = [_i]
@@ -90,7 +101,7 @@ def lib():
 
 def exported_symbols():
     return sorted(list(_PROTOS) + ["vaw_version", "vaw_last_error_string", "vaw_colsum_workspace_floats",
-                                   "vaw_sumsq_workspace_floats"])
+                                   "vaw_sumsq_workspace_floats", "vaw_groupnorm_workspace_floats"])
 
 
 def check(rc, what):

@@ -26,7 +26,8 @@ struct EpiDev {
     void* aux_out;
     const float* gate;
     int64_t gate_ld;
-    const float* resid;
+    const void* resid;
+    int resid_act;    // 1: resid has act dtype (UNet skip/residual adds), 0: f32 (DiT residual stream)
     const float* rowadd;
     int rpb;
     float alpha, beta;
@@ -58,7 +59,7 @@ __device__ __forceinline__ void epi_store4(const EpiDev& e, int64_t m, int64_t n
         else if (e.act == 2) v *= gelu_tanh_grad_f(to_f32(((const TO*)e.aux_in)[off]));
         const unsigned mu = (unsigned)mm, rpb = (unsigned)e.rpb;
         if (e.gate) v *= e.gate[(int64_t)(mu / rpb) * e.gate_ld + n];
-        if (e.resid) v += e.resid[off];
+        if (e.resid) v += e.resid_act ? to_f32(((const TO*)e.resid)[off]) : ((const float*)e.resid)[off];
         if (e.rowadd) v += e.rowadd[(int64_t)(mu % rpb) * e.N + n];
         if (e.out_f32) {
             float* c = (float*)e.C + off;
@@ -98,8 +99,13 @@ __device__ __forceinline__ void epi_row8(const EpiDev& e, unsigned m, int64_t n,
         v1 *= load4(g + 4);
     }
     if (e.resid) {
-        v0 += load4(e.resid + off);
-        v1 += load4(e.resid + off + 4);
+        if (e.resid_act) {
+            v0 += load4((const bf16_t*)e.resid + off);
+            v1 += load4((const bf16_t*)e.resid + off + 4);
+        } else {
+            v0 += load4((const float*)e.resid + off);
+            v1 += load4((const float*)e.resid + off + 4);
+        }
     }
     if (e.rowadd) {
         const float* ra = e.rowadd + (int64_t)(m % rpb) * e.N + n;
@@ -480,7 +486,7 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
     if (ep) {
         e.bias = ep->bias; e.act = ep->act; e.aux_in = ep->aux_in; e.aux_out = ep->aux_out; e.gate = ep->gate;
         e.gate_ld = ep->gate_ld; e.resid = ep->resid; e.rowadd = ep->rowadd; e.rpb = ep->rows_per_batch;
-        e.alpha = ep->alpha; e.beta = ep->beta; e.out_f32 = ep->out_f32;
+        e.alpha = ep->alpha; e.beta = ep->beta; e.out_f32 = ep->out_f32; e.resid_act = ep->resid_is_act;
     }
     float* colsum_out = ep ? ep->colsum_out : nullptr;
     const float colsum_beta = ep ? ep->colsum_beta : 0.f;

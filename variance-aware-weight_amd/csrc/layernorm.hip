@@ -269,6 +269,17 @@ colsum_final_kernel(const float* __restrict__ part, int64_t RB, int64_t N, float
     }
 }
 
+// any alignment / any N (e.g. the 3-channel output conv): one thread per (row block, column)
+template <typename T>
+__global__ void colsum_partial_scalar_kernel(const T* __restrict__ X, int64_t M, int64_t N, int64_t ldx, float* __restrict__ part_out) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    const int64_t r0 = (int64_t)blockIdx.y * 512, r1 = r0 + 512 < M ? r0 + 512 : M;
+    float acc = 0.f;
+    for (int64_t r = r0; r < r1; ++r) acc += to_f32(X[r * ldx + c]);
+    part_out[(int64_t)blockIdx.y * N + c] = acc;
+}
+
 extern "C" int64_t vaw_colsum_workspace_floats(int64_t M, int64_t N) { return ((M + 511) / 512) * N; }
 
 extern "C" int vaw_reduce_rows(const float* partial, int64_t R, int64_t N, float* out, float beta, vaw_stream stream) {
@@ -281,15 +292,20 @@ extern "C" int vaw_reduce_rows(const float* partial, int64_t R, int64_t N, float
 extern "C" int vaw_colsum(vaw_dtype dt, const void* X, int64_t M, int64_t N, int64_t ldx, float* out, float beta,
                           float* workspace, int64_t workspace_floats, vaw_stream stream) {
     VAW_CHECK_ARG(M > 0 && N > 0 && ldx >= N, "colsum: bad sizes");
-    VAW_CHECK_ARG((ldx % 4 == 0) && (((uintptr_t)X & 15) == 0), "colsum: X must be 16-byte aligned with ldx%%4==0");
+    const bool vec = (ldx % 4 == 0) && (((uintptr_t)X & 15) == 0);
     const int64_t RB = (M + 511) / 512;
     VAW_CHECK_ARG(workspace && workspace_floats >= RB * N, "colsum: workspace too small (%ld < %ld floats)",
                   (long)workspace_floats, (long)(RB * N));
     VAW_CHECK_ARG(RB < 65536, "colsum: M too large");
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(ceil_div(N, 256), (int)RB);
-    if (dt == VAW_F32) colsum_partial_kernel<float><<<grid, 256, 0, s>>>((const float*)X, M, N, ldx, workspace);
-    else colsum_partial_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)X, M, N, ldx, workspace);
+    if (vec) {
+        if (dt == VAW_F32) colsum_partial_kernel<float><<<grid, 256, 0, s>>>((const float*)X, M, N, ldx, workspace);
+        else colsum_partial_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)X, M, N, ldx, workspace);
+    } else {
+        if (dt == VAW_F32) colsum_partial_scalar_kernel<float><<<grid, 256, 0, s>>>((const float*)X, M, N, ldx, workspace);
+        else colsum_partial_scalar_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)X, M, N, ldx, workspace);
+    }
     colsum_final_kernel<<<ceil_div(N, 32), 1024, 0, s>>>(workspace, RB, N, out, beta);
     VAW_CHECK_LAUNCH("colsum");
     return VAW_OK;

@@ -1,0 +1,429 @@
+// UNet-side kernels (reference models/unet.py + tools/nn.py), all on NHWC ("pixels x channels") activations so
+// that every conv is a GEMM over M = B*H*W pixel rows and the attention qkv rows are token-major:
+//   GroupNorm32 (+ FiLM scale/shift, + SiLU) forward / backward      tools/nn.py:17-19,93-100, unet.py:236-256
+//   im2col / col2im for conv3x3 pad 1 (round 1: explicit patch matrix, GEMM does the arithmetic)
+//   2x2 average pool, nearest x2 upsample (+ their transposes), channel concat / split, NCHW <-> NHWC
+// All HBM-bound, 4 channels per thread (16 B f32 / 8 B bf16), reductions in a fixed order (no float atomics).
+#include "common.h"
+
+static inline int sgrid(int64_t work, int block) {
+    int64_t g = (work + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+#define GRID_STRIDE(i, n) for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm statistics.  Stage 1: per (sample, channel) sums over the HW pixels, 64 channels x 4 row groups per
+// block (coalesced 128-B rows of bf16).  Stage 2: fold the C/G channels of each group.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int NS>   // NS sums per channel
+struct ChanSums {
+    float v[NS];
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+gn_chan_stats_kernel(const T* __restrict__ x, int HW, int C, float* __restrict__ sum, float* __restrict__ sumsq) {
+    __shared__ float red[2][4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl, b = blockIdx.y;
+    float s = 0.f, q = 0.f;
+    if (c < C) {
+        const T* p = x + (int64_t)b * HW * C + c;
+        for (int r = rg; r < HW; r += 4) {
+            const float v = to_f32(p[(int64_t)r * C]);
+            s += v;
+            q += v * v;
+        }
+    }
+    red[0][rg][cl] = s;
+    red[1][rg][cl] = q;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        sum[(int64_t)b * C + c] = ((red[0][0][cl] + red[0][1][cl]) + red[0][2][cl]) + red[0][3][cl];
+        sumsq[(int64_t)b * C + c] = ((red[1][0][cl] + red[1][1][cl]) + red[1][2][cl]) + red[1][3][cl];
+    }
+}
+
+__global__ void gn_group_stats_kernel(const float* __restrict__ sum, const float* __restrict__ sumsq, int B, int C, int G,
+                                      int HW, float eps, float* __restrict__ mean, float* __restrict__ rstd) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * G) return;
+    const int b = i / G, g = i % G, cg = C / G;
+    double s = 0.0, q = 0.0;
+    for (int j = 0; j < cg; ++j) {
+        s += (double)sum[(int64_t)b * C + g * cg + j];
+        q += (double)sumsq[(int64_t)b * C + g * cg + j];
+    }
+    const double n = (double)cg * HW;
+    const double m = s / n;
+    double var = q / n - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[i] = (float)m;
+    rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// y = act( GN(x)*gamma + beta [ *(1+scale[b,c]) + shift[b,c] ] ),  act = SiLU or identity
+template <typename T>
+__global__ void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                const float* __restrict__ scale, const float* __restrict__ shift, int64_t film_ld,
+                                int silu, T* __restrict__ y, int B, int HW, int C, int G) {
+    const int cg = C / G;
+    const int64_t total4 = (int64_t)B * HW * C / 4;
+    GRID_STRIDE(i, total4) {
+        const int64_t e = 4 * i;
+        const int c = (int)(e % C);
+        const int b = (int)(e / ((int64_t)HW * C));
+        f32x4 v = load4(x + e), r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int g = (c + j) / cg;
+            float n = (v[j] - mean[b * G + g]) * rstd[b * G + g] * gamma[c + j] + beta[c + j];
+            if (scale) n = n * (1.f + scale[(int64_t)b * film_ld + c + j]) + shift[(int64_t)b * film_ld + c + j];
+            r[j] = silu ? silu_f(n) : n;
+        }
+        store4(y + e, r);
+    }
+}
+
+// Backward stage 1: per (sample, channel) sums over pixels of
+//   A = dn1*xhat, Bs = dn1, DS = dn2*n1, DH = dn2     (n1 = xhat*gamma+beta, n2 = FiLM(n1), dn2 = dout*act'(n2), dn1 = dn2*(1+scale))
+template <typename T>
+__global__ void __launch_bounds__(256)
+gn_bwd_chan_kernel(const T* __restrict__ dout, const T* __restrict__ x, const float* __restrict__ mean,
+                   const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                   const float* __restrict__ scale, const float* __restrict__ shift, int64_t film_ld, int silu, int HW,
+                   int C, int G, float* __restrict__ A, float* __restrict__ Bs, float* __restrict__ DS,
+                   float* __restrict__ DH) {
+    __shared__ float red[4][4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl, b = blockIdx.y;
+    float a = 0.f, bs = 0.f, ds = 0.f, dh = 0.f;
+    if (c < C) {
+        const int g = c / (C / G);
+        const float mu = mean[b * G + g], rs = rstd[b * G + g], ga = gamma[c], be = beta[c];
+        const float sc = scale ? scale[(int64_t)b * film_ld + c] : 0.f, sh = scale ? shift[(int64_t)b * film_ld + c] : 0.f;
+        const int64_t base = (int64_t)b * HW * C + c;
+        for (int r = rg; r < HW; r += 4) {
+            const float xh = (to_f32(x[base + (int64_t)r * C]) - mu) * rs;
+            const float n1 = xh * ga + be;
+            const float n2 = scale ? n1 * (1.f + sc) + sh : n1;
+            const float dn2 = to_f32(dout[base + (int64_t)r * C]) * (silu ? silu_grad_f(n2) : 1.f);
+            const float dn1 = scale ? dn2 * (1.f + sc) : dn2;
+            a += dn1 * xh;
+            bs += dn1;
+            ds += dn2 * n1;
+            dh += dn2;
+        }
+    }
+    red[0][rg][cl] = a; red[1][rg][cl] = bs; red[2][rg][cl] = ds; red[3][rg][cl] = dh;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        const int64_t o = (int64_t)b * C + c;
+        A[o] = ((red[0][0][cl] + red[0][1][cl]) + red[0][2][cl]) + red[0][3][cl];
+        Bs[o] = ((red[1][0][cl] + red[1][1][cl]) + red[1][2][cl]) + red[1][3][cl];
+        if (scale) {
+            DS[o] = ((red[2][0][cl] + red[2][1][cl]) + red[2][2][cl]) + red[2][3][cl];
+            DH[o] = ((red[3][0][cl] + red[3][1][cl]) + red[3][2][cl]) + red[3][3][cl];
+        }
+    }
+}
+
+// Backward stage 2: per (b,g): S1 = sum_c gamma_c*Bs, S2 = sum_c gamma_c*A; per c: dgamma, dbeta over samples (fixed order)
+__global__ void gn_bwd_group_kernel(const float* __restrict__ A, const float* __restrict__ Bs, const float* __restrict__ gamma,
+                                    int B, int C, int G, float* __restrict__ S1, float* __restrict__ S2,
+                                    float* __restrict__ dgamma, float* __restrict__ dbeta, float gbeta) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int cg = C / G;
+    if (i < B * G) {
+        const int b = i / G, g = i % G;
+        float s1 = 0.f, s2 = 0.f;
+        for (int j = 0; j < cg; ++j) {
+            const int c = g * cg + j;
+            s1 += gamma[c] * Bs[(int64_t)b * C + c];
+            s2 += gamma[c] * A[(int64_t)b * C + c];
+        }
+        S1[i] = s1;
+        S2[i] = s2;
+    }
+    if (i < C) {
+        float dg = 0.f, db = 0.f;
+        for (int b = 0; b < B; ++b) {
+            dg += A[(int64_t)b * C + i];
+            db += Bs[(int64_t)b * C + i];
+        }
+        dgamma[i] = (gbeta != 0.f ? gbeta * dgamma[i] : 0.f) + dg;
+        dbeta[i] = (gbeta != 0.f ? gbeta * dbeta[i] : 0.f) + db;
+    }
+}
+
+// Backward stage 3: dx = rstd * (dn1*gamma - S1/N - xhat*S2/N)  (+ dx_add if given)
+template <typename T>
+__global__ void gn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ x, const float* __restrict__ mean,
+                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, const float* __restrict__ scale,
+                                    const float* __restrict__ shift, int64_t film_ld, int silu,
+                                    const float* __restrict__ S1, const float* __restrict__ S2, const T* __restrict__ dx_add,
+                                    T* __restrict__ dx, int B, int HW, int C, int G) {
+    const int cg = C / G;
+    const float invn = 1.f / ((float)cg * HW);
+    const int64_t total4 = (int64_t)B * HW * C / 4;
+    GRID_STRIDE(i, total4) {
+        const int64_t e = 4 * i;
+        const int c = (int)(e % C);
+        const int b = (int)(e / ((int64_t)HW * C));
+        f32x4 xv = load4(x + e), dv = load4(dout + e), r;
+        f32x4 add = dx_add ? load4(dx_add + e) : f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int g = (c + j) / cg;
+            const float rs = rstd[b * G + g];
+            const float xh = (xv[j] - mean[b * G + g]) * rs;
+            const float n1 = xh * gamma[c + j] + beta[c + j];
+            float sc = 0.f;
+            float n2 = n1;
+            if (scale) {
+                sc = scale[(int64_t)b * film_ld + c + j];
+                n2 = n1 * (1.f + sc) + shift[(int64_t)b * film_ld + c + j];
+            }
+            const float dn2 = dv[j] * (silu ? silu_grad_f(n2) : 1.f);
+            const float dn1 = scale ? dn2 * (1.f + sc) : dn2;
+            r[j] = rs * (dn1 * gamma[c + j] - S1[b * G + g] * invn - xh * S2[b * G + g] * invn) + add[j];
+        }
+        store4(dx + e, r);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv3x3 (stride 1, pad 1) patch matrix: col[m, tap*C + c] = x[pixel(m) + (tap/3-1, tap%3-1), c]  (0 outside)
+// col2im is its transpose as a GATHER: dx[p, c] = sum_tap dcol[p - shift(tap), tap*C + c]
+// ---------------------------------------------------------------------------------------------
+template <typename T, int V>
+__global__ void im2col3x3_kernel(const T* __restrict__ x, T* __restrict__ col, int B, int H, int W, int C) {
+    const int64_t total = (int64_t)B * H * W * 9 * (C / V);
+    GRID_STRIDE(i, total) {
+        const int cv = (int)(i % (C / V));
+        int64_t r = i / (C / V);
+        const int tap = (int)(r % 9);
+        const int64_t m = r / 9;
+        const int w = (int)(m % W), h = (int)((m / W) % H);
+        const int hh = h + tap / 3 - 1, ww = w + tap % 3 - 1;
+        T* dst = col + (m * 9 + tap) * C + cv * V;
+        const bool in = hh >= 0 && hh < H && ww >= 0 && ww < W;
+        const T* src = x + (m + (int64_t)(tap / 3 - 1) * W + (tap % 3 - 1)) * C + cv * V;
+        if (V == 4) {
+            store4(dst, in ? load4(src) : f32x4{0, 0, 0, 0});
+        } else {
+            dst[0] = in ? src[0] : from_f32<T>(0.f);
+        }
+    }
+}
+
+template <typename T, int V>
+__global__ void col2im3x3_kernel(const T* __restrict__ dcol, T* __restrict__ dx, int B, int H, int W, int C) {
+    const int64_t total = (int64_t)B * H * W * (C / V);
+    GRID_STRIDE(i, total) {
+        const int cv = (int)(i % (C / V));
+        const int64_t p = i / (C / V);
+        const int w = (int)(p % W), h = (int)((p / W) % H);
+        f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dh = tap / 3 - 1, dw = tap % 3 - 1;
+            const int hh = h - dh, ww = w - dw;     // the pixel whose patch holds p at position `tap`
+            if (hh >= 0 && hh < H && ww >= 0 && ww < W) {
+                const T* src = dcol + ((p - (int64_t)dh * W - dw) * 9 + tap) * C + cv * V;
+                if (V == 4) acc += load4(src);
+                else acc[0] += to_f32(src[0]);
+            }
+        }
+        if (V == 4) store4(dx + p * C + cv * 4, acc);
+        else dx[p * C + cv] = from_f32<T>(acc[0]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// resampling, concat, layout
+// ---------------------------------------------------------------------------------------------
+// mode 0: out[b,h,w,:] = mean of the 2x2 block of in (in is 2H x 2W)          (avg_pool2d; also nearest-upsample^T * 1/4 * 4)
+// mode 1: out[b,h,w,:] = in[b,h/2,w/2,:] * s                                     (nearest x2; also avg_pool^T with s = 1/4)
+template <typename T>
+__global__ void resample2_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int Ho, int Wo, int C, int mode, float s) {
+    const int64_t total4 = (int64_t)B * Ho * Wo * C / 4;
+    GRID_STRIDE(i, total4) {
+        const int64_t e = 4 * i;
+        const int c = (int)(e % C);
+        int64_t r = e / C;
+        const int w = (int)(r % Wo), h = (int)((r / Wo) % Ho), b = (int)(r / ((int64_t)Wo * Ho));
+        f32x4 v;
+        if (mode == 0) {
+            const int Wi = 2 * Wo;
+            const T* p = in + (((int64_t)b * 2 * Ho + 2 * h) * Wi + 2 * w) * C + c;
+            v = ((load4(p) + load4(p + C)) + load4(p + (int64_t)Wi * C)) + load4(p + (int64_t)Wi * C + C);
+            v *= s;
+        } else {
+            const int Wi = Wo / 2;
+            v = load4(in + (((int64_t)b * (Ho / 2) + h / 2) * Wi + w / 2) * C + c) * s;
+        }
+        store4(out + e, v);
+    }
+}
+
+// out[m, 0:Ca] = a[m,:], out[m, Ca:Ca+Cb] = b[m,:]   (split = the inverse; ADD accumulates into a/b instead of overwriting)
+template <typename T, bool SPLIT>
+__global__ void concat_kernel(T* __restrict__ a, T* __restrict__ b, T* __restrict__ cat, int64_t M, int Ca, int Cb) {
+    const int C = Ca + Cb;
+    const int64_t total4 = M * C / 4;
+    GRID_STRIDE(i, total4) {
+        const int64_t e = 4 * i;
+        const int c = (int)(e % C);
+        const int64_t m = e / C;
+        T* side = c < Ca ? a + m * Ca + c : b + m * Cb + (c - Ca);
+        if (SPLIT) store4(side, load4(cat + e));
+        else store4(cat + e, load4(side));
+    }
+}
+
+template <typename T>
+__global__ void add_kernel(T* __restrict__ dst, const T* __restrict__ src, int64_t n) {
+    GRID_STRIDE(i, n / 4) store4(dst + 4 * i, load4(dst + 4 * i) + load4(src + 4 * i));
+}
+
+// NCHW f32 <-> NHWC act dtype
+template <typename T, bool TO_NHWC>
+__global__ void layout_kernel(const float* __restrict__ nchw_in, float* __restrict__ nchw_out, const T* __restrict__ nhwc_in,
+                              T* __restrict__ nhwc_out, int B, int C, int HW) {
+    const int64_t total = (int64_t)B * C * HW;
+    GRID_STRIDE(i, total) {
+        const int p = (int)(i % HW);
+        const int c = (int)((i / HW) % C);
+        const int b = (int)(i / ((int64_t)HW * C));
+        const int64_t j = ((int64_t)b * HW + p) * C + c;
+        if (TO_NHWC) nhwc_out[j] = from_f32<T>(nchw_in[i]);
+        else nchw_out[i] = to_f32(nhwc_in[j]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+#define BY_DTYPE(dt, CALL)                      \
+    if (dt == VAW_F32) { using T = float; CALL; } \
+    else { using T = bf16_t; CALL; }
+
+extern "C" int64_t vaw_groupnorm_workspace_floats(int B, int C) { return 6 * (int64_t)B * C + 64; }
+
+extern "C" int vaw_groupnorm_fwd(vaw_dtype dt, const void* x, const float* gamma, const float* beta, const float* scale,
+                                 const float* shift, int64_t film_ld, int silu, void* y, float* mean, float* rstd, int B,
+                                 int HW, int C, int G, float eps, float* workspace, vaw_stream stream) {
+    VAW_CHECK_ARG(B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0 && C % 4 == 0 && workspace, "groupnorm_fwd: bad sizes (C=%d G=%d)", C, G);
+    VAW_CHECK_ARG((scale == nullptr) == (shift == nullptr), "groupnorm_fwd: scale and shift go together");
+    hipStream_t s = (hipStream_t)stream;
+    float* sum = workspace;
+    float* sq = workspace + (int64_t)B * C;
+    dim3 g1(ceil_div(C, 64), B);
+    BY_DTYPE(dt, (gn_chan_stats_kernel<T><<<g1, 256, 0, s>>>((const T*)x, HW, C, sum, sq)));
+    gn_group_stats_kernel<<<ceil_div(B * G, 128), 128, 0, s>>>(sum, sq, B, C, G, HW, eps, mean, rstd);
+    const int64_t n4 = (int64_t)B * HW * C / 4;
+    BY_DTYPE(dt, (gn_apply_kernel<T><<<sgrid(n4, 256), 256, 0, s>>>((const T*)x, mean, rstd, gamma, beta, scale, shift, film_ld, silu, (T*)y, B, HW, C, G)));
+    VAW_CHECK_LAUNCH("groupnorm_fwd");
+    return VAW_OK;
+}
+
+extern "C" int vaw_groupnorm_bwd(vaw_dtype dt, const void* dout, const void* x, const float* mean, const float* rstd,
+                                 const float* gamma, const float* beta, const float* scale, const float* shift,
+                                 int64_t film_ld, int silu, const void* dx_add, void* dx, float* dgamma, float* dbeta,
+                                 float grad_beta, float* dscale, float* dshift, int64_t dfilm_ld, int B, int HW, int C, int G,
+                                 float* workspace, vaw_stream stream) {
+    VAW_CHECK_ARG(B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0 && C % 4 == 0 && workspace, "groupnorm_bwd: bad sizes");
+    VAW_CHECK_ARG(!scale || (shift && dscale && dshift), "groupnorm_bwd: FiLM needs shift, dscale, dshift");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t BC = (int64_t)B * C;
+    float *A = workspace, *Bs = A + BC, *DS = Bs + BC, *DH = DS + BC, *S1 = DH + BC, *S2 = S1 + (int64_t)B * G;
+    dim3 g1(ceil_div(C, 64), B);
+    BY_DTYPE(dt, (gn_bwd_chan_kernel<T><<<g1, 256, 0, s>>>((const T*)dout, (const T*)x, mean, rstd, gamma, beta, scale, shift, film_ld, silu, HW, C, G, A, Bs, DS, DH)));
+    const int n2 = B * G > C ? B * G : C;
+    gn_bwd_group_kernel<<<ceil_div(n2, 128), 128, 0, s>>>(A, Bs, gamma, B, C, G, S1, S2, dgamma, dbeta, grad_beta);
+    if (scale) {   // dscale[b,c] = DS, dshift[b,c] = DH into rows of stride dfilm_ld
+        if (hipMemcpy2DAsync(dscale, dfilm_ld * sizeof(float), DS, C * sizeof(float), C * sizeof(float), B, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+            hipMemcpy2DAsync(dshift, dfilm_ld * sizeof(float), DH, C * sizeof(float), C * sizeof(float), B, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+            vaw_set_error("groupnorm_bwd: copy failed");
+            return VAW_ERR_LAUNCH;
+        }
+    }
+    const int64_t n4 = (int64_t)B * HW * C / 4;
+    BY_DTYPE(dt, (gn_bwd_apply_kernel<T><<<sgrid(n4, 256), 256, 0, s>>>((const T*)dout, (const T*)x, mean, rstd, gamma, beta, scale, shift, film_ld, silu, S1, S2, (const T*)dx_add, (T*)dx, B, HW, C, G)));
+    VAW_CHECK_LAUNCH("groupnorm_bwd");
+    return VAW_OK;
+}
+
+extern "C" int vaw_im2col3x3(vaw_dtype dt, const void* x, void* col, int B, int H, int W, int C, vaw_stream stream) {
+    VAW_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0, "im2col3x3: bad sizes");
+    hipStream_t s = (hipStream_t)stream;
+    if (C % 4 == 0) {
+        const int64_t n = (int64_t)B * H * W * 9 * (C / 4);
+        BY_DTYPE(dt, (im2col3x3_kernel<T, 4><<<sgrid(n, 256), 256, 0, s>>>((const T*)x, (T*)col, B, H, W, C)));
+    } else {
+        const int64_t n = (int64_t)B * H * W * 9 * C;
+        BY_DTYPE(dt, (im2col3x3_kernel<T, 1><<<sgrid(n, 256), 256, 0, s>>>((const T*)x, (T*)col, B, H, W, C)));
+    }
+    VAW_CHECK_LAUNCH("im2col3x3");
+    return VAW_OK;
+}
+
+extern "C" int vaw_col2im3x3(vaw_dtype dt, const void* dcol, void* dx, int B, int H, int W, int C, vaw_stream stream) {
+    VAW_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0, "col2im3x3: bad sizes");
+    hipStream_t s = (hipStream_t)stream;
+    if (C % 4 == 0) {
+        const int64_t n = (int64_t)B * H * W * (C / 4);
+        BY_DTYPE(dt, (col2im3x3_kernel<T, 4><<<sgrid(n, 256), 256, 0, s>>>((const T*)dcol, (T*)dx, B, H, W, C)));
+    } else {
+        const int64_t n = (int64_t)B * H * W * C;
+        BY_DTYPE(dt, (col2im3x3_kernel<T, 1><<<sgrid(n, 256), 256, 0, s>>>((const T*)dcol, (T*)dx, B, H, W, C)));
+    }
+    VAW_CHECK_LAUNCH("col2im3x3");
+    return VAW_OK;
+}
+
+extern "C" int vaw_resample2(vaw_dtype dt, const void* in, void* out, int B, int Ho, int Wo, int C, int mode, float s_,
+                             vaw_stream stream) {
+    VAW_CHECK_ARG(B > 0 && Ho > 0 && Wo > 0 && C % 4 == 0 && (mode == 0 || (mode == 1 && Ho % 2 == 0 && Wo % 2 == 0)), "resample2: bad sizes");
+    const int64_t n4 = (int64_t)B * Ho * Wo * C / 4;
+    BY_DTYPE(dt, (resample2_kernel<T><<<sgrid(n4, 256), 256, 0, (hipStream_t)stream>>>((const T*)in, (T*)out, B, Ho, Wo, C, mode, s_)));
+    VAW_CHECK_LAUNCH("resample2");
+    return VAW_OK;
+}
+
+extern "C" int vaw_concat_channels(vaw_dtype dt, void* a, void* b, void* cat, int64_t M, int Ca, int Cb, int split,
+                                   vaw_stream stream) {
+    VAW_CHECK_ARG(M > 0 && Ca > 0 && Cb > 0 && Ca % 4 == 0 && Cb % 4 == 0, "concat_channels: channel counts must be multiples of 4");
+    const int64_t n4 = M * (Ca + Cb) / 4;
+    hipStream_t s = (hipStream_t)stream;
+    if (split) { BY_DTYPE(dt, (concat_kernel<T, true><<<sgrid(n4, 256), 256, 0, s>>>((T*)a, (T*)b, (T*)cat, M, Ca, Cb))); }
+    else { BY_DTYPE(dt, (concat_kernel<T, false><<<sgrid(n4, 256), 256, 0, s>>>((T*)a, (T*)b, (T*)cat, M, Ca, Cb))); }
+    VAW_CHECK_LAUNCH("concat_channels");
+    return VAW_OK;
+}
+
+extern "C" int vaw_add_inplace(vaw_dtype dt, void* dst, const void* src, int64_t n, vaw_stream stream) {
+    VAW_CHECK_ARG(n > 0 && n % 4 == 0, "add_inplace: n must be a positive multiple of 4");
+    BY_DTYPE(dt, (add_kernel<T><<<sgrid(n / 4, 256), 256, 0, (hipStream_t)stream>>>((T*)dst, (const T*)src, n)));
+    VAW_CHECK_LAUNCH("add_inplace");
+    return VAW_OK;
+}
+
+extern "C" int vaw_nchw_to_nhwc(vaw_dtype dt, const float* nchw, void* nhwc, int B, int C, int HW, vaw_stream stream) {
+    VAW_CHECK_ARG(B > 0 && C > 0 && HW > 0, "nchw_to_nhwc: bad sizes");
+    const int64_t n = (int64_t)B * C * HW;
+    BY_DTYPE(dt, (layout_kernel<T, true><<<sgrid(n, 256), 256, 0, (hipStream_t)stream>>>(nchw, nullptr, nullptr, (T*)nhwc, B, C, HW)));
+    VAW_CHECK_LAUNCH("nchw_to_nhwc");
+    return VAW_OK;
+}
+extern "C" int vaw_nhwc_to_nchw(vaw_dtype dt, const void* nhwc, float* nchw, int B, int C, int HW, vaw_stream stream) {
+    VAW_CHECK_ARG(B > 0 && C > 0 && HW > 0, "nhwc_to_nchw: bad sizes");
+    const int64_t n = (int64_t)B * C * HW;
+    BY_DTYPE(dt, (layout_kernel<T, false><<<sgrid(n, 256), 256, 0, (hipStream_t)stream>>>(nullptr, nchw, (const T*)nhwc, nullptr, B, C, HW)));
+    VAW_CHECK_LAUNCH("nhwc_to_nchw");
+    return VAW_OK;
+}

@@ -25,6 +25,18 @@ class FlatModule(nn.Module):
     def _flat_groups(self):
         return []
 
+    def _flat_channels_last(self, name, p):
+        """True -> a 4-D parameter [Co,Ci,kh,kw] is STORED [Co][kh][kw][Ci] (torch channels_last) and exposed as a
+        permuted view with the reference's shape."""
+        return False
+
+    @staticmethod
+    def _view_as_param(buf, p, channels_last):
+        if channels_last:
+            co, ci, kh, kw = p.shape
+            return buf.view(co, kh, kw, ci).permute(0, 3, 1, 2)
+        return buf.view(p.shape)
+
     def _ordered_named_params(self):
         """-> (trainable, frozen) lists of (name, param, packed) where packed=True means "no alignment gap
         before this entry" (members of one group form a single contiguous matrix)."""
@@ -55,13 +67,16 @@ class FlatModule(nn.Module):
             off += p.numel()
         off = _round_up(off)
         flat = torch.zeros(off, device=dev, dtype=torch.float32)
+        self._flat_cl = {}
         with torch.no_grad():
             for n, p, _ in train + frozen:
                 o, k = offs[n]
                 if p.dtype != torch.float32:
                     raise TypeError(f"{n}: master parameters must be float32, got {p.dtype}")
-                flat[o:o + k].copy_(p.data.reshape(-1))
-                p.data = flat[o:o + k].view(p.shape)
+                cl = self._flat_cl[n] = bool(p.dim() == 4 and self._flat_channels_last(n, p))
+                v = self._view_as_param(flat[o:o + k], p, cl)
+                v.copy_(p.data)
+                p.data = v
         self._flat = flat
         self._flat_offsets = offs
         self._flat_n_train = n_train
@@ -125,7 +140,7 @@ class FlatModule(nn.Module):
         for n, p in zip(self._flat_names, self._flat_params):
             if p.grad is None or p.grad.data_ptr() != g.data_ptr() + 4 * self._flat_offsets[n][0]:
                 o, k = self._flat_offsets[n]
-                p.grad = g[o:o + k].view(p.shape)
+                p.grad = self._view_as_param(g[o:o + k], p, self._flat_cl[n])
 
     def grads_live(self):
         """True when gradients already hold a value that the next backward must add to

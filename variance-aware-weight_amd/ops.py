@@ -77,10 +77,11 @@ def weighted_mse(model_out, x0, noise, ca, cb, w):
 # ---- dense -------------------------------------------------------------------------------------
 def gemm(dt, a_kmajor, b_kmajor, M, N, K, A, lda, B, ldb, Cp, ldc, *, bias=None, act=0, aux_in=None, aux_out=None,
          gate=None, gate_ld=0, resid=None, rowadd=None, rows_per_batch=0, alpha=1.0, beta=0.0, out_f32=False,
-         colsum_out=None, colsum_beta=0.0):
+         colsum_out=None, colsum_beta=0.0, resid_is_act=False):
     """Raw-pointer GEMM; A, B, Cp, bias... are integers (device addresses).  See vaw_gemm in the header."""
     e = Epilogue(bias or None, act, aux_in or None, aux_out or None, gate or None, gate_ld, resid or None,
-                 rowadd or None, rows_per_batch, alpha, beta, 1 if out_f32 else 0, colsum_out or None, colsum_beta)
+                 rowadd or None, rows_per_batch, alpha, beta, 1 if out_f32 else 0, colsum_out or None, colsum_beta,
+                 1 if resid_is_act else 0)
     tr = gemm_trace
     if tr is not None:
         e0, e1 = tr.events()
