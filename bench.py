@@ -30,10 +30,16 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 WORKLOADS = {
-    # name: (factory kwargs, per-GPU batch, train GFLOP/img from BASELINE.md §3)
-    "dit_b4": dict(model="DiT-B", patch=4, batch=256, gflop_per_img=33.37, desc="DiT-B/4, 4x32x32 latents, 1000 classes"),
-    "dit_b2": dict(model="DiT-B", patch=2, batch=256, gflop_per_img=138.0, desc="DiT-B/2, 4x32x32 latents, 1000 classes"),
-    "dit_s4": dict(model="DiT-S", patch=4, batch=256, gflop_per_img=None, desc="DiT-S/4 (smoke)"),
+    # per-GPU batch and train GFLOP/img from BASELINE.md §3 (BASELINE.json configs 4, 1, 2, 3)
+    "dit_b4": dict(kind="dit", model="DiT-B", patch=4, batch=256, gflop_per_img=33.37, desc="DiT-B/4, 4x32x32 latents, 1000 classes"),
+    "dit_b2": dict(kind="dit", model="DiT-B", patch=2, batch=256, gflop_per_img=138.0, desc="DiT-B/2, 4x32x32 latents, 1000 classes"),
+    "dit_s4": dict(kind="dit", model="DiT-S", patch=4, batch=256, gflop_per_img=None, desc="DiT-S/4 (smoke)"),
+    "unet32": dict(kind="unet", size=32, classes=0, batch=16, gflop_per_img=9.91,
+                   desc="CIFAR-10-shaped UNet (32x32, base 64 ch, mult 1,2,2,2, 10.4 M params), BASELINE config 1"),
+    "unet64": dict(kind="unet", size=64, classes=0, batch=128, gflop_per_img=464.7,
+                   desc="UNet_64 (CelebA-64, 192 ch, mult 1,2,2,2, attention at 16/8, 128 M params), BASELINE config 2"),
+    "adm64": dict(kind="unet", size=64, classes=1000, batch=256, gflop_per_img=657.9,
+                  desc="ADM_64 (ImageNet-64, 192 ch, mult 1,2,3,4, attention at 32/16/8, 296 M params), BASELINE config 3"),
 }
 BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md
 
@@ -48,12 +54,22 @@ def make_args(**kw):
     return SimpleNamespace(**a)
 
 
-def synth_batches(B, n, device, seed):
-    """latents = cat[mean ~ 4*N(0,1), std ~ U(0.05,1.5)] [B,8,32,32], labels in [0,1000)."""
+def workload_args(wl, **kw):
+    if wl["kind"] == "unet":
+        return make_args(in_chans=3, dataset="CelebA", image_size=wl["size"], class_cond=bool(wl["classes"]), **kw)
+    return make_args(**kw)
+
+
+def synth_batches(B, n, device, seed, wl=None):
+    """SURVEY §8(d): latents = cat[mean ~ 4*N(0,1), std ~ U(0.05,1.5)] [B,8,32,32], labels in [0,1000);
+    pixel models: x = rand*2-1 in [B,3,H,W]."""
     g = torch.Generator().manual_seed(seed)
     out = []
     for _ in range(n):
-        x = torch.cat([torch.randn(B, 4, 32, 32, generator=g) * 4, torch.rand(B, 4, 32, 32, generator=g) * 1.45 + 0.05], 1)
+        if wl is not None and wl["kind"] == "unet":
+            x = torch.rand(B, 3, wl["size"], wl["size"], generator=g) * 2 - 1
+        else:
+            x = torch.cat([torch.randn(B, 4, 32, 32, generator=g) * 4, torch.rand(B, 4, 32, 32, generator=g) * 1.45 + 0.05], 1)
         y = torch.randint(0, 1000, (B,), generator=g)
         out.append((x.to(device), y.to(device)))
     return out
@@ -68,10 +84,22 @@ class _Loader(list):
     sampler = _Sampler()
 
 
+def make_model(pkg, wl):
+    """pkg is vaw_amd (HIP) or a namespace with the oracle's constructors (CPU baseline)."""
+    if wl["kind"] == "dit":
+        return pkg.DiT_models[wl["model"]](image_size=32, patch_size=wl["patch"], in_channels=4, class_dropout_prob=0.0,
+                                           num_classes=1000, learn_sigma=False)
+    if wl["size"] == 32:
+        return pkg.UNetModel(32, 3, 64, 3, 2, attention_resolutions=(), channel_mult=(1, 2, 2, 2), num_heads=4,
+                             use_scale_shift_norm=True, resblock_updown=True, use_new_attention_order=True)
+    if wl["classes"]:
+        return pkg.ADM_64(num_classes=1000, class_cond=True)
+    return pkg.UNet_64(class_cond=False)
+
+
 def build(pkg, wl, args, device, rank):
     torch.manual_seed(42)          # same seed on every rank => identical replicas, like DDP's broadcast
-    model = pkg.DiT_models[wl["model"]](image_size=32, patch_size=wl["patch"], in_channels=4, class_dropout_prob=0.0,
-                                        num_classes=1000, learn_sigma=False).to(device)
+    model = make_model(pkg, wl).to(device)
     # random-init weights of the architecture; adaLN-Zero would make every block an identity, so perturb
     g = torch.Generator().manual_seed(7)
     with torch.no_grad():
@@ -84,21 +112,21 @@ def build(pkg, wl, args, device, rank):
 
 def cpu_baseline(wl, budget_s=25.0):
     """The CPU oracle (torch restatement of the reference path, pinned by tests/golden) on this host."""
-    from oracle import diffusion as od, dit as odit, trainer as otr
+    from oracle import diffusion as od, dit as odit, trainer as otr, unet as ounet
     torch.manual_seed(42)
     # a one-GPU box gives this job a 16-core CPU share; more threads than that only thrash
     torch.set_num_threads(int(os.environ.get("VAW_CPU_THREADS", "16")))
-    B = 32
-    args = make_args(amp=False, defer_loss_sync=False)
-    model = odit.DiT_models[wl["model"]](image_size=32, patch_size=wl["patch"], in_channels=4, class_dropout_prob=0.0,
-                                         num_classes=1000, learn_sigma=False)
+    B = {"dit": 32, "unet": 16 if wl.get("size") == 32 else 4}[wl["kind"]]
+    args = workload_args(wl, amp=False, defer_loss_sync=False)
+    opkg = SimpleNamespace(DiT_models=odit.DiT_models, UNetModel=ounet.UNetModel, ADM_64=ounet.ADM_64, UNet_64=ounet.UNet_64)
+    model = make_model(opkg, wl)
     ema_model = copy.deepcopy(model)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.95), weight_decay=0.0)
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=otr.get_lr_lambda(args))
     diff = od.GaussianDiffusion(args=args, betas=od.get_named_beta_schedule("cosine", 1000),
                                 model_mean_type=od.ModelMeanType.EPSILON, model_var_type=od.ModelVarType.FIXED_LARGE,
                                 loss_type=od.LossType.MSE, rescale_timesteps=True)
-    tr = otr.Trainer(args, torch.device("cpu"), model, ema_model, opt, sched, diff, synth_batches(B, 2, "cpu", 123))
+    tr = otr.Trainer(args, torch.device("cpu"), model, ema_model, opt, sched, diff, synth_batches(B, 2, "cpu", 123, wl))
     tr.train_step(0)               # warm-up (allocator, oneDNN primitive cache)
     t0, n = time.perf_counter(), 0
     while n < 2 or (time.perf_counter() - t0 < budget_s and n < 20):
@@ -136,7 +164,7 @@ def main():
     if parallel:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         vaw_amd.dist_util.setup_dist()
-    args = make_args(parallel=parallel, amp=not a.fp32)
+    args = workload_args(wl, parallel=parallel, amp=not a.fp32)
     model, ema_model = build(vaw_amd, wl, args, device, rank)
     if a.fp32:
         model.set_compute_dtype("fp32")
@@ -148,7 +176,7 @@ def main():
                                      model_var_type=vaw_amd.ModelVarType.FIXED_LARGE, loss_type=vaw_amd.LossType.MSE,
                                      rescale_timesteps=True)
     torch.manual_seed(1000 + rank)          # seed + rank: every rank draws its own t / noise (reference utils.py:62-69)
-    loader = _Loader(synth_batches(B, 4, device, 123 + rank))
+    loader = _Loader(synth_batches(B, 4, device, 123 + rank, wl))
     tr = vaw_amd.Trainer(args, device, net, ema_model if rank == 0 else None, opt, sched, diff, loader)
 
     def barrier():

@@ -119,14 +119,24 @@ def test_gemm_layouts_exact_integers(a_k, b_k, mode):
     """Small-integer operands are exact in bf16 and f32: any fragment-layout or swizzle error shows as a
     wrong integer, with asymmetric data on both sides (a symmetric operand would hide a transpose)."""
     dtype = torch.float32 if mode == "f32" else torch.bfloat16
-    shapes = [(256, 384, 192)] if mode == "bf16_fast" else [(256, 384, 192), (70, 45, 23), (129, 1, 17), (5, 200, 64)]
+    # the MFMA path predicates edge tiles: any M (multiple of 8 when A is mn-major), N % 8 == 0, K % 64 == 0
+    shapes = ([(256, 384, 192), (200, 72, 128), (136, 200, 64), (192, 1728, 256), (64, 64, 64)] if mode == "bf16_fast"
+              else [(256, 384, 192), (70, 45, 23), (129, 1, 17), (5, 200, 64)])
     lib().vaw_debug_force_generic_gemm(1 if mode == "bf16_generic" else 0)
     try:
         for (M, N, K) in shapes:
             A, B = _mk(M, N, K, a_k, b_k, dtype, seed=M + N + K, ints=True)
-            got = ops.gemm_t(A.to(DEV), B.to(DEV), a_kmajor=a_k, b_kmajor=b_k, out_dtype=torch.float32).cpu()
+            Ad, Bd = A.to(DEV), B.to(DEV)
+            if mode == "bf16_fast":
+                assert lib().vaw_gemm_uses_bf16_mfma(BF16, M, N, K, ptr(Ad), Ad.shape[1], ptr(Bd), Bd.shape[1]) == 1
+            got = ops.gemm_t(Ad, Bd, a_kmajor=a_k, b_kmajor=b_k, out_dtype=torch.float32).cpu()
             ref = _gemm_ref(A, B, a_k, b_k)
             assert torch.equal(got.double(), ref), (mode, a_k, b_k, M, N, K, (got.double() - ref).abs().max())
+            # bf16 output + fused column sums on edge tiles
+            cs = torch.zeros(N, device=DEV)
+            got2 = ops.gemm_t(Ad, Bd, a_kmajor=a_k, b_kmajor=b_k, colsum_out=cs).cpu()
+            assert torch.equal(got2.double(), ref.to(dtype).double())
+            torch.testing.assert_close(cs.cpu().double(), ref.to(dtype).double().sum(0), rtol=1e-6, atol=1e-3)
     finally:
         lib().vaw_debug_force_generic_gemm(0)
 

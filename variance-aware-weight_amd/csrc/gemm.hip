@@ -169,7 +169,11 @@ __device__ __forceinline__ int mnmaj_off(int row, int chunk) {
 // Stage one 128 x BKT (k-major) or BKT x 128 (mn-major) operand tile into LDS by LDS-DMA: BKT/4 wave-instructions
 // of 1 KiB, BKT/16 per wave.  g points at the tile's first element; ld = leading dimension in elements.
 template <bool KMAJOR, int BKT>
-__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int64_t ld, char* lds_tile, int wid, int lane) {
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int64_t ld, char* lds_tile, int wid, int lane,
+                                           int valid) {
+    // `valid` = rows (k-major) or columns (mn-major, multiple of 8) of this 128-wide tile that exist in the matrix.
+    // Out-of-range lanes re-read an in-range chunk instead (LDS-DMA cannot zero-fill): the duplicate data only
+    // reaches accumulator rows/columns that the epilogue never stores.
     constexpr int PER_WAVE = BKT / 16;
     constexpr int CPR = BKT / 8;             // 16-byte chunks per k-major row
 #pragma unroll
@@ -177,12 +181,14 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int64_t
         const int inst = wid * PER_WAVE + i;
         const bf16_t* src;
         if (KMAJOR) {
-            const int row = inst * (64 / CPR) + lane / CPR;
+            int row = inst * (64 / CPR) + lane / CPR;
             const int chunk = (lane % CPR) ^ kmaj_swz<BKT>(row);
+            row = row < valid ? row : valid - 1;
             src = g + (int64_t)row * ld + chunk * 8;
         } else {
             const int row = inst * 4 + (lane >> 4);
-            const int chunk = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
+            int chunk = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
+            chunk = chunk * 8 < valid ? chunk : 0;
             src = g + (int64_t)row * ld + chunk * 8;
         }
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(lds_tile + inst * 1024), 16, 0, 0);
@@ -227,7 +233,7 @@ gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __rest
     // an XCD then touch ~8 A panels + ~8 B panels (3 MB at K=768), which stay in its 4 MiB L2.
     int tm, tn;
     {
-        const int tiles_m = n_wg / tiles_n, per_group = 8 * tiles_n;
+        const int tiles_m = n_wg / tiles_n, per_group = 8 * tiles_n;   // n_wg = tiles_m * tiles_n exactly
         const int group = wg / per_group, first_m = group * 8;
         const int gsize = tiles_m - first_m < 8 ? tiles_m - first_m : 8;
         const int in_group = wg - group * per_group;
@@ -244,6 +250,8 @@ gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __rest
     const bf16_t* Ag = (AK ? A + m0 * lda : A + m0) + kt0 * a_step;
     const bf16_t* Bg = (BKM ? B + n0 * ldb : B + n0) + kt0 * b_step;
     const int wm = (wid >> 1) * 64, wn = (wid & 1) * 64;
+    const int mvalid = e.M - m0 < BM ? (int)(e.M - m0) : BM;     // edge tiles: rows / columns that exist
+    const int nvalid = e.N - n0 < BN ? (int)(e.N - n0) : BN;
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -251,16 +259,16 @@ gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __rest
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
 
-    stage_tile<AK, BKT>(Ag, lda, smem, wid, lane);
-    stage_tile<BKM, BKT>(Bg, ldb, smem + Cfg::tile_bytes, wid, lane);
+    stage_tile<AK, BKT>(Ag, lda, smem, wid, lane, mvalid);
+    stage_tile<BKM, BKT>(Bg, ldb, smem + Cfg::tile_bytes, wid, lane, nvalid);
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA for tile kt has landed
         __syncthreads();                                    // everyone's has; and tile kt-1 is no longer read
         char* cur = smem + (kt & 1) * Cfg::stage_bytes;
         if (kt + 1 < nk) {
             char* nxt = smem + ((kt + 1) & 1) * Cfg::stage_bytes;
-            stage_tile<AK, BKT>(Ag + (kt + 1) * a_step, lda, nxt, wid, lane);
-            stage_tile<BKM, BKT>(Bg + (kt + 1) * b_step, ldb, nxt + Cfg::tile_bytes, wid, lane);
+            stage_tile<AK, BKT>(Ag + (kt + 1) * a_step, lda, nxt, wid, lane, mvalid);
+            stage_tile<BKM, BKT>(Bg + (kt + 1) * b_step, ldb, nxt + Cfg::tile_bytes, wid, lane, nvalid);
         }
 #pragma unroll
         for (int s = 0; s < BKT / 32; ++s) {
@@ -289,8 +297,9 @@ gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __rest
     //      then each thread owns 8 consecutive columns of one row per pass: 16-byte loads and stores ----
     float* cs = reinterpret_cast<float*>(smem);
     const int c8 = (threadIdx.x & 15) * 8, r0 = threadIdx.x >> 4;
+    const bool col_ok = c8 < nvalid;             // N % 8 == 0: an 8-column group is in or out as a whole
     f32x4 b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
-    if (e.bias && n_split == 1) {
+    if (e.bias && n_split == 1 && col_ok) {
         b0 = load4(e.bias + n0 + c8);
         b1 = load4(e.bias + n0 + c8 + 4);
     }
@@ -313,6 +322,7 @@ gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __rest
 #pragma unroll
             for (int pass = 0; pass < 4; ++pass) {
                 const int row = pass * 16 + r0;
+                if (!col_ok || 64 * half + row >= mvalid) continue;
                 const float* src = cs + row * CS_LD + c8;
                 float* dst = slab + (m0 + 64 * half + row) * e.N + n0 + c8;
                 store4(dst, load4(src));
@@ -322,6 +332,7 @@ gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __rest
 #pragma unroll
             for (int pass = 0; pass < 4; ++pass) {
                 const int row = pass * 16 + r0;
+                if (!col_ok || 64 * half + row >= mvalid) continue;
                 const float* src = cs + row * CS_LD + c8;
                 f32x4 v0 = load4(src), v1 = load4(src + 4);
                 epi_row8(e, (unsigned)(m0 + 64 * half + row), n0 + c8, v0, v1, b0, b1);
@@ -343,7 +354,7 @@ gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __rest
             store4(cp + wid * 128 + c8 + 4, s1);
         }
         __syncthreads();
-        if (threadIdx.x < 128)
+        if (threadIdx.x < nvalid)
             e.colpart[(int64_t)tm * e.N + n0 + threadIdx.x] =
                 ((cp[threadIdx.x] + cp[128 + threadIdx.x]) + cp[256 + threadIdx.x]) + cp[384 + threadIdx.x];
     }
@@ -456,9 +467,11 @@ extern "C" void vaw_debug_force_generic_gemm(int on) { g_force_generic = on; }
 
 static bool takes_fast_path(vaw_dtype dt, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
                             int64_t ldb) {
-    return dt == VAW_BF16 && !g_force_generic && M % BM == 0 && N % BN == 0 && K % BK == 0 && lda % 8 == 0 &&
-           ldb % 8 == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0;
+    // any M and N (edge tiles are predicated), as long as rows are whole 16-byte chunks
+    return dt == VAW_BF16 && !g_force_generic && N % 8 == 0 && K % BK == 0 && lda % 8 == 0 && ldb % 8 == 0 &&
+           (((uintptr_t)A | (uintptr_t)B) & 15) == 0 && M >= 16 && N >= 16;
 }
+static bool fast_layout_ok(int a_kmajor, int64_t M) { return a_kmajor || M % 8 == 0; }
 extern "C" int vaw_gemm_uses_bf16_mfma(vaw_dtype dt, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
                                        const void* B, int64_t ldb) {
     return takes_fast_path(dt, M, N, K, A, lda, B, ldb) ? 1 : 0;
@@ -513,9 +526,9 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
     VAW_CHECK_ARG(!colsum_out || (workspace && workspace_floats >= vaw_colsum_workspace_floats(M, N) &&
                                   workspace_floats >= ((M + 127) / 128) * N),
                   "gemm: colsum_out needs a workspace of max(ceil(M/128), ceil(M/512))*N floats");
-    if (takes_fast_path(dt, M, N, K, A, lda, B, ldb) && epi_aligned) {
-        const int tiles_n = (int)(N / BN);
-        const int64_t n_wg = (M / BM) * tiles_n;
+    if (takes_fast_path(dt, M, N, K, A, lda, B, ldb) && epi_aligned && fast_layout_ok(a_kmajor, M)) {
+        const int tiles_n = (int)((N + BN - 1) / BN);
+        const int64_t n_wg = ((M + BM - 1) / BM) * tiles_n;
         VAW_CHECK_ARG(n_wg < (1LL << 31), "gemm: grid too large");
         // stage depth: 64 for long K (weight gradients), 32 for the K <= 1024 forward / input-gradient launches
         static int bk_env = -1;
@@ -557,7 +570,7 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
             splitk_reduce_kernel<float><<<ceil_div(M * N / 4, 256) > 2048 ? 2048 : ceil_div(M * N / 4, 256), 256, 0, s>>>(
                 workspace, split, M, N, ldc, C, e.alpha, e.beta, 1);
         VAW_CHECK_LAUNCH("gemm_bf16");
-        if (colsum_out) return vaw_reduce_rows(workspace, M / BM, N, colsum_out, colsum_beta, stream);
+        if (colsum_out) return vaw_reduce_rows(workspace, (M + BM - 1) / BM, N, colsum_out, colsum_beta, stream);
         return VAW_OK;
     }
     const int64_t tiles = (int64_t)ceil_div(N, GBN) * ceil_div(M, GBM);
