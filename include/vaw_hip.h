@@ -195,6 +195,12 @@ int vaw_groupnorm_bwd(vaw_dtype dt, const void* dout, const void* x, const float
  * vaw_col2im3x3 is the transposed map written as a gather (deterministic): the input gradient from d(col). */
 int vaw_im2col3x3(vaw_dtype dt, const void* x, void* col, int B, int H, int W, int C, vaw_stream stream);
 int vaw_col2im3x3(vaw_dtype dt, const void* dcol, void* dx, int B, int H, int W, int C, vaw_stream stream);
+/* conv3x3 weight gradient for the 3-channel stem / output convs (Ci <= 4 or Co <= 4), where a GEMM would be 3 wide:
+ * dw[co][tap][ci] (f32, channels-last weight layout) = beta*dw + sum_m dy[m,co] * x[pixel(m)+tap, ci]; chunk
+ * partials in the workspace are folded in a fixed order. */
+int64_t vaw_conv3x3_wgrad_small_workspace_floats(int B, int H, int W, int Ci, int Co);
+int vaw_conv3x3_wgrad_small(vaw_dtype dt, const void* dy, const void* x, float* dw, float beta, int B, int H, int W, int Ci,
+                            int Co, float* workspace, int64_t workspace_floats, vaw_stream stream);
 /* mode 0: out[Ho,Wo] = s * sum of the 2x2 block of in[2Ho,2Wo] (avg_pool2d with s=1/4; nearest-upsample^T with s=1)
  * mode 1: out[Ho,Wo] = s * in[Ho/2,Wo/2]                        (nearest x2 with s=1; avg_pool2d^T with s=1/4) */
 int vaw_resample2(vaw_dtype dt, const void* in, void* out, int B, int Ho, int Wo, int C, int mode, float s,

@@ -292,7 +292,8 @@ def _attn_ref(q, k, v, scale):
 
 
 @pytest.mark.parametrize("dtype,rowwise", [(torch.float32, True), (torch.bfloat16, True), (torch.bfloat16, False)])
-@pytest.mark.parametrize("B,H,T,hd", [(2, 3, 64, 64), (1, 2, 16, 32), (2, 2, 100, 72), (1, 1, 256, 64), (3, 2, 128, 64)])
+@pytest.mark.parametrize("B,H,T,hd", [(2, 3, 64, 64), (1, 2, 16, 32), (2, 2, 100, 72), (1, 1, 256, 64), (3, 2, 128, 64),
+                                      (2, 4, 256, 96), (1, 2, 1024, 64), (2, 2, 64, 32), (1, 2, 192, 128)])
 def test_attention_token_major(dtype, rowwise, B, H, T, hd):
     """rowwise=False lets bf16 / hd 64 / T%64==0 shapes take the MFMA kernels; the others always run rowwise."""
     tol = dict(rtol=1e-4, atol=2e-5) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2)

@@ -53,6 +53,7 @@ _PROTOS = {
     "vaw_groupnorm_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _l, _i, _p, _p, _p, _p, _f, _p, _p, _l, _i, _i, _i, _i, _p, _p],
     "vaw_im2col3x3": [_i, _p, _p, _i, _i, _i, _i, _p],
     "vaw_col2im3x3": [_i, _p, _p, _i, _i, _i, _i, _p],
+    "vaw_conv3x3_wgrad_small": [_i, _p, _p, _p, _f, _i, _i, _i, _i, _i, _p, _l, _p],
     "vaw_resample2": [_i, _p, _p, _i, _i, _i, _i, _i, _f, _p],
     "vaw_concat_channels": [_i, _p, _p, _p, _l, _i, _i, _i, _p],
     "vaw_add_inplace": [_i, _p, _p, _l, _p],
@@ -87,6 +88,8 @@ def lib():
         L.vaw_last_error_string.restype = C.c_char_p
         L.vaw_colsum_workspace_floats.argtypes = [_l, _l]
         L.vaw_colsum_workspace_floats.restype = _l
+        L.vaw_conv3x3_wgrad_small_workspace_floats.argtypes = [_i, _i, _i, _i, _i]
+        L.vaw_conv3x3_wgrad_small_workspace_floats.restype = _l
         L.vaw_groupnorm_workspace_floats.argtypes = [_i, _i]
         L.vaw_groupnorm_workspace_floats.restype = _l
         L.vaw_sumsq_workspace_floats.argtypes = []
@@ -101,7 +104,8 @@ def lib():
 
 def exported_symbols():
     return sorted(list(_PROTOS) + ["vaw_version", "vaw_last_error_string", "vaw_colsum_workspace_floats",
-                                   "vaw_sumsq_workspace_floats", "vaw_groupnorm_workspace_floats"])
+                                   "vaw_sumsq_workspace_floats", "vaw_groupnorm_workspace_floats",
+                                   "vaw_conv3x3_wgrad_small_workspace_floats"])
 
 
 def check(rc, what):

@@ -180,7 +180,7 @@ attn_bwd_kv_rowwise(AttnDev a, const T* __restrict__ q, const T* __restrict__ k,
 // bf16 MFMA path (attention_mfma.hip)
 bool vaw_attn_mfma_ok(vaw_dtype dt, const vaw_attn_desc* d, const void* q, const void* k, const void* v, const void* o);
 int vaw_attn_fwd_mfma(const vaw_attn_desc* d, const void* q, const void* k, const void* v, void* o, float* lse, hipStream_t s);
-int vaw_attn_bwd_mfma(const vaw_attn_desc* d, const void* q, const void* k, const void* v, const void* d_o,
+int vaw_attn_bwd_mfma(const vaw_attn_desc* d, const void* q, const void* k, const void* v, const void* o, const void* d_o,
                       const float* lse, float* delta, void* dq, void* dk, void* dv, hipStream_t s);
 static int g_force_rowwise = 0;
 extern "C" void vaw_debug_force_rowwise_attention(int on) { g_force_rowwise = on; }
@@ -220,7 +220,7 @@ extern "C" int vaw_attn_bwd(vaw_dtype dt, const vaw_attn_desc* d, const void* q,
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     if (!g_force_rowwise && vaw_attn_mfma_ok(dt, d, q, k, v, d_o) && (((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 7) == 0)
-        return vaw_attn_bwd_mfma(d, q, k, v, d_o, lse, delta, dq, dk, dv, s);
+        return vaw_attn_bwd_mfma(d, q, k, v, o, d_o, lse, delta, dq, dk, dv, s);
     AttnDev a = to_dev(d);
     dim3 grid(ceil_div(a.T, 4), a.B * a.H);
     const size_t lds_q = 4 * (size_t)(2 * a.hd + a.T) * sizeof(float);

@@ -1,4 +1,5 @@
-// bf16 MFMA attention for the token-major DiT layout, head dim 64, T in {64,128,192,256}.
+// bf16 MFMA attention for token-major q/k/v rows (DiT's timm Attention AND the UNet's QKVAttention once its
+// activations are NHWC): head dim HD in {32, 64, 96, 128}, any sequence length T that is a multiple of 64.
 //
 // Everything is computed TRANSPOSED so that no probability tile ever crosses lanes or LDS:
 //   S^T[key][query] = K . Q^T  lands in the 16x16 accumulator layout with the QUERY on the lane (col = l&15) and
@@ -7,13 +8,14 @@
 //   (cdna_hip_programming.md §3 "An accumulator tile as the next MFMA's operand": the k order of such an operand
 //   is permuted -- k slot (g, jj) holds accumulator row 4g+jj of tile 2s (jj<4) or tile 2s+1 (jj>=4) -- so the A
 //   operand V^T is fetched with the same permutation by ds_read_b64_tr_b16).
-// Backward recomputes P from the saved row log-sum-exp in BOTH orientations (S^T for dQ, S for dK/dV): two
-// extra 64x64x64 products per tile buy a kernel with no transposes, no atomics and no T x T tensor in memory.
-// delta_i = sum_j P_ij dP_ij is taken from the tiles themselves (equals rowsum(dO*O)).
+// Keys (forward, dQ) or queries (dK/dV) stream through LDS in blocks of 64 rows; the forward keeps a running
+// (max, sum) per query (online softmax), the backward recomputes P from the saved row log-sum-exp in BOTH
+// orientations (S^T for dQ, S for dK/dV) -- two extra products per tile buy kernels with no transposes, no
+// atomics and no T x T tensor in memory.  delta_i = rowsum(dO * O).
 //
-// LDS: every operand tile is a [rows][64] bf16 image with 128-byte rows, filled by LDS-DMA
-// (global_load_lds_dwordx4, 8 rows per wave-instruction) with the 16-byte chunk XOR-swizzled on the SOURCE
-// side: chunk' = chunk ^ ((row>>1)&7).  Row reads (ds_read_b128) are conflict-free, transposed reads 2-way.
+// LDS: every operand block is a [64 rows][HD] bf16 image filled by LDS-DMA (global_load_lds_dwordx4) with the
+// 16-byte chunk XOR-swizzled on the SOURCE side so that the ds_read_b128 row reads are conflict-free
+// (HD 32/64/128; the 192-byte rows of HD 96 stay linear: 4-way conflicts, still far ahead of the VALU kernel).
 #include "common.h"
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -26,31 +28,42 @@ struct AttnMfmaArgs {
     float scale;
 };
 
-__device__ __forceinline__ int img_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+template <int HD>
+__device__ __forceinline__ int swz(int row) {
+    return HD == 32 ? ((-(row >> 2)) & 3) : HD == 64 ? ((row >> 1) & 7) : HD == 128 ? (row & 15) : 0;
+}
+template <int HD>
+__device__ __forceinline__ int img_off(int row, int chunk) { return row * (2 * HD) + ((chunk ^ swz<HD>(row)) << 4); }
 
-// rows [r_begin, r_begin+nrows) of a token-major operand -> LDS image rows [0, nrows); all 4 waves cooperate
-__device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ g, int64_t stride_t, int nrows, char* img, int wid,
-                                           int lane) {
-    for (int inst = wid; inst < nrows / 8; inst += 4) {
-        const int row = inst * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+// 64 token rows starting at g (row stride stride_t elements) -> LDS image rows [0,64); all 4 waves cooperate
+template <int HD>
+__device__ __forceinline__ void stage_block(const bf16_t* __restrict__ g, int64_t stride_t, char* img, int wid, int lane) {
+    constexpr int CPR = HD / 8;      // 16-byte chunks per row; the image is CPR wave-instructions of 1 KiB
+#pragma unroll
+    for (int i = 0; i < CPR / 4; ++i) {
+        const int inst = wid * (CPR / 4) + i;
+        const int idx = inst * 64 + lane;
+        const int row = idx / CPR;
+        const int chunk = (idx % CPR) ^ swz<HD>(row);
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)(g + (int64_t)row * stride_t + chunk * 8),
                                          (lds_ptr_t)(img + inst * 1024), 16, 0, 0);
     }
 }
 
-// 16 rows x 32 k (k = channel), rows r0.., k-step s: the natural A (or B) fragment of a [rows][64] image
+// 16 rows x 32 k (k = channel), rows r0.., k-step s: the natural A (or B) fragment
+template <int HD>
 __device__ __forceinline__ bf16x8 frag_rows(const char* img, int r0, int s, int lane) {
-    return *reinterpret_cast<const bf16x8*>(img + img_off(r0 + (lane & 15), 4 * s + (lane >> 4)));
+    return *reinterpret_cast<const bf16x8*>(img + img_off<HD>(r0 + (lane & 15), 4 * s + (lane >> 4)));
 }
 // Transposed fragment: operand row = image column d0 + (l&15), k = image rows in the accumulator-derived order
 // {kbase + 4g + 0..3, kbase + 16 + 4g + 0..3}, g = l>>4.
+template <int HD>
 __device__ __forceinline__ bf16x8 frag_cols_perm(const char* img, int d0, int kbase, int lane) {
     const int li = lane & 15, q = li >> 2, p = li & 3, g = lane >> 4;
     const int ch = (d0 >> 3) + (p >> 1);
     const int r_lo = kbase + 4 * g + q, r_hi = r_lo + 16;
-    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(img + img_off(r_lo, ch) + 8 * (p & 1)));
-    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(img + img_off(r_hi, ch) + 8 * (p & 1)));
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(img + img_off<HD>(r_lo, ch) + 8 * (p & 1)));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(img + img_off<HD>(r_hi, ch) + 8 * (p & 1)));
     bf16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return r;
 }
@@ -69,191 +82,234 @@ __device__ __forceinline__ float group_max(float v) {
     return v;
 }
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define DMA_WAIT_SYNC()                                 \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    \
+    __syncthreads()
 
 // ------------------------------------------------------------------------------------------------
-// forward: grid (T/64, B*H), 4 waves x 16 queries.  NT = T/16 key tiles.
+// forward: grid (T/64, B*H), 4 waves x 16 queries; keys stream in blocks of 64 with an online softmax
 // ------------------------------------------------------------------------------------------------
-template <int NT>
+template <int HD>
 __global__ void __launch_bounds__(256)
 attn_fwd_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
               bf16_t* __restrict__ o, float* __restrict__ lse) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int T = NT * 16;
-    char* qimg = smem;                  // [64][64]
-    char* kimg = smem + 64 * 128;       // [T][64]
-    char* vimg = kimg + T * 128;        // [T][64]
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 3 images of 64 x HD bf16
+    constexpr int KS = HD / 32, DT = HD / 16;
+    char* qimg = smem;
+    char* kimg = smem + 64 * 2 * HD;
+    char* vimg = kimg + 64 * 2 * HD;
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
     const int qb = blockIdx.x * 64;
     const int64_t base = b * a.q_sb + h * a.q_sh;
-    stage_rows(q + base + (int64_t)qb * a.q_st, a.q_st, 64, qimg, wid, lane);
-    stage_rows(k + base, a.q_st, T, kimg, wid, lane);
-    stage_rows(v + base, a.q_st, T, vimg, wid, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    f32x4 st[NT];
-    const bf16x8 qf0 = frag_rows(qimg, 16 * wid, 0, lane), qf1 = frag_rows(qimg, 16 * wid, 1, lane);
+    stage_block<HD>(q + base + (int64_t)qb * a.q_st, a.q_st, qimg, wid, lane);
+    bf16x8 qf[KS];
+    f32x4 ot[DT];
 #pragma unroll
-    for (int jt = 0; jt < NT; ++jt) {
-        f32x4 c = {0, 0, 0, 0};
-        c = MFMA(frag_rows(kimg, 16 * jt, 0, lane), qf0, c);
-        c = MFMA(frag_rows(kimg, 16 * jt, 1, lane), qf1, c);
-        st[jt] = c;
-    }
-    float mx = -INFINITY;
+    for (int dt = 0; dt < DT; ++dt) ot[dt] = f32x4{0, 0, 0, 0};
+    float m = -INFINITY, l = 0.f;
+    for (int kb = 0; kb < a.T; kb += 64) {
+        __syncthreads();                                     // previous block's reads of kimg / vimg are done
+        stage_block<HD>(k + base + (int64_t)kb * a.q_st, a.q_st, kimg, wid, lane);
+        stage_block<HD>(v + base + (int64_t)kb * a.q_st, a.q_st, vimg, wid, lane);
+        DMA_WAIT_SYNC();
+        if (kb == 0) {
 #pragma unroll
-    for (int jt = 0; jt < NT; ++jt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[jt][r]);
-    mx = group_max(mx) * a.scale;
-    float l = 0.f;
-#pragma unroll
-    for (int jt = 0; jt < NT; ++jt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            st[jt][r] = __expf(st[jt][r] * a.scale - mx);
-            l += st[jt][r];
+            for (int s = 0; s < KS; ++s) qf[s] = frag_rows<HD>(qimg, 16 * wid, s, lane);
         }
-    l = group_sum(l);
-    f32x4 ot[4];
+        f32x4 st[4];
+        float bm = -INFINITY;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) ot[dt] = f32x4{0, 0, 0, 0};
+        for (int jt = 0; jt < 4; ++jt) {
+            f32x4 c = {0, 0, 0, 0};
 #pragma unroll
-    for (int s2 = 0; s2 < NT / 2; ++s2) {
-        const bf16x8 pf = pack_acc(st[2 * s2], st[2 * s2 + 1]);
+            for (int s = 0; s < KS; ++s) c = MFMA(frag_rows<HD>(kimg, 16 * jt, s, lane), qf[s], c);
+            st[jt] = c;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) ot[dt] = MFMA(frag_cols_perm(vimg, 16 * dt, 32 * s2, lane), pf, ot[dt]);
+            for (int r = 0; r < 4; ++r) bm = fmaxf(bm, c[r]);
+        }
+        const float m_new = fmaxf(m, group_max(bm) * a.scale);
+        const float alpha = __expf(m - m_new);               // first block: exp(-inf) = 0 on l = 0, ot = 0
+        float ps = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                st[jt][r] = __expf(st[jt][r] * a.scale - m_new);
+                ps += st[jt][r];
+            }
+        l = l * alpha + group_sum(ps);
+        m = m_new;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) ot[dt] *= alpha;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 pf = pack_acc(st[2 * s2], st[2 * s2 + 1]);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) ot[dt] = MFMA(frag_cols_perm<HD>(vimg, 16 * dt, 32 * s2, lane), pf, ot[dt]);
+        }
     }
     const float inv = 1.f / l;
     const int qi = qb + 16 * wid + (lane & 15);
     bf16_t* orow = o + b * a.o_sb + h * a.o_sh + (int64_t)qi * a.o_st + 4 * (lane >> 4);
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) store4(orow + 16 * dt, ot[dt] * inv);
-    if ((lane >> 4) == 0) lse[(int64_t)bh * a.T + qi] = mx + __logf(l);
+    for (int dt = 0; dt < DT; ++dt) store4(orow + 16 * dt, ot[dt] * inv);
+    if ((lane >> 4) == 0) lse[(int64_t)bh * a.T + qi] = m + __logf(l);
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward: grid (B*H), 4 waves; phase A = query-major (dQ, delta), phase B = key-major (dK, dV).
+// backward, query-major: grid (T/64, B*H); delta and dQ for 64 queries, keys stream
 // ------------------------------------------------------------------------------------------------
-template <int NT>
+template <int HD>
 __global__ void __launch_bounds__(256)
-attn_bwd_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
-              const bf16_t* __restrict__ d_o, const float* __restrict__ lse, float* __restrict__ delta_out,
-              bf16_t* __restrict__ dq, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int T = NT * 16;
+attn_bwd_dq_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                 const bf16_t* __restrict__ o, const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
+                 float* __restrict__ delta_out, bf16_t* __restrict__ dq) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 images of 64 x HD bf16
+    constexpr int KS = HD / 32, DT = HD / 16;
     char* qimg = smem;
-    char* kimg = qimg + T * 128;
-    char* vimg = kimg + T * 128;
-    char* gimg = vimg + T * 128;                                    // dO
-    float* lse_s = reinterpret_cast<float*>(gimg + T * 128);        // [T]
-    float* del_s = lse_s + T;                                       // [T]
-    const int lane = threadIdx.x & 63;
+    char* gimg = qimg + 64 * 2 * HD;
+    char* kimg = gimg + 64 * 2 * HD;
+    char* vimg = kimg + 64 * 2 * HD;
+    const int lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
+    const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
+    const int qb = blockIdx.x * 64;
     const int64_t base = b * a.q_sb + h * a.q_sh, obase = b * a.o_sb + h * a.o_sh;
-    stage_rows(q + base, a.q_st, T, qimg, wid, lane);
-    stage_rows(k + base, a.q_st, T, kimg, wid, lane);
-    stage_rows(v + base, a.q_st, T, vimg, wid, lane);
-    stage_rows(d_o + obase, a.o_st, T, gimg, wid, lane);
-    for (int i = threadIdx.x; i < T; i += 256) lse_s[i] = lse[(int64_t)bh * a.T + i];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const int g = lane >> 4, li = lane & 15;
-
-    // ---- phase A: this wave's queries are the lane dimension ---------------------------------
-    for (int qt = wid; qt < NT; qt += 4) {
-        const int q0 = 16 * qt;
-        const bf16x8 qf0 = frag_rows(qimg, q0, 0, lane), qf1 = frag_rows(qimg, q0, 1, lane);
-        const bf16x8 gf0 = frag_rows(gimg, q0, 0, lane), gf1 = frag_rows(gimg, q0, 1, lane);
-        f32x4 p[NT], dp[NT];
+    stage_block<HD>(q + base + (int64_t)qb * a.q_st, a.q_st, qimg, wid, lane);
+    stage_block<HD>(d_o + obase + (int64_t)qb * a.o_st, a.o_st, gimg, wid, lane);
+    const int qi = qb + 16 * wid + li;
+    // delta_i = sum_d dO[i,d] * O[i,d]: lane (li, g) takes a quarter of the row
+    float dl = 0.f;
+    {
+        const bf16_t* gp = d_o + obase + (int64_t)qi * a.o_st + g * (HD / 4);
+        const bf16_t* op = o + obase + (int64_t)qi * a.o_st + g * (HD / 4);
 #pragma unroll
-        for (int jt = 0; jt < NT; ++jt) {
-            f32x4 c = {0, 0, 0, 0}, d = {0, 0, 0, 0};
-            c = MFMA(frag_rows(kimg, 16 * jt, 0, lane), qf0, c);
-            c = MFMA(frag_rows(kimg, 16 * jt, 1, lane), qf1, c);
-            d = MFMA(frag_rows(vimg, 16 * jt, 0, lane), gf0, d);
-            d = MFMA(frag_rows(vimg, 16 * jt, 1, lane), gf1, d);
-            p[jt] = c;
-            dp[jt] = d;
+        for (int d = 0; d < HD / 4; d += 4) {
+            const f32x4 x = load4(gp + d), y = load4(op + d);
+            dl += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
         }
-        const float li_lse = lse_s[q0 + li];
-        float dl = 0.f;
-#pragma unroll
-        for (int jt = 0; jt < NT; ++jt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                p[jt][r] = __expf(p[jt][r] * a.scale - li_lse);
-                dl += p[jt][r] * dp[jt][r];
-            }
         dl = group_sum(dl);
-        if (g == 0) {
-            del_s[q0 + li] = dl;
-            delta_out[(int64_t)bh * a.T + q0 + li] = dl;
-        }
-#pragma unroll
-        for (int jt = 0; jt < NT; ++jt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) p[jt][r] = a.scale * p[jt][r] * (dp[jt][r] - dl);   // dS^T (scaled)
-        f32x4 acc[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) acc[dt] = f32x4{0, 0, 0, 0};
-#pragma unroll
-        for (int s2 = 0; s2 < NT / 2; ++s2) {
-            const bf16x8 sf = pack_acc(p[2 * s2], p[2 * s2 + 1]);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) acc[dt] = MFMA(frag_cols_perm(kimg, 16 * dt, 32 * s2, lane), sf, acc[dt]);
-        }
-        bf16_t* row = dq + base + (int64_t)(q0 + li) * a.q_st + 4 * g;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) store4(row + 16 * dt, acc[dt]);
     }
-    __syncthreads();   // delta of every query is in LDS
-
-    // ---- phase B: this wave's keys are the lane dimension ---------------------------------
-    for (int kt = wid; kt < NT; kt += 4) {
-        const int j0 = 16 * kt;
-        const bf16x8 kf0 = frag_rows(kimg, j0, 0, lane), kf1 = frag_rows(kimg, j0, 1, lane);
-        const bf16x8 vf0 = frag_rows(vimg, j0, 0, lane), vf1 = frag_rows(vimg, j0, 1, lane);
-        f32x4 p[NT], ds[NT];
+    const float li_lse = lse[(int64_t)bh * a.T + qi];
+    if (g == 0) delta_out[(int64_t)bh * a.T + qi] = dl;
+    bf16x8 qf[KS], gf[KS];
+    f32x4 acc[DT];
 #pragma unroll
-        for (int it = 0; it < NT; ++it) {
+    for (int dt = 0; dt < DT; ++dt) acc[dt] = f32x4{0, 0, 0, 0};
+    for (int kb = 0; kb < a.T; kb += 64) {
+        __syncthreads();
+        stage_block<HD>(k + base + (int64_t)kb * a.q_st, a.q_st, kimg, wid, lane);
+        stage_block<HD>(v + base + (int64_t)kb * a.q_st, a.q_st, vimg, wid, lane);
+        DMA_WAIT_SYNC();
+        if (kb == 0) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                qf[s] = frag_rows<HD>(qimg, 16 * wid, s, lane);
+                gf[s] = frag_rows<HD>(gimg, 16 * wid, s, lane);
+            }
+        }
+        f32x4 ds[4];
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
             f32x4 c = {0, 0, 0, 0}, d = {0, 0, 0, 0};
-            c = MFMA(frag_rows(qimg, 16 * it, 0, lane), kf0, c);
-            c = MFMA(frag_rows(qimg, 16 * it, 1, lane), kf1, c);
-            d = MFMA(frag_rows(gimg, 16 * it, 0, lane), vf0, d);
-            d = MFMA(frag_rows(gimg, 16 * it, 1, lane), vf1, d);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                c = MFMA(frag_rows<HD>(kimg, 16 * jt, s, lane), qf[s], c);
+                d = MFMA(frag_rows<HD>(vimg, 16 * jt, s, lane), gf[s], d);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ds[jt][r] = a.scale * __expf(c[r] * a.scale - li_lse) * (d[r] - dl);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 sf = pack_acc(ds[2 * s2], ds[2 * s2 + 1]);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) acc[dt] = MFMA(frag_cols_perm<HD>(kimg, 16 * dt, 32 * s2, lane), sf, acc[dt]);
+        }
+    }
+    bf16_t* row = dq + base + (int64_t)qi * a.q_st + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) store4(row + 16 * dt, acc[dt]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, key-major: grid (T/64, B*H); dK and dV for 64 keys, queries stream
+// ------------------------------------------------------------------------------------------------
+template <int HD>
+__global__ void __launch_bounds__(256)
+attn_bwd_dkv_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                  const bf16_t* __restrict__ d_o, const float* __restrict__ lse, const float* __restrict__ delta,
+                  bf16_t* __restrict__ dk, bf16_t* __restrict__ dv) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 images of 64 x HD bf16 + lse / delta of the query block
+    constexpr int KS = HD / 32, DT = HD / 16;
+    char* kimg = smem;
+    char* vimg = kimg + 64 * 2 * HD;
+    char* qimg = vimg + 64 * 2 * HD;
+    char* gimg = qimg + 64 * 2 * HD;
+    float* lse_s = reinterpret_cast<float*>(gimg + 64 * 2 * HD);
+    float* del_s = lse_s + 64;
+    const int lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
+    const int jb = blockIdx.x * 64;
+    const int64_t base = b * a.q_sb + h * a.q_sh, obase = b * a.o_sb + h * a.o_sh;
+    stage_block<HD>(k + base + (int64_t)jb * a.q_st, a.q_st, kimg, wid, lane);
+    stage_block<HD>(v + base + (int64_t)jb * a.q_st, a.q_st, vimg, wid, lane);
+    bf16x8 kf[KS], vf[KS];
+    f32x4 av[DT], ak[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) av[dt] = ak[dt] = f32x4{0, 0, 0, 0};
+    for (int ib = 0; ib < a.T; ib += 64) {
+        __syncthreads();
+        stage_block<HD>(q + base + (int64_t)ib * a.q_st, a.q_st, qimg, wid, lane);
+        stage_block<HD>(d_o + obase + (int64_t)ib * a.o_st, a.o_st, gimg, wid, lane);
+        if (threadIdx.x < 64) {
+            lse_s[threadIdx.x] = lse[(int64_t)bh * a.T + ib + threadIdx.x];
+            del_s[threadIdx.x] = delta[(int64_t)bh * a.T + ib + threadIdx.x];
+        }
+        DMA_WAIT_SYNC();
+        if (ib == 0) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                kf[s] = frag_rows<HD>(kimg, 16 * wid, s, lane);
+                vf[s] = frag_rows<HD>(vimg, 16 * wid, s, lane);
+            }
+        }
+        f32x4 p[4], ds[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            f32x4 c = {0, 0, 0, 0}, d = {0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                c = MFMA(frag_rows<HD>(qimg, 16 * it, s, lane), kf[s], c);
+                d = MFMA(frag_rows<HD>(gimg, 16 * it, s, lane), vf[s], d);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = 16 * it + 4 * g + r;
                 const float pr = __expf(c[r] * a.scale - lse_s[i]);
-                c[r] = pr;
-                d[r] = a.scale * pr * (d[r] - del_s[i]);
+                p[it][r] = pr;
+                ds[it][r] = a.scale * pr * (d[r] - del_s[i]);
             }
-            p[it] = c;
-            ds[it] = d;
         }
-        f32x4 av[4], ak[4];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) av[dt] = ak[dt] = f32x4{0, 0, 0, 0};
-#pragma unroll
-        for (int s2 = 0; s2 < NT / 2; ++s2) {
+        for (int s2 = 0; s2 < 2; ++s2) {
             const bf16x8 pf = pack_acc(p[2 * s2], p[2 * s2 + 1]);
             const bf16x8 sf = pack_acc(ds[2 * s2], ds[2 * s2 + 1]);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                av[dt] = MFMA(frag_cols_perm(gimg, 16 * dt, 32 * s2, lane), pf, av[dt]);
-                ak[dt] = MFMA(frag_cols_perm(qimg, 16 * dt, 32 * s2, lane), sf, ak[dt]);
+            for (int dt = 0; dt < DT; ++dt) {
+                av[dt] = MFMA(frag_cols_perm<HD>(gimg, 16 * dt, 32 * s2, lane), pf, av[dt]);
+                ak[dt] = MFMA(frag_cols_perm<HD>(qimg, 16 * dt, 32 * s2, lane), sf, ak[dt]);
             }
         }
-        const int64_t off = base + (int64_t)(j0 + li) * a.q_st + 4 * g;
+    }
+    const int64_t off = base + (int64_t)(jb + 16 * wid + li) * a.q_st + 4 * g;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            store4(dv + off + 16 * dt, av[dt]);
-            store4(dk + off + 16 * dt, ak[dt]);
-        }
+    for (int dt = 0; dt < DT; ++dt) {
+        store4(dv + off + 16 * dt, av[dt]);
+        store4(dk + off + 16 * dt, ak[dt]);
     }
 }
 
@@ -263,9 +319,10 @@ attn_bwd_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __rest
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 bool vaw_attn_mfma_ok(vaw_dtype dt, const vaw_attn_desc* d, const void* q, const void* k, const void* v, const void* o) {
-    return dt == VAW_BF16 && d->hd == 64 && d->T % 64 == 0 && d->T <= 256 && d->q_sd == 1 && d->o_sd == 1 &&
-           d->q_st % 8 == 0 && d->q_sh % 8 == 0 && d->q_sb % 8 == 0 && d->o_st % 8 == 0 && d->o_sh % 8 == 0 &&
-           d->o_sb % 8 == 0 && aligned16(q) && aligned16(k) && aligned16(v) && aligned16(o) && (int64_t)d->B * d->H < 65536;
+    const bool hd_ok = d->hd == 32 || d->hd == 64 || d->hd == 96 || d->hd == 128;
+    return dt == VAW_BF16 && hd_ok && d->T % 64 == 0 && d->q_sd == 1 && d->o_sd == 1 && d->q_st % 8 == 0 && d->q_sh % 8 == 0 &&
+           d->q_sb % 8 == 0 && d->o_st % 8 == 0 && d->o_sh % 8 == 0 && d->o_sb % 8 == 0 && aligned16(q) && aligned16(k) &&
+           aligned16(v) && aligned16(o) && (int64_t)d->B * d->H < 65536;
 }
 
 static AttnMfmaArgs mk_args(const vaw_attn_desc* d) {
@@ -273,35 +330,39 @@ static AttnMfmaArgs mk_args(const vaw_attn_desc* d) {
     return a;
 }
 
-#define DISPATCH_NT(T, ...)                               \
-    switch ((T) / 16) {                                   \
-        case 4: { constexpr int NT = 4; __VA_ARGS__ } break;   \
-        case 8: { constexpr int NT = 8; __VA_ARGS__ } break;   \
-        case 12: { constexpr int NT = 12; __VA_ARGS__ } break; \
-        default: { constexpr int NT = 16; __VA_ARGS__ } break; \
+#define DISPATCH_HD(hd, ...)                                \
+    switch (hd) {                                           \
+        case 32: { constexpr int HD = 32; __VA_ARGS__ } break;   \
+        case 64: { constexpr int HD = 64; __VA_ARGS__ } break;   \
+        case 96: { constexpr int HD = 96; __VA_ARGS__ } break;   \
+        default: { constexpr int HD = 128; __VA_ARGS__ } break;  \
     }
 
 int vaw_attn_fwd_mfma(const vaw_attn_desc* d, const void* q, const void* k, const void* v, void* o, float* lse,
                       hipStream_t s) {
     AttnMfmaArgs a = mk_args(d);
     dim3 grid(d->T / 64, d->B * d->H);
-    const size_t lds = (size_t)(64 + 2 * d->T) * 128;
-    DISPATCH_NT(d->T,
-        (void)hipFuncSetAttribute((const void*)attn_fwd_mfma<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attn_fwd_mfma<NT><<<grid, 256, lds, s>>>(a, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse);
+    DISPATCH_HD(d->hd,
+        const int lds = 3 * 64 * 2 * HD;
+        (void)hipFuncSetAttribute((const void*)attn_fwd_mfma<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attn_fwd_mfma<HD><<<grid, 256, lds, s>>>(a, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse);
     )
     VAW_CHECK_LAUNCH("attn_fwd_mfma");
     return VAW_OK;
 }
 
-int vaw_attn_bwd_mfma(const vaw_attn_desc* d, const void* q, const void* k, const void* v, const void* d_o,
+int vaw_attn_bwd_mfma(const vaw_attn_desc* d, const void* q, const void* k, const void* v, const void* o, const void* d_o,
                       const float* lse, float* delta, void* dq, void* dk, void* dv, hipStream_t s) {
     AttnMfmaArgs a = mk_args(d);
-    const size_t lds = (size_t)4 * d->T * 128 + 2 * d->T * sizeof(float);
-    DISPATCH_NT(d->T,
-        (void)hipFuncSetAttribute((const void*)attn_bwd_mfma<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attn_bwd_mfma<NT><<<d->B * d->H, 256, lds, s>>>(a, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
-                                                          (const bf16_t*)d_o, lse, delta, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv);
+    dim3 grid(d->T / 64, d->B * d->H);
+    DISPATCH_HD(d->hd,
+        const int lds = 4 * 64 * 2 * HD + 2 * 64 * 4;
+        (void)hipFuncSetAttribute((const void*)attn_bwd_dq_mfma<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_mfma<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attn_bwd_dq_mfma<HD><<<grid, 256, lds, s>>>(a, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o,
+                                                   (const bf16_t*)d_o, lse, delta, (bf16_t*)dq);
+        attn_bwd_dkv_mfma<HD><<<grid, 256, lds, s>>>(a, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)d_o,
+                                                    lse, delta, (bf16_t*)dk, (bf16_t*)dv);
     )
     VAW_CHECK_LAUNCH("attn_bwd_mfma");
     return VAW_OK;

@@ -10,6 +10,9 @@ static inline int sgrid(int64_t work, int block) {
     int64_t g = (work + block - 1) / block;
     return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
 }
+#define BY_DTYPE(dt, CALL)                      \
+    if (dt == VAW_F32) { using T = float; CALL; } \
+    else { using T = bf16_t; CALL; }
 #define GRID_STRIDE(i, n) for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
 
 // ---------------------------------------------------------------------------------------------
@@ -244,6 +247,113 @@ __global__ void col2im3x3_kernel(const T* __restrict__ dcol, T* __restrict__ dx,
 }
 
 // ---------------------------------------------------------------------------------------------
+// conv3x3 weight gradient when one side has <= 4 channels (the 3-channel stem and output convs): a GEMM would
+// have a 3- or 27-wide dimension.  One thread per channel of the WIDE side keeps its 9*S accumulators (S = small
+// channel count) in registers and walks a chunk of pixels; chunk partials are folded in a fixed order.
+//   SMALL_IN : dW[co][tap][ci] = sum_m dy[m][co] * x[nbr(m,tap)][ci],  thread = co, ci < S
+//   !SMALL_IN: same sum, thread = ci, co < S
+// ---------------------------------------------------------------------------------------------
+#define WG_CHUNK 256
+template <typename T, int S, bool SMALL_IN>
+__global__ void __launch_bounds__(256)
+conv3x3_wgrad_small_kernel(const T* __restrict__ dy, const T* __restrict__ x, float* __restrict__ part, int B, int H, int W,
+                           int Cw /* wide channel count */) {
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    const int64_t M = (int64_t)B * H * W;
+    const int64_t m0 = (int64_t)blockIdx.x * WG_CHUNK, m1 = m0 + WG_CHUNK < M ? m0 + WG_CHUNK : M;
+    float acc[9][S];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < S; ++j) acc[t][j] = 0.f;
+    if (c < Cw) {
+        for (int64_t m = m0; m < m1; ++m) {
+            const int w = (int)(m % W), h = (int)((m / W) % H);
+            if (SMALL_IN) {
+                const float g = to_f32(dy[m * Cw + c]);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
+                    if (hh >= 0 && hh < H && ww >= 0 && ww < W) {
+                        const T* xp = x + (m + (int64_t)(t / 3 - 1) * W + (t % 3 - 1)) * S;
+#pragma unroll
+                        for (int j = 0; j < S; ++j) acc[t][j] += g * to_f32(xp[j]);
+                    }
+                }
+            } else {
+                float g[S];
+#pragma unroll
+                for (int j = 0; j < S; ++j) g[j] = to_f32(dy[m * S + j]);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
+                    if (hh >= 0 && hh < H && ww >= 0 && ww < W) {
+                        const float xv = to_f32(x[(m + (int64_t)(t / 3 - 1) * W + (t % 3 - 1)) * Cw + c]);
+#pragma unroll
+                        for (int j = 0; j < S; ++j) acc[t][j] += g[j] * xv;
+                    }
+                }
+            }
+        }
+        // partial layout = the weight layout [Co][9][Ci], one slab per chunk
+        float* out = part + (int64_t)blockIdx.x * 9 * S * Cw;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                if (SMALL_IN) out[((int64_t)c * 9 + t) * S + j] = acc[t][j];
+                else out[((int64_t)j * 9 + t) * Cw + c] = acc[t][j];
+            }
+    }
+}
+__global__ void fold_slabs_kernel(const float* __restrict__ part, int64_t nslab, int64_t n, float* __restrict__ out, float beta) {
+    __shared__ float fold[8][33];
+    const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;   // 32 outputs x 8 slab groups
+    const int64_t i = (int64_t)blockIdx.x * 32 + cl;
+    float acc = 0.f;
+    if (i < n)
+        for (int64_t sidx = grp; sidx < nslab; sidx += 8) acc += part[sidx * n + i];
+    fold[grp][cl] = acc;
+    __syncthreads();
+    if (grp == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) t += fold[g][cl];
+        out[i] = (beta != 0.f ? beta * out[i] : 0.f) + t;
+    }
+}
+
+extern "C" int64_t vaw_conv3x3_wgrad_small_workspace_floats(int B, int H, int W, int Ci, int Co) {
+    const int64_t M = (int64_t)B * H * W;
+    return ((M + WG_CHUNK - 1) / WG_CHUNK) * 9 * Ci * Co;
+}
+
+extern "C" int vaw_conv3x3_wgrad_small(vaw_dtype dt, const void* dy, const void* x, float* dw, float beta, int B, int H, int W,
+                                       int Ci, int Co, float* workspace, int64_t workspace_floats, vaw_stream stream) {
+    VAW_CHECK_ARG(B > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0 && (Ci <= 4 || Co <= 4), "conv3x3_wgrad_small: needs Ci<=4 or Co<=4");
+    VAW_CHECK_ARG(workspace && workspace_floats >= vaw_conv3x3_wgrad_small_workspace_floats(B, H, W, Ci, Co), "conv3x3_wgrad_small: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t M = (int64_t)B * H * W;
+    const int nchunk = (int)((M + WG_CHUNK - 1) / WG_CHUNK);
+    const bool small_in = Ci <= 4;
+    const int S = small_in ? Ci : Co, Cw = small_in ? Co : Ci;
+    dim3 grid(nchunk, ceil_div(Cw, 256));
+#define WG_LAUNCH(Sv)                                                                                                          \
+    if (small_in) { BY_DTYPE(dt, (conv3x3_wgrad_small_kernel<T, Sv, true><<<grid, 256, 0, s>>>((const T*)dy, (const T*)x, workspace, B, H, W, Cw))); } \
+    else { BY_DTYPE(dt, (conv3x3_wgrad_small_kernel<T, Sv, false><<<grid, 256, 0, s>>>((const T*)dy, (const T*)x, workspace, B, H, W, Cw))); }
+    switch (S) {
+        case 1: WG_LAUNCH(1) break;
+        case 2: WG_LAUNCH(2) break;
+        case 3: WG_LAUNCH(3) break;
+        default: WG_LAUNCH(4) break;
+    }
+    const int64_t n = 9LL * Ci * Co;
+    fold_slabs_kernel<<<ceil_div(n, 32), 256, 0, s>>>(workspace, nchunk, n, dw, beta);
+    VAW_CHECK_LAUNCH("conv3x3_wgrad_small");
+    return VAW_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // resampling, concat, layout
 // ---------------------------------------------------------------------------------------------
 // mode 0: out[b,h,w,:] = mean of the 2x2 block of in (in is 2H x 2W)          (avg_pool2d; also nearest-upsample^T * 1/4 * 4)
@@ -308,10 +418,6 @@ __global__ void layout_kernel(const float* __restrict__ nchw_in, float* __restri
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
-#define BY_DTYPE(dt, CALL)                      \
-    if (dt == VAW_F32) { using T = float; CALL; } \
-    else { using T = bf16_t; CALL; }
-
 extern "C" int64_t vaw_groupnorm_workspace_floats(int B, int C) { return 6 * (int64_t)B * C + 64; }
 
 extern "C" int vaw_groupnorm_fwd(vaw_dtype dt, const void* x, const float* gamma, const float* beta, const float* scale,

@@ -285,11 +285,19 @@ class UNetModel(FlatModule):
 
         def bw():
             dy = y.grad
-            colb = self._new(M, K)
-            L.check(lib.vaw_im2col3x3(dt, ptr(a.t), ptr(colb), a.B, a.H, a.W, Ci, L.stream_ptr()), "im2col")
-            ops.gemm(dt, 0, 0, Co, K, M, ptr(dy), Co, ptr(colb), K, self._g(name + ".weight"), K, beta=self._beta, out_f32=True)
             ops.colsum(dt, ptr(dy), M, Co, Co, self._g(name + ".bias"), self._beta, device=self._flat.device)
-            if a.grad is not None or self._needs_grad(a):
+            need_dx = a.grad is not None or self._needs_grad(a)
+            if min(Ci, Co) <= 4:       # 3-channel stem / output conv: dedicated skinny weight-gradient kernel
+                need = lib.vaw_conv3x3_wgrad_small_workspace_floats(a.B, a.H, a.W, Ci, Co)
+                ws = ops.scratch_f32(self._flat.device, need)
+                L.check(lib.vaw_conv3x3_wgrad_small(dt, ptr(dy), ptr(a.t), self._g(name + ".weight"), self._beta, a.B, a.H, a.W,
+                                                    Ci, Co, ptr(ws), ws.numel(), L.stream_ptr()), "conv3x3_wgrad_small")
+                colb = self._new(M, K) if need_dx else None
+            else:
+                colb = self._new(M, K)
+                L.check(lib.vaw_im2col3x3(dt, ptr(a.t), ptr(colb), a.B, a.H, a.W, Ci, L.stream_ptr()), "im2col")
+                ops.gemm(dt, 0, 0, Co, K, M, ptr(dy), Co, ptr(colb), K, self._g(name + ".weight"), K, beta=self._beta, out_f32=True)
+            if need_dx:
                 ops.gemm(dt, 1, 0, M, K, Co, ptr(dy), Co, self._w(name + ".weight"), K, ptr(colb), K)     # d(col), in place of col
                 dx = self._new(M, Ci)
                 L.check(lib.vaw_col2im3x3(dt, ptr(colb), ptr(dx), a.B, a.H, a.W, Ci, L.stream_ptr()), "col2im")
