@@ -195,6 +195,14 @@ int vaw_groupnorm_bwd(vaw_dtype dt, const void* dout, const void* x, const float
  * vaw_col2im3x3 is the transposed map written as a gather (deterministic): the input gradient from d(col). */
 int vaw_im2col3x3(vaw_dtype dt, const void* x, void* col, int B, int H, int W, int C, vaw_stream stream);
 int vaw_col2im3x3(vaw_dtype dt, const void* dcol, void* dx, int B, int H, int W, int C, vaw_stream stream);
+/* conv3x3 (stride 1, pad 1) as IMPLICIT GEMM on the bf16 MFMA kernel: the patch matrix is never written; padding taps
+ * read a zero page.  mode 0: out[M,Co] = conv(act=x[M,Ci]; w) with the vaw_gemm epilogue (bias, residual, column sums);
+ * mode 1: out = dx[M,Ci] from act = dy[M,Co]; mode 2: out = dW[Co][9][Ci] f32 = beta*dW + dy^T . patches(x) with
+ * act = dy, act2 = x (split-K through the workspace).  w: [Co][3][3][Ci] act dtype.  Returns VAW_ERR_UNSUPPORTED
+ * (nothing launched) for shapes that need the explicit vaw_im2col3x3 + vaw_gemm path: f32, Ci or Co not a multiple
+ * of 64 (mode 0 / 1), ... */
+int vaw_conv3x3(vaw_dtype dt, int mode, const void* act, const void* act2, const void* w, void* out, int B, int H, int W,
+                int Ci, int Co, const vaw_epilogue* epi_host, float* workspace, int64_t workspace_floats, vaw_stream stream);
 /* conv3x3 weight gradient for the 3-channel stem / output convs (Ci <= 4 or Co <= 4), where a GEMM would be 3 wide:
  * dw[co][tap][ci] (f32, channels-last weight layout) = beta*dw + sum_m dy[m,co] * x[pixel(m)+tap, ci]; chunk
  * partials in the workspace are folded in a fixed order. */

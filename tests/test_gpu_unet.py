@@ -108,6 +108,38 @@ def test_conv3x3_via_gemm_matches_torch_and_weight_layout():
     torch.testing.assert_close(_nchw(y.cpu().double(), B, H, H), ref, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 8, 8, 64, 128), (3, 8, 8, 128, 192), (1, 16, 8, 192, 64), (4, 4, 4, 64, 64)])
+def test_implicit_gemm_conv3x3_fwd_dgrad_wgrad(B, H, W, Ci, Co):
+    """vaw_conv3x3 (no patch matrix; padding taps read a zero page) vs torch.conv2d and its gradients.  Small-integer
+    data makes the f32 weight gradient exact, so a wrong tap/pixel/channel address shows as a wrong integer."""
+    g = torch.Generator().manual_seed(B * H + Ci)
+    x = torch.randint(-2, 3, (B, Ci, H, W), generator=g).float()
+    w = torch.randint(-1, 2, (Co, Ci, 3, 3), generator=g).float()
+    dy = torch.randint(-2, 3, (B, Co, H, W), generator=g).float()
+    bias = torch.randint(-3, 4, (Co,), generator=g).float()
+    res = torch.randint(-2, 3, (B, Co, H, W), generator=g).float()
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    ref = F.conv2d(xr, wr, bias.double(), padding=1) + res.double()
+    (ref * dy.double()).sum().backward()
+    bf = torch.bfloat16
+    xd, dyd, rd = _nhwc(x).to(bf).to(DEV), _nhwc(dy).to(bf).to(DEV), _nhwc(res).to(bf).to(DEV)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(bf).to(DEV)            # stored [Co][3][3][Ci]
+    bd = bias.to(DEV)
+    M = B * H * W
+    y = torch.empty(M, Co, device=DEV, dtype=bf)
+    assert ops.conv3x3(BF16, 0, ptr(xd), None, ptr(wd), ptr(y), B, H, W, Ci, Co, bias=ptr(bd), resid=ptr(rd))
+    torch.testing.assert_close(_nchw(y.cpu().double(), B, H, W), ref.detach(), rtol=1e-2, atol=1.0)   # bf16 output rounding only
+    dx = torch.empty(M, Ci, device=DEV, dtype=bf)
+    assert ops.conv3x3(BF16, 1, ptr(dyd), None, ptr(wd), ptr(dx), B, H, W, Ci, Co)
+    torch.testing.assert_close(_nchw(dx.cpu().double(), B, H, W), xr.grad, rtol=1e-2, atol=1.0)
+    dw = torch.ones(Co, 3, 3, Ci, device=DEV)
+    assert ops.conv3x3(BF16, 2, ptr(dyd), ptr(xd), None, ptr(dw), B, H, W, Ci, Co, beta=1.0)
+    assert torch.equal(dw.cpu().double().permute(0, 3, 1, 2), 1.0 + wr.grad)                           # exact, and beta=1 accumulated
+    # unsupported shapes decline without launching
+    assert not ops.conv3x3(BF16, 0, ptr(xd), None, ptr(wd), ptr(y), B, H, W, 24, Co)
+    assert not ops.conv3x3(F32, 0, ptr(xd), None, ptr(wd), ptr(y), B, H, W, Ci, Co)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_resample_concat_layout(dtype):
     B, C, H = 2, 8, 6

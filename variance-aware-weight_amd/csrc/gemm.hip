@@ -214,10 +214,21 @@ __device__ __forceinline__ bf16x8 load_frag(const char* lds_tile, int r0, int s,
     }
 }
 
-template <bool AK, bool BKM, int BKT>
+// ---- implicit-GEMM conv3x3 (stride 1, pad 1) on NHWC activations: the patch matrix is never materialised; the LDS-DMA
+// source address of each 16-byte chunk is computed from (pixel, tap, channel) and padding taps read a zero page.
+//   CONV 1 (forward)        A[m][k=(tap,ci)]  = x[pix(m)+s(tap)][ci]                      B = W[co][(tap,ci)] (plain, k-major)
+//   CONV 2 (input gradient) A[m][k=(tap,co)]  = dy[pix(m)+s(tap)][co]                     B[k][n=ci] = W[co][8-tap][ci]  (mn-major slice)
+//   CONV 3 (weight gradient) A = dy^T (plain, mn-major)                                   B[k=m][n=(tap,ci)] = x[pix(m)+s(tap)][ci] (mn-major)
+// K tiles never straddle a tap: Ci (CONV 1) / Co (CONV 2) is a multiple of the stage depth.
+struct ConvGeom {
+    int H, W, Ci, Co;
+};
+__device__ __attribute__((aligned(64))) const unsigned char vaw_zero_page[64] = {0};
+
+template <bool AK, bool BKM, int BKT, int CONV>
 __global__ void __launch_bounds__(256, BKT == 64 ? 2 : 3)
 gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb, int nk_total,
-                 int tiles_n, int n_wg, int n_split, EpiDev e) {
+                 int tiles_n, int n_wg, int n_split, EpiDev e, ConvGeom cg) {
     using Cfg = FastCfg<BKT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A tile | B tile]; reused by the epilogue
     const int lane = threadIdx.x & 63;
@@ -247,8 +258,6 @@ gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __rest
     const int nk_per = (nk_total + n_split - 1) / n_split;
     const int kt0 = blockIdx.y * nk_per;
     const int nk = e.debug == 2 ? 1 : (kt0 + nk_per <= nk_total ? nk_per : nk_total - kt0);
-    const bf16_t* Ag = (AK ? A + m0 * lda : A + m0) + kt0 * a_step;
-    const bf16_t* Bg = (BKM ? B + n0 * ldb : B + n0) + kt0 * b_step;
     const int wm = (wid >> 1) * 64, wn = (wid & 1) * 64;
     const int mvalid = e.M - m0 < BM ? (int)(e.M - m0) : BM;     // edge tiles: rows / columns that exist
     const int nvalid = e.N - n0 < BN ? (int)(e.N - n0) : BN;
@@ -259,16 +268,87 @@ gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __rest
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
 
-    stage_tile<AK, BKT>(Ag, lda, smem, wid, lane, mvalid);
-    stage_tile<BKM, BKT>(Bg, ldb, smem + Cfg::tile_bytes, wid, lane, nvalid);
+    // ---- per-lane constants of the gather modes (pixel coordinates of the rows / columns this lane stages) ----
+    constexpr int PW = BKT / 16, CPR = BKT / 8;
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(vaw_zero_page);
+    int ga_h[PW], ga_w[PW];
+    int64_t ga_pix[PW];
+    if (CONV == 1 || CONV == 2) {
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            int row = (wid * PW + i) * (64 / CPR) + lane / CPR;
+            row = row < mvalid ? row : mvalid - 1;
+            const int64_t p = m0 + row;
+            ga_pix[i] = p;
+            ga_w[i] = (int)(p % cg.W);
+            ga_h[i] = (int)((p / cg.W) % cg.H);
+        }
+    }
+    int gb_tap[PW], gb_ci[PW];
+    if (CONV == 3) {
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            const int row = (wid * PW + i) * 4 + (lane >> 4);
+            const int chunk = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
+            const int n = (int)n0 + chunk * 8;
+            gb_tap[i] = n < e.N ? n / cg.Ci : -1;     // -1: column beyond 9*Ci (edge tile) -> zero page
+            gb_ci[i] = n % cg.Ci;
+        }
+    }
+    auto stage_a = [&](int ktile, char* dst) {        // ktile counts BKT-deep tiles from k = 0
+        if (CONV == 1 || CONV == 2) {
+            const int cin = CONV == 1 ? cg.Ci : cg.Co;
+            const int kglob = ktile * BKT;
+            const int tap = kglob / cin, c0 = kglob - tap * cin;
+            const int dh = tap / 3 - 1, dw = tap % 3 - 1;
+#pragma unroll
+            for (int i = 0; i < PW; ++i) {
+                const int inst = wid * PW + i;
+                const int row = inst * (64 / CPR) + lane / CPR;
+                const int chunk = (lane % CPR) ^ kmaj_swz<BKT>(row);
+                const int hh = ga_h[i] + dh, ww = ga_w[i] + dw;
+                const bool in = hh >= 0 && hh < cg.H && ww >= 0 && ww < cg.W;
+                const bf16_t* src = in ? A + (ga_pix[i] + (int64_t)dh * cg.W + dw) * cin + c0 + chunk * 8 : zero;
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(dst + inst * 1024), 16, 0, 0);
+            }
+        } else {
+            stage_tile<AK, BKT>((AK ? A + m0 * lda : A + m0) + ktile * a_step, lda, dst, wid, lane, mvalid);
+        }
+    };
+    auto stage_b = [&](int ktile, char* dst) {
+        if (CONV == 2) {                              // W[co][8-tap][ci]: rows = co, row stride 9*Ci, tap picks the column window
+            const int kglob = ktile * BKT;
+            const int tap = kglob / cg.Co, c0 = kglob - tap * cg.Co;
+            stage_tile<false, BKT>(B + (int64_t)c0 * ldb + (8 - tap) * cg.Ci + n0, ldb, dst, wid, lane, nvalid);
+        } else if (CONV == 3) {
+            const int64_t kglob = (int64_t)ktile * BKT;
+#pragma unroll
+            for (int i = 0; i < PW; ++i) {
+                const int inst = wid * PW + i;
+                const int row = inst * 4 + (lane >> 4);
+                const int64_t p = kglob + row;
+                const int w = (int)(p % cg.W), h = (int)((p / cg.W) % cg.H);
+                const int tap = gb_tap[i];
+                const int dh = tap / 3 - 1, dw = tap % 3 - 1;
+                const int hh = h + dh, ww = w + dw;
+                const bool in = tap >= 0 && hh >= 0 && hh < cg.H && ww >= 0 && ww < cg.W;
+                const bf16_t* src = in ? B + (p + (int64_t)dh * cg.W + dw) * cg.Ci + gb_ci[i] : zero;
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(dst + inst * 1024), 16, 0, 0);
+            }
+        } else {
+            stage_tile<BKM, BKT>((BKM ? B + n0 * ldb : B + n0) + ktile * b_step, ldb, dst, wid, lane, nvalid);
+        }
+    };
+    stage_a(kt0, smem);
+    stage_b(kt0, smem + Cfg::tile_bytes);
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA for tile kt has landed
         __syncthreads();                                    // everyone's has; and tile kt-1 is no longer read
         char* cur = smem + (kt & 1) * Cfg::stage_bytes;
         if (kt + 1 < nk) {
             char* nxt = smem + ((kt + 1) & 1) * Cfg::stage_bytes;
-            stage_tile<AK, BKT>(Ag + (kt + 1) * a_step, lda, nxt, wid, lane, mvalid);
-            stage_tile<BKM, BKT>(Bg + (kt + 1) * b_step, ldb, nxt + Cfg::tile_bytes, wid, lane, nvalid);
+            stage_a(kt0 + kt + 1, nxt);
+            stage_b(kt0 + kt + 1, nxt + Cfg::tile_bytes);
         }
 #pragma unroll
         for (int s = 0; s < BKT / 32; ++s) {
@@ -551,11 +631,12 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
         static bool attr_done = false;                                                                                \
         const int lds = FastCfg<BKTv>::lds_bytes;                                                                     \
         if (!attr_done) {                                                                                             \
-            (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AKv, BKv, BKTv>,                                  \
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AKv, BKv, BKTv, 0>,                               \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);                               \
             attr_done = true;                                                                                         \
         }                                                                                                             \
-        gemm_bf16_kernel<AKv, BKv, BKTv><<<grid, 256, lds, s>>>(a, lda, b, ldb, nk_total, tiles_n, (int)n_wg, split, e); \
+        gemm_bf16_kernel<AKv, BKv, BKTv, 0><<<grid, 256, lds, s>>>(a, lda, b, ldb, nk_total, tiles_n, (int)n_wg, split, e, \
+                                                                    ConvGeom{});                                     \
     } while (0)
 #define LAUNCH_FAST_BK(BKTv)                                         \
     do {                                                             \
@@ -598,5 +679,81 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
     VAW_CHECK_LAUNCH("gemm_generic");
     if (colsum_out)   // generic path: a separate pass over the output just written
         return vaw_colsum(e.out_f32 ? VAW_F32 : dt, C, M, N, ldc, colsum_out, colsum_beta, workspace, workspace_floats, stream);
+    return VAW_OK;
+}
+
+
+// =============================================================================================
+// conv3x3 (stride 1, pad 1, NHWC) as implicit GEMM on the MFMA kernel.  Returns VAW_ERR_UNSUPPORTED when the
+// shape needs the explicit path (f32 parity mode, channel counts that are not multiples of 64, ...).
+//   mode 0  y[M,Co]   = conv(x; W) (+ epilogue)          act = x  [M,Ci]
+//   mode 1  dx[M,Ci]  = conv^T(dy; W)                    act = dy [M,Co]
+//   mode 2  dW[Co,9Ci] (f32) = beta*dW + dy^T . patches(x)   act = dy, act2 = x
+// W is stored [Co][3][3][Ci] (channels-last), act dtype.
+// =============================================================================================
+extern "C" int vaw_conv3x3(vaw_dtype dt, int mode, const void* act, const void* act2, const void* w, void* out, int B, int H,
+                           int W, int Ci, int Co, const vaw_epilogue* ep, float* workspace, int64_t workspace_floats,
+                           vaw_stream stream) {
+    VAW_CHECK_ARG(mode >= 0 && mode <= 2 && act && (w || mode == 2) && out && B > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0,
+                  "conv3x3: bad arguments");
+    if (dt != VAW_BF16 || g_force_generic) return VAW_ERR_UNSUPPORTED;
+    const int64_t Mpix = (int64_t)B * H * W;
+    int64_t M, N, K;
+    if (mode == 0) { M = Mpix; N = Co; K = 9LL * Ci; if (Ci % 64) return VAW_ERR_UNSUPPORTED; }
+    else if (mode == 1) { M = Mpix; N = Ci; K = 9LL * Co; if (Co % 64) return VAW_ERR_UNSUPPORTED; }
+    else { M = Co; N = 9LL * Ci; K = Mpix; if (Ci % 8 || Mpix % 64 || Co % 8 || !act2) return VAW_ERR_UNSUPPORTED; }
+    if (N % 8 || M < 16 || N < 16 || Mpix >= (1LL << 31)) return VAW_ERR_UNSUPPORTED;
+    if ((((uintptr_t)act | (uintptr_t)act2 | (uintptr_t)w | (uintptr_t)out) & 15) != 0) return VAW_ERR_UNSUPPORTED;
+    EpiDev e{};
+    e.alpha = 1.f;
+    if (ep) {
+        e.bias = ep->bias; e.act = ep->act; e.aux_in = ep->aux_in; e.aux_out = ep->aux_out; e.gate = ep->gate;
+        e.gate_ld = ep->gate_ld; e.resid = ep->resid; e.rowadd = ep->rowadd; e.rpb = ep->rows_per_batch;
+        e.alpha = ep->alpha; e.beta = ep->beta; e.out_f32 = ep->out_f32; e.resid_act = ep->resid_is_act;
+    }
+    if (e.rpb <= 0) e.rpb = 1;
+    if (mode == 2) e.out_f32 = 1;
+    VAW_CHECK_ARG(e.beta == 0.f || e.out_f32, "conv3x3: beta needs f32 output");
+    float* colsum_out = ep ? ep->colsum_out : nullptr;
+    const float colsum_beta = ep ? ep->colsum_beta : 0.f;
+    const int64_t ldc = N;
+    e.M = M; e.N = N; e.ldc = ldc; e.C = out; e.slab = workspace;
+    const bool epi_aligned = e.gate_ld % 4 == 0 && ((((uintptr_t)e.bias | (uintptr_t)e.aux_in | (uintptr_t)e.aux_out |
+                                                     (uintptr_t)e.gate | (uintptr_t)e.resid | (uintptr_t)e.rowadd) & 15) == 0);
+    if (!epi_aligned) return VAW_ERR_UNSUPPORTED;
+    VAW_CHECK_ARG(!colsum_out || (workspace && workspace_floats >= ((M + 127) / 128) * N), "conv3x3: colsum_out needs a workspace");
+    hipStream_t s = (hipStream_t)stream;
+    const int tiles_n = (int)((N + BN - 1) / BN);
+    const int64_t n_wg = ((M + BM - 1) / BM) * tiles_n;
+    const int nk_total = (int)(K / 64);
+    const bool plain_f32 = mode == 2 && !e.bias && !e.act;
+    int split = colsum_out ? 1 : pick_split(n_wg, K, M * N, workspace_floats, plain_f32);
+    if (colsum_out) e.colpart = workspace;
+    if (split > 1) {
+        const int per = (nk_total + split - 1) / split;
+        split = (nk_total + per - 1) / per;
+    }
+    dim3 grid((unsigned)n_wg, (unsigned)split);
+    const ConvGeom cg{H, W, Ci, Co};
+    const int lds = FastCfg<64>::lds_bytes;
+#define LAUNCH_CONV(AKv, BKv, CV, Aptr, LDA, Bptr, LDB)                                                                  \
+    do {                                                                                                                 \
+        static bool attr_done = false;                                                                                   \
+        if (!attr_done) {                                                                                                \
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AKv, BKv, 64, CV>,                                   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                  \
+            attr_done = true;                                                                                            \
+        }                                                                                                                \
+        gemm_bf16_kernel<AKv, BKv, 64, CV><<<grid, 256, lds, s>>>((const bf16_t*)(Aptr), LDA, (const bf16_t*)(Bptr), LDB, \
+                                                                  nk_total, tiles_n, (int)n_wg, split, e, cg);           \
+    } while (0)
+    if (mode == 0) LAUNCH_CONV(true, true, 1, act, (int64_t)Ci, w, 9LL * Ci);
+    else if (mode == 1) LAUNCH_CONV(true, false, 2, act, (int64_t)Co, w, 9LL * Ci);
+    else LAUNCH_CONV(false, false, 3, act, (int64_t)Co, act2, (int64_t)Ci);
+    if (split > 1)
+        splitk_reduce_kernel<float><<<ceil_div(M * N / 4, 256) > 2048 ? 2048 : ceil_div(M * N / 4, 256), 256, 0, s>>>(
+            workspace, split, M, N, ldc, out, e.alpha, e.beta, 1);
+    VAW_CHECK_LAUNCH("conv3x3");
+    if (colsum_out) return vaw_reduce_rows(workspace, (M + BM - 1) / BM, N, colsum_out, colsum_beta, stream);
     return VAW_OK;
 }

@@ -102,6 +102,28 @@ def beta_or_plain(bias, act, aux_out, gate, resid, rowadd):
     return not (bias or act or aux_out or gate or resid or rowadd)
 
 
+def conv3x3(dt, mode, act, act2, w, out, B, H, W, Ci, Co, *, bias=None, resid=None, resid_is_act=True, beta=0.0,
+            colsum_out=None, colsum_beta=0.0):
+    """Implicit-GEMM conv3x3 (vaw_conv3x3).  Returns False -- nothing launched -- when the shape needs the explicit
+    im2col + GEMM path.  mode 0 forward, 1 input gradient, 2 weight gradient (f32 out, beta accumulates)."""
+    e = Epilogue(bias or None, 0, None, None, None, 0, resid or None, None, 0, 1.0, beta, 1 if mode == 2 else 0,
+                 colsum_out or None, colsum_beta, 1 if resid_is_act else 0)
+    ws = scratch_f32(torch.device("cuda", torch.cuda.current_device()), 0)
+    tr = gemm_trace
+    if tr is not None:
+        e0, e1 = tr.events()
+        e0.record()
+    rc = L.lib().vaw_conv3x3(dt, mode, act, act2 or None, w, out, B, H, W, Ci, Co, C.byref(e), ws.data_ptr(), ws.numel(), stream_ptr())
+    if rc == -3:
+        return False
+    check(rc, "vaw_conv3x3")
+    if tr is not None:
+        e1.record()
+        M = B * H * W
+        tr.add(1, mode != 2, mode == 0, *((M, Co, 9 * Ci) if mode == 0 else (M, Ci, 9 * Co) if mode == 1 else (Co, 9 * Ci, M)), e0, e1)
+    return True
+
+
 class GemmTrace:
     """Measurement aid (bench.py): brackets every GEMM launch with HIP events on the launch stream."""
 

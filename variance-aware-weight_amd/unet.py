@@ -276,31 +276,38 @@ class UNetModel(FlatModule):
         name = mod._vaw_name
         Ci, Co, M, dt, lib = a.C, mod.out_channels, a.M, self._dt, L.lib()
         K = 9 * Ci
-        col = self._new(M, K)
-        L.check(lib.vaw_im2col3x3(dt, ptr(a.t), ptr(col), a.B, a.H, a.W, Ci, L.stream_ptr()), "im2col")
         y = _Act(self._new(M, Co), a.B, a.H, a.W, Co)
-        ops.gemm(dt, 1, 1, M, Co, K, ptr(col), K, self._w(name + ".weight"), K, ptr(y.t), Co, bias=self._p32(name + ".bias"),
-                 resid=ptr(resid.t) if resid is not None else None, resid_is_act=True)
-        del col
+        wp, bp = self._w(name + ".weight"), self._p32(name + ".bias")
+        rp = ptr(resid.t) if resid is not None else None
+        geo = (a.B, a.H, a.W, Ci, Co)
+        if not ops.conv3x3(dt, 0, ptr(a.t), None, wp, ptr(y.t), *geo, bias=bp, resid=rp):
+            col = self._new(M, K)           # explicit patch matrix: f32 parity mode and channel counts off the 64 grid
+            L.check(lib.vaw_im2col3x3(dt, ptr(a.t), ptr(col), a.B, a.H, a.W, Ci, L.stream_ptr()), "im2col")
+            ops.gemm(dt, 1, 1, M, Co, K, ptr(col), K, wp, K, ptr(y.t), Co, bias=bp, resid=rp, resid_is_act=True)
+            del col
 
         def bw():
             dy = y.grad
             ops.colsum(dt, ptr(dy), M, Co, Co, self._g(name + ".bias"), self._beta, device=self._flat.device)
             need_dx = a.grad is not None or self._needs_grad(a)
+            gw = self._g(name + ".weight")
+            colb = None
             if min(Ci, Co) <= 4:       # 3-channel stem / output conv: dedicated skinny weight-gradient kernel
                 need = lib.vaw_conv3x3_wgrad_small_workspace_floats(a.B, a.H, a.W, Ci, Co)
                 ws = ops.scratch_f32(self._flat.device, need)
-                L.check(lib.vaw_conv3x3_wgrad_small(dt, ptr(dy), ptr(a.t), self._g(name + ".weight"), self._beta, a.B, a.H, a.W,
-                                                    Ci, Co, ptr(ws), ws.numel(), L.stream_ptr()), "conv3x3_wgrad_small")
-                colb = self._new(M, K) if need_dx else None
-            else:
+                L.check(lib.vaw_conv3x3_wgrad_small(dt, ptr(dy), ptr(a.t), gw, self._beta, a.B, a.H, a.W, Ci, Co, ptr(ws),
+                                                    ws.numel(), L.stream_ptr()), "conv3x3_wgrad_small")
+            elif not ops.conv3x3(dt, 2, ptr(dy), ptr(a.t), None, gw, *geo, beta=self._beta):
                 colb = self._new(M, K)
                 L.check(lib.vaw_im2col3x3(dt, ptr(a.t), ptr(colb), a.B, a.H, a.W, Ci, L.stream_ptr()), "im2col")
-                ops.gemm(dt, 0, 0, Co, K, M, ptr(dy), Co, ptr(colb), K, self._g(name + ".weight"), K, beta=self._beta, out_f32=True)
+                ops.gemm(dt, 0, 0, Co, K, M, ptr(dy), Co, ptr(colb), K, gw, K, beta=self._beta, out_f32=True)
             if need_dx:
-                ops.gemm(dt, 1, 0, M, K, Co, ptr(dy), Co, self._w(name + ".weight"), K, ptr(colb), K)     # d(col), in place of col
                 dx = self._new(M, Ci)
-                L.check(lib.vaw_col2im3x3(dt, ptr(colb), ptr(dx), a.B, a.H, a.W, Ci, L.stream_ptr()), "col2im")
+                if not ops.conv3x3(dt, 1, ptr(dy), None, wp, ptr(dx), *geo):
+                    if colb is None:
+                        colb = self._new(M, K)
+                    ops.gemm(dt, 1, 0, M, K, Co, ptr(dy), Co, wp, K, ptr(colb), K)     # d(col)
+                    L.check(lib.vaw_col2im3x3(dt, ptr(colb), ptr(dx), a.B, a.H, a.W, Ci, L.stream_ptr()), "col2im")
                 self._acc(a, dx)
             if resid is not None:
                 self._acc(resid, dy)
