@@ -180,8 +180,8 @@ int vaw_attn_bwd(vaw_dtype dt, const vaw_attn_desc* d_host, const void* q, const
 /* GroupNorm32 (tools/nn.py:17-19,93-100; G groups, eps) fused with what follows it in ResBlock._forward
  * (unet.py:236-256):  y = act( GN(x)*gamma + beta [ *(1 + scale[b,c]) + shift[b,c] ] ), act = SiLU if silu else id.
  * scale/shift: f32 rows with stride film_ld (the emb_layers output), or both NULL.  mean/rstd: f32 [B*G] saved.
- * workspace: vaw_groupnorm_workspace_floats(B, C) f32. */
-int64_t vaw_groupnorm_workspace_floats(int B, int C);
+ * workspace: vaw_groupnorm_workspace_floats(B, HW, C) f32. */
+int64_t vaw_groupnorm_workspace_floats(int B, int HW, int C);
 int vaw_groupnorm_fwd(vaw_dtype dt, const void* x, const float* gamma, const float* beta, const float* scale,
                       const float* shift, int64_t film_ld, int silu, void* y, float* mean, float* rstd, int B, int HW,
                       int C, int G, float eps, float* workspace, vaw_stream stream);

@@ -33,7 +33,8 @@ def _nchw(m, B, H, W):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B,C,H,film,silu", [(2, 64, 8, True, True), (3, 96, 5, False, True), (2, 32, 4, False, False), (1, 192, 16, True, True)])
+@pytest.mark.parametrize("B,C,H,film,silu", [(2, 64, 8, True, True), (3, 96, 5, False, True), (2, 32, 4, False, False), (1, 192, 16, True, True),
+                                             (2, 64, 40, True, True)])
 def test_groupnorm_film_silu_fwd_bwd(dtype, B, C, H, film, silu):
     tol = dict(rtol=2e-5, atol=2e-5) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2)
     HW = H * H
@@ -54,7 +55,7 @@ def test_groupnorm_film_silu_fwd_bwd(dtype, B, C, H, film, silu):
     xd, gd, bd, ed = _nhwc(x).to(DEV), gamma.to(DEV), beta.to(DEV), emb.to(DEV)
     y = torch.empty(B * HW, C, device=DEV, dtype=dtype)
     mean, rstd = torch.empty(B * 32, device=DEV), torch.empty(B * 32, device=DEV)
-    ws = torch.empty(lib().vaw_groupnorm_workspace_floats(B, C), device=DEV)
+    ws = torch.empty(lib().vaw_groupnorm_workspace_floats(B, HW, C), device=DEV)
     sc = ptr(ed) + 4 * C if film else None
     sh = ptr(ed) + 8 * C if film else None
     assert lib().vaw_groupnorm_fwd(dt, ptr(xd), ptr(gd), ptr(bd), sc, sh, 3 * C, int(silu), ptr(y), ptr(mean), ptr(rstd), B, HW, C, 32,

@@ -91,7 +91,7 @@ def lib():
         L.vaw_colsum_workspace_floats.restype = _l
         L.vaw_conv3x3_wgrad_small_workspace_floats.argtypes = [_i, _i, _i, _i, _i]
         L.vaw_conv3x3_wgrad_small_workspace_floats.restype = _l
-        L.vaw_groupnorm_workspace_floats.argtypes = [_i, _i]
+        L.vaw_groupnorm_workspace_floats.argtypes = [_i, _i, _i]
         L.vaw_groupnorm_workspace_floats.restype = _l
         L.vaw_sumsq_workspace_floats.argtypes = []
         L.vaw_sumsq_workspace_floats.restype = _l

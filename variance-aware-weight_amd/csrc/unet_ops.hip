@@ -16,48 +16,75 @@ static inline int sgrid(int64_t work, int block) {
 #define GRID_STRIDE(i, n) for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
 
 // ---------------------------------------------------------------------------------------------
-// GroupNorm statistics.  Stage 1: per (sample, channel) sums over the HW pixels, 64 channels x 4 row groups per
-// block (coalesced 128-B rows of bf16).  Stage 2: fold the C/G channels of each group.
+// GroupNorm32 (+FiLM, +SiLU) forward and backward as streaming passes over [B, HW, C].  Every pass uses one
+// thread mapping: a block covers 64 channels x one chunk of 512 pixels of one sample; a thread owns a channel QUAD
+// (8-byte bf16 / 16-byte f32 accesses) and one of 16 row groups, so all per-channel parameters (mean, rstd, gamma,
+// beta, FiLM scale/shift, group sums) are loaded once per thread and the row loop is pure streaming.
+//   sums    per-(sample, channel) partial sums per chunk -> tiny group kernel folds chunks and channels in a fixed
+//           order (double accumulation for the variance)
+//   apply   y = act(GN(x)*gamma+beta [*(1+scale)+shift])    /    dx = rstd*(dn1*gamma - S1/N - xhat*S2/N) (+ dx_add)
 // ---------------------------------------------------------------------------------------------
-template <typename T, int NS>   // NS sums per channel
-struct ChanSums {
-    float v[NS];
+#define GN_ROWS 512
+
+struct GnQuad {   // per-thread constants for its 4 channels
+    f32x4 mu, rs, ga, be, sc, sh;
 };
+__device__ __forceinline__ GnQuad gn_quad(const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                          const float* scale, const float* shift, int64_t film_ld, int b, int c, int C, int G) {
+    GnQuad q;
+    const int cg = C / G;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int g = (c + j) / cg;
+        q.mu[j] = mean[b * G + g];
+        q.rs[j] = rstd[b * G + g];
+    }
+    q.ga = load4(gamma + c);
+    q.be = load4(beta + c);
+    q.sc = scale ? load4(scale + (int64_t)b * film_ld + c) : f32x4{0, 0, 0, 0};
+    q.sh = scale ? load4(shift + (int64_t)b * film_ld + c) : f32x4{0, 0, 0, 0};
+    return q;
+}
 
 template <typename T>
 __global__ void __launch_bounds__(256)
-gn_chan_stats_kernel(const T* __restrict__ x, int HW, int C, float* __restrict__ sum, float* __restrict__ sumsq) {
-    __shared__ float red[2][4][64];
-    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl, b = blockIdx.y;
-    float s = 0.f, q = 0.f;
+gn_fwd_sums_kernel(const T* __restrict__ x, int HW, int C, int B, int nchunk, float* __restrict__ part /* [2][nchunk][B][C] */) {
+    __shared__ __attribute__((aligned(16))) float red[2][16][64];
+    const int cq = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + cq * 4, b = blockIdx.y, chunk = blockIdx.z;
+    f32x4 s = {0, 0, 0, 0}, q = {0, 0, 0, 0};
     if (c < C) {
+        const int r0 = chunk * GN_ROWS, r1 = r0 + GN_ROWS < HW ? r0 + GN_ROWS : HW;
         const T* p = x + (int64_t)b * HW * C + c;
-        for (int r = rg; r < HW; r += 4) {
-            const float v = to_f32(p[(int64_t)r * C]);
+        for (int r = r0 + rg; r < r1; r += 16) {
+            const f32x4 v = load4(p + (int64_t)r * C);
             s += v;
             q += v * v;
         }
     }
-    red[0][rg][cl] = s;
-    red[1][rg][cl] = q;
+    store4(&red[0][rg][cq * 4], s);
+    store4(&red[1][rg][cq * 4], q);
     __syncthreads();
-    if (rg == 0 && c < C) {
-        sum[(int64_t)b * C + c] = ((red[0][0][cl] + red[0][1][cl]) + red[0][2][cl]) + red[0][3][cl];
-        sumsq[(int64_t)b * C + c] = ((red[1][0][cl] + red[1][1][cl]) + red[1][2][cl]) + red[1][3][cl];
+    const int cl = threadIdx.x & 63, k = threadIdx.x >> 6;
+    if (k < 2 && blockIdx.x * 64 + cl < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[k][g][cl];
+        part[(((int64_t)k * nchunk + chunk) * B + b) * C + blockIdx.x * 64 + cl] = t;
     }
 }
 
-__global__ void gn_group_stats_kernel(const float* __restrict__ sum, const float* __restrict__ sumsq, int B, int C, int G,
-                                      int HW, float eps, float* __restrict__ mean, float* __restrict__ rstd) {
+__global__ void gn_group_stats_kernel(const float* __restrict__ part, int nchunk, int B, int C, int G, int HW, float eps,
+                                      float* __restrict__ mean, float* __restrict__ rstd) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * G) return;
     const int b = i / G, g = i % G, cg = C / G;
     double s = 0.0, q = 0.0;
-    for (int j = 0; j < cg; ++j) {
-        s += (double)sum[(int64_t)b * C + g * cg + j];
-        q += (double)sumsq[(int64_t)b * C + g * cg + j];
-    }
+    for (int ch = 0; ch < nchunk; ++ch)
+        for (int j = 0; j < cg; ++j) {
+            s += (double)part[(((int64_t)0 * nchunk + ch) * B + b) * C + g * cg + j];
+            q += (double)part[(((int64_t)1 * nchunk + ch) * B + b) * C + g * cg + j];
+        }
     const double n = (double)cg * HW;
     const double m = s / n;
     double var = q / n - m * m;
@@ -66,79 +93,93 @@ __global__ void gn_group_stats_kernel(const float* __restrict__ sum, const float
     rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
-// y = act( GN(x)*gamma + beta [ *(1+scale[b,c]) + shift[b,c] ] ),  act = SiLU or identity
 template <typename T>
-__global__ void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
-                                const float* __restrict__ gamma, const float* __restrict__ beta,
-                                const float* __restrict__ scale, const float* __restrict__ shift, int64_t film_ld,
-                                int silu, T* __restrict__ y, int B, int HW, int C, int G) {
-    const int cg = C / G;
-    const int64_t total4 = (int64_t)B * HW * C / 4;
-    GRID_STRIDE(i, total4) {
-        const int64_t e = 4 * i;
-        const int c = (int)(e % C);
-        const int b = (int)(e / ((int64_t)HW * C));
-        f32x4 v = load4(x + e), r;
+__global__ void __launch_bounds__(256)
+gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ scale,
+                const float* __restrict__ shift, int64_t film_ld, int silu, T* __restrict__ y, int HW, int C, int G) {
+    const int cq = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + cq * 4, b = blockIdx.y, chunk = blockIdx.z;
+    if (c >= C) return;
+    const GnQuad k = gn_quad(mean, rstd, gamma, beta, scale, shift, film_ld, b, c, C, G);
+    const f32x4 a1 = k.rs * k.ga, b1 = k.be - k.mu * k.rs * k.ga;       // n1 = x*a1 + b1
+    const int r0 = chunk * GN_ROWS, r1 = r0 + GN_ROWS < HW ? r0 + GN_ROWS : HW;
+    const int64_t base = (int64_t)b * HW * C + c;
+    for (int r = r0 + rg; r < r1; r += 16) {
+        f32x4 n = load4(x + base + (int64_t)r * C) * a1 + b1;
+        if (scale) n = n * (1.f + k.sc) + k.sh;
+        if (silu) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int g = (c + j) / cg;
-            float n = (v[j] - mean[b * G + g]) * rstd[b * G + g] * gamma[c + j] + beta[c + j];
-            if (scale) n = n * (1.f + scale[(int64_t)b * film_ld + c + j]) + shift[(int64_t)b * film_ld + c + j];
-            r[j] = silu ? silu_f(n) : n;
+            for (int j = 0; j < 4; ++j) n[j] = silu_f(n[j]);
         }
-        store4(y + e, r);
+        store4(y + base + (int64_t)r * C, n);
     }
 }
 
-// Backward stage 1: per (sample, channel) sums over pixels of
-//   A = dn1*xhat, Bs = dn1, DS = dn2*n1, DH = dn2     (n1 = xhat*gamma+beta, n2 = FiLM(n1), dn2 = dout*act'(n2), dn1 = dn2*(1+scale))
+// Backward sums per (sample, channel): A = dn1*xhat, Bs = dn1, DS = dn2*n1, DH = dn2
+//   (n1 = xhat*gamma+beta, n2 = FiLM(n1), dn2 = dout*act'(n2), dn1 = dn2*(1+scale))
 template <typename T>
 __global__ void __launch_bounds__(256)
-gn_bwd_chan_kernel(const T* __restrict__ dout, const T* __restrict__ x, const float* __restrict__ mean,
+gn_bwd_sums_kernel(const T* __restrict__ dout, const T* __restrict__ x, const float* __restrict__ mean,
                    const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
-                   const float* __restrict__ scale, const float* __restrict__ shift, int64_t film_ld, int silu, int HW,
-                   int C, int G, float* __restrict__ A, float* __restrict__ Bs, float* __restrict__ DS,
-                   float* __restrict__ DH) {
-    __shared__ float red[4][4][64];
-    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl, b = blockIdx.y;
-    float a = 0.f, bs = 0.f, ds = 0.f, dh = 0.f;
+                   const float* __restrict__ scale, const float* __restrict__ shift, int64_t film_ld, int silu, int HW, int C,
+                   int G, int B, int nchunk, float* __restrict__ part /* [4][nchunk][B][C] */) {
+    __shared__ __attribute__((aligned(16))) float red[4][16][64];
+    const int cq = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + cq * 4, b = blockIdx.y, chunk = blockIdx.z;
+    f32x4 a = {0, 0, 0, 0}, bs = {0, 0, 0, 0}, ds = {0, 0, 0, 0}, dh = {0, 0, 0, 0};
     if (c < C) {
-        const int g = c / (C / G);
-        const float mu = mean[b * G + g], rs = rstd[b * G + g], ga = gamma[c], be = beta[c];
-        const float sc = scale ? scale[(int64_t)b * film_ld + c] : 0.f, sh = scale ? shift[(int64_t)b * film_ld + c] : 0.f;
+        const GnQuad k = gn_quad(mean, rstd, gamma, beta, scale, shift, film_ld, b, c, C, G);
+        const int r0 = chunk * GN_ROWS, r1 = r0 + GN_ROWS < HW ? r0 + GN_ROWS : HW;
         const int64_t base = (int64_t)b * HW * C + c;
-        for (int r = rg; r < HW; r += 4) {
-            const float xh = (to_f32(x[base + (int64_t)r * C]) - mu) * rs;
-            const float n1 = xh * ga + be;
-            const float n2 = scale ? n1 * (1.f + sc) + sh : n1;
-            const float dn2 = to_f32(dout[base + (int64_t)r * C]) * (silu ? silu_grad_f(n2) : 1.f);
-            const float dn1 = scale ? dn2 * (1.f + sc) : dn2;
+        for (int r = r0 + rg; r < r1; r += 16) {
+            const f32x4 xh = (load4(x + base + (int64_t)r * C) - k.mu) * k.rs;
+            const f32x4 n1 = xh * k.ga + k.be;
+            const f32x4 n2 = scale ? n1 * (1.f + k.sc) + k.sh : n1;
+            f32x4 dn2 = load4(dout + base + (int64_t)r * C);
+            if (silu) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dn2[j] *= silu_grad_f(n2[j]);
+            }
+            const f32x4 dn1 = scale ? dn2 * (1.f + k.sc) : dn2;
             a += dn1 * xh;
             bs += dn1;
             ds += dn2 * n1;
             dh += dn2;
         }
     }
-    red[0][rg][cl] = a; red[1][rg][cl] = bs; red[2][rg][cl] = ds; red[3][rg][cl] = dh;
+    store4(&red[0][rg][cq * 4], a);
+    store4(&red[1][rg][cq * 4], bs);
+    store4(&red[2][rg][cq * 4], ds);
+    store4(&red[3][rg][cq * 4], dh);
     __syncthreads();
-    if (rg == 0 && c < C) {
-        const int64_t o = (int64_t)b * C + c;
-        A[o] = ((red[0][0][cl] + red[0][1][cl]) + red[0][2][cl]) + red[0][3][cl];
-        Bs[o] = ((red[1][0][cl] + red[1][1][cl]) + red[1][2][cl]) + red[1][3][cl];
-        if (scale) {
-            DS[o] = ((red[2][0][cl] + red[2][1][cl]) + red[2][2][cl]) + red[2][3][cl];
-            DH[o] = ((red[3][0][cl] + red[3][1][cl]) + red[3][2][cl]) + red[3][3][cl];
-        }
+    const int cl = threadIdx.x & 63, kk = threadIdx.x >> 6;
+    if (blockIdx.x * 64 + cl < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[kk][g][cl];
+        part[(((int64_t)kk * nchunk + chunk) * B + b) * C + blockIdx.x * 64 + cl] = t;
     }
 }
 
-// Backward stage 2: per (b,g): S1 = sum_c gamma_c*Bs, S2 = sum_c gamma_c*A; per c: dgamma, dbeta over samples (fixed order)
-__global__ void gn_bwd_group_kernel(const float* __restrict__ A, const float* __restrict__ Bs, const float* __restrict__ gamma,
-                                    int B, int C, int G, float* __restrict__ S1, float* __restrict__ S2,
-                                    float* __restrict__ dgamma, float* __restrict__ dbeta, float gbeta) {
+// fold chunks -> per (b,c) sums; per (b,g): S1 = sum_c gamma_c*Bs, S2 = sum_c gamma_c*A; dgamma/dbeta over samples;
+// FiLM gradients into the rows of the emb_layers output gradient.  One thread per (b, c) for the folds (fixed order).
+__global__ void gn_bwd_fold_kernel(const float* __restrict__ part, int nchunk, int B, int C, float* __restrict__ sums /* [4][B][C] */) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)4 * B * C) return;
+    const int64_t k = i / ((int64_t)B * C), bc = i % ((int64_t)B * C);
+    float t = 0.f;
+    for (int ch = 0; ch < nchunk; ++ch) t += part[((k * nchunk + ch) * B) * C + bc];
+    sums[i] = t;
+}
+__global__ void gn_bwd_group_kernel(const float* __restrict__ sums, const float* __restrict__ gamma, int B, int C, int G,
+                                    float* __restrict__ S1, float* __restrict__ S2, float* __restrict__ dgamma,
+                                    float* __restrict__ dbeta, float gbeta, float* __restrict__ dscale,
+                                    float* __restrict__ dshift, int64_t dfilm_ld) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int cg = C / G;
+    const int64_t BC = (int64_t)B * C;
+    const float *A = sums, *Bs = sums + BC, *DS = sums + 2 * BC, *DH = sums + 3 * BC;
     if (i < B * G) {
         const int b = i / G, g = i % G;
         float s1 = 0.f, s2 = 0.f;
@@ -158,43 +199,50 @@ __global__ void gn_bwd_group_kernel(const float* __restrict__ A, const float* __
         }
         dgamma[i] = (gbeta != 0.f ? gbeta * dgamma[i] : 0.f) + dg;
         dbeta[i] = (gbeta != 0.f ? gbeta * dbeta[i] : 0.f) + db;
+        if (dscale)
+            for (int b = 0; b < B; ++b) {
+                dscale[(int64_t)b * dfilm_ld + i] = DS[(int64_t)b * C + i];
+                dshift[(int64_t)b * dfilm_ld + i] = DH[(int64_t)b * C + i];
+            }
     }
 }
 
-// Backward stage 3: dx = rstd * (dn1*gamma - S1/N - xhat*S2/N)  (+ dx_add if given)
 template <typename T>
-__global__ void gn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ x, const float* __restrict__ mean,
-                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                    const float* __restrict__ beta, const float* __restrict__ scale,
-                                    const float* __restrict__ shift, int64_t film_ld, int silu,
-                                    const float* __restrict__ S1, const float* __restrict__ S2, const T* __restrict__ dx_add,
-                                    T* __restrict__ dx, int B, int HW, int C, int G) {
+__global__ void __launch_bounds__(256)
+gn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ x, const float* __restrict__ mean,
+                    const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                    const float* __restrict__ scale, const float* __restrict__ shift, int64_t film_ld, int silu,
+                    const float* __restrict__ S1, const float* __restrict__ S2, const T* __restrict__ dx_add,
+                    T* __restrict__ dx, int HW, int C, int G) {
+    const int cq = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + cq * 4, b = blockIdx.y, chunk = blockIdx.z;
+    if (c >= C) return;
+    const GnQuad k = gn_quad(mean, rstd, gamma, beta, scale, shift, film_ld, b, c, C, G);
     const int cg = C / G;
     const float invn = 1.f / ((float)cg * HW);
-    const int64_t total4 = (int64_t)B * HW * C / 4;
-    GRID_STRIDE(i, total4) {
-        const int64_t e = 4 * i;
-        const int c = (int)(e % C);
-        const int b = (int)(e / ((int64_t)HW * C));
-        f32x4 xv = load4(x + e), dv = load4(dout + e), r;
-        f32x4 add = dx_add ? load4(dx_add + e) : f32x4{0, 0, 0, 0};
+    f32x4 t1, t2;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int g = (c + j) / cg;
-            const float rs = rstd[b * G + g];
-            const float xh = (xv[j] - mean[b * G + g]) * rs;
-            const float n1 = xh * gamma[c + j] + beta[c + j];
-            float sc = 0.f;
-            float n2 = n1;
-            if (scale) {
-                sc = scale[(int64_t)b * film_ld + c + j];
-                n2 = n1 * (1.f + sc) + shift[(int64_t)b * film_ld + c + j];
-            }
-            const float dn2 = dv[j] * (silu ? silu_grad_f(n2) : 1.f);
-            const float dn1 = scale ? dn2 * (1.f + sc) : dn2;
-            r[j] = rs * (dn1 * gamma[c + j] - S1[b * G + g] * invn - xh * S2[b * G + g] * invn) + add[j];
+    for (int j = 0; j < 4; ++j) {
+        const int g = (c + j) / cg;
+        t1[j] = S1[b * G + g] * invn;
+        t2[j] = S2[b * G + g] * invn;
+    }
+    const int r0 = chunk * GN_ROWS, r1 = r0 + GN_ROWS < HW ? r0 + GN_ROWS : HW;
+    const int64_t base = (int64_t)b * HW * C + c;
+    for (int r = r0 + rg; r < r1; r += 16) {
+        const int64_t e = base + (int64_t)r * C;
+        const f32x4 xh = (load4(x + e) - k.mu) * k.rs;
+        const f32x4 n1 = xh * k.ga + k.be;
+        const f32x4 n2 = scale ? n1 * (1.f + k.sc) + k.sh : n1;
+        f32x4 dn2 = load4(dout + e);
+        if (silu) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dn2[j] *= silu_grad_f(n2[j]);
         }
-        store4(dx + e, r);
+        const f32x4 dn1 = scale ? dn2 * (1.f + k.sc) : dn2;
+        f32x4 r4 = k.rs * (dn1 * k.ga - t1 - xh * t2);
+        if (dx_add) r4 += load4(dx_add + e);
+        store4(dx + e, r4);
     }
 }
 
@@ -418,21 +466,24 @@ __global__ void layout_kernel(const float* __restrict__ nchw_in, float* __restri
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
-extern "C" int64_t vaw_groupnorm_workspace_floats(int B, int C) { return 6 * (int64_t)B * C + 64; }
+static inline int gn_chunks(int HW) { return (HW + GN_ROWS - 1) / GN_ROWS; }
+extern "C" int64_t vaw_groupnorm_workspace_floats(int B, int HW, int C) {
+    return (int64_t)4 * gn_chunks(HW) * B * C + (int64_t)4 * B * C + 2 * (int64_t)B * 64 + 64;
+}
 
 extern "C" int vaw_groupnorm_fwd(vaw_dtype dt, const void* x, const float* gamma, const float* beta, const float* scale,
                                  const float* shift, int64_t film_ld, int silu, void* y, float* mean, float* rstd, int B,
                                  int HW, int C, int G, float eps, float* workspace, vaw_stream stream) {
-    VAW_CHECK_ARG(B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0 && C % 4 == 0 && workspace, "groupnorm_fwd: bad sizes (C=%d G=%d)", C, G);
+    VAW_CHECK_ARG(B > 0 && HW > 0 && C > 0 && G > 0 && G <= 64 && C % G == 0 && C % 4 == 0 && workspace && B < 65536,
+                  "groupnorm_fwd: bad sizes (C=%d G=%d)", C, G);
     VAW_CHECK_ARG((scale == nullptr) == (shift == nullptr), "groupnorm_fwd: scale and shift go together");
+    VAW_CHECK_ARG(!scale || film_ld % 4 == 0, "groupnorm_fwd: film_ld must be a multiple of 4");
     hipStream_t s = (hipStream_t)stream;
-    float* sum = workspace;
-    float* sq = workspace + (int64_t)B * C;
-    dim3 g1(ceil_div(C, 64), B);
-    BY_DTYPE(dt, (gn_chan_stats_kernel<T><<<g1, 256, 0, s>>>((const T*)x, HW, C, sum, sq)));
-    gn_group_stats_kernel<<<ceil_div(B * G, 128), 128, 0, s>>>(sum, sq, B, C, G, HW, eps, mean, rstd);
-    const int64_t n4 = (int64_t)B * HW * C / 4;
-    BY_DTYPE(dt, (gn_apply_kernel<T><<<sgrid(n4, 256), 256, 0, s>>>((const T*)x, mean, rstd, gamma, beta, scale, shift, film_ld, silu, (T*)y, B, HW, C, G)));
+    const int nch = gn_chunks(HW);
+    dim3 grid(ceil_div(C, 64), B, nch);
+    BY_DTYPE(dt, (gn_fwd_sums_kernel<T><<<grid, 256, 0, s>>>((const T*)x, HW, C, B, nch, workspace)));
+    gn_group_stats_kernel<<<ceil_div(B * G, 128), 128, 0, s>>>(workspace, nch, B, C, G, HW, eps, mean, rstd);
+    BY_DTYPE(dt, (gn_apply_kernel<T><<<grid, 256, 0, s>>>((const T*)x, mean, rstd, gamma, beta, scale, shift, film_ld, silu, (T*)y, HW, C, G)));
     VAW_CHECK_LAUNCH("groupnorm_fwd");
     return VAW_OK;
 }
@@ -442,24 +493,23 @@ extern "C" int vaw_groupnorm_bwd(vaw_dtype dt, const void* dout, const void* x, 
                                  int64_t film_ld, int silu, const void* dx_add, void* dx, float* dgamma, float* dbeta,
                                  float grad_beta, float* dscale, float* dshift, int64_t dfilm_ld, int B, int HW, int C, int G,
                                  float* workspace, vaw_stream stream) {
-    VAW_CHECK_ARG(B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0 && C % 4 == 0 && workspace, "groupnorm_bwd: bad sizes");
-    VAW_CHECK_ARG(!scale || (shift && dscale && dshift), "groupnorm_bwd: FiLM needs shift, dscale, dshift");
+    VAW_CHECK_ARG(B > 0 && HW > 0 && C > 0 && G > 0 && G <= 64 && C % G == 0 && C % 4 == 0 && workspace && B < 65536,
+                  "groupnorm_bwd: bad sizes");
+    VAW_CHECK_ARG(!scale || (shift && dscale && dshift && film_ld % 4 == 0), "groupnorm_bwd: FiLM needs shift, dscale, dshift");
     hipStream_t s = (hipStream_t)stream;
+    const int nch = gn_chunks(HW);
     const int64_t BC = (int64_t)B * C;
-    float *A = workspace, *Bs = A + BC, *DS = Bs + BC, *DH = DS + BC, *S1 = DH + BC, *S2 = S1 + (int64_t)B * G;
-    dim3 g1(ceil_div(C, 64), B);
-    BY_DTYPE(dt, (gn_bwd_chan_kernel<T><<<g1, 256, 0, s>>>((const T*)dout, (const T*)x, mean, rstd, gamma, beta, scale, shift, film_ld, silu, HW, C, G, A, Bs, DS, DH)));
+    float* part = workspace;
+    float* sums = part + 4 * nch * BC;
+    float* S1 = sums + 4 * BC;
+    float* S2 = S1 + (int64_t)B * G;
+    dim3 grid(ceil_div(C, 64), B, nch);
+    BY_DTYPE(dt, (gn_bwd_sums_kernel<T><<<grid, 256, 0, s>>>((const T*)dout, (const T*)x, mean, rstd, gamma, beta, scale, shift, film_ld, silu, HW, C, G, B, nch, part)));
+    gn_bwd_fold_kernel<<<ceil_div(4 * BC, 256), 256, 0, s>>>(part, nch, B, C, sums);
     const int n2 = B * G > C ? B * G : C;
-    gn_bwd_group_kernel<<<ceil_div(n2, 128), 128, 0, s>>>(A, Bs, gamma, B, C, G, S1, S2, dgamma, dbeta, grad_beta);
-    if (scale) {   // dscale[b,c] = DS, dshift[b,c] = DH into rows of stride dfilm_ld
-        if (hipMemcpy2DAsync(dscale, dfilm_ld * sizeof(float), DS, C * sizeof(float), C * sizeof(float), B, hipMemcpyDeviceToDevice, s) != hipSuccess ||
-            hipMemcpy2DAsync(dshift, dfilm_ld * sizeof(float), DH, C * sizeof(float), C * sizeof(float), B, hipMemcpyDeviceToDevice, s) != hipSuccess) {
-            vaw_set_error("groupnorm_bwd: copy failed");
-            return VAW_ERR_LAUNCH;
-        }
-    }
-    const int64_t n4 = (int64_t)B * HW * C / 4;
-    BY_DTYPE(dt, (gn_bwd_apply_kernel<T><<<sgrid(n4, 256), 256, 0, s>>>((const T*)dout, (const T*)x, mean, rstd, gamma, beta, scale, shift, film_ld, silu, S1, S2, (const T*)dx_add, (T*)dx, B, HW, C, G)));
+    gn_bwd_group_kernel<<<ceil_div(n2, 128), 128, 0, s>>>(sums, gamma, B, C, G, S1, S2, dgamma, dbeta, grad_beta,
+                                                           scale ? dscale : nullptr, dshift, dfilm_ld);
+    BY_DTYPE(dt, (gn_bwd_apply_kernel<T><<<grid, 256, 0, s>>>((const T*)dout, (const T*)x, mean, rstd, gamma, beta, scale, shift, film_ld, silu, S1, S2, (const T*)dx_add, (T*)dx, HW, C, G)));
     VAW_CHECK_LAUNCH("groupnorm_bwd");
     return VAW_OK;
 }

@@ -253,7 +253,7 @@ class UNetModel(FlatModule):
         gam, bet = self._p32(name + ".weight"), self._p32(name + ".bias")
         sc = film
         sh = film + 4 * C if film else 0
-        ws = ops.scratch_f32(self._flat.device, lib.vaw_groupnorm_workspace_floats(B, C))
+        ws = ops.scratch_f32(self._flat.device, lib.vaw_groupnorm_workspace_floats(B, HW, C))
         L.check(lib.vaw_groupnorm_fwd(dt, ptr(a.t), gam, bet, sc or None, sh or None, self.emb_cols, 1 if silu else 0,
                                       ptr(y.t), ptr(mean), ptr(rstd), B, HW, C, 32, 1e-5, ptr(ws), L.stream_ptr()), "groupnorm_fwd")
 
@@ -264,7 +264,7 @@ class UNetModel(FlatModule):
                                           self.emb_cols, 1 if silu else 0, ptr(a.grad) if a.grad is not None else None,
                                           ptr(dx), self._g(name + ".weight"), self._g(name + ".bias"), self._beta,
                                           dsc or None, (dsc + 4 * C) if dsc else None, self.emb_cols, B, HW, C, 32,
-                                          ptr(ops.scratch_f32(self._flat.device, lib.vaw_groupnorm_workspace_floats(B, C))),
+                                          ptr(ops.scratch_f32(self._flat.device, lib.vaw_groupnorm_workspace_floats(B, HW, C))),
                                           L.stream_ptr()), "groupnorm_bwd")
             a.grad = dx
             y.grad = None
