@@ -114,20 +114,24 @@ def _mk(M, N, K, a_k, b_k, dtype, seed, ints=False):
 
 
 @pytest.mark.parametrize("a_k,b_k", [(True, True), (True, False), (False, False), (False, True)])
-@pytest.mark.parametrize("mode", ["f32", "bf16_generic", "bf16_fast"])
+@pytest.mark.parametrize("mode", ["f32", "bf16_generic", "bf16_fast", "bf16_big"])
 def test_gemm_layouts_exact_integers(a_k, b_k, mode):
     """Small-integer operands are exact in bf16 and f32: any fragment-layout or swizzle error shows as a
     wrong integer, with asymmetric data on both sides (a symmetric operand would hide a transpose)."""
     dtype = torch.float32 if mode == "f32" else torch.bfloat16
     # the MFMA path predicates edge tiles: any M (multiple of 8 when A is mn-major), N % 8 == 0, K % 64 == 0
     shapes = ([(256, 384, 192), (200, 72, 128), (136, 200, 64), (192, 1728, 256), (64, 64, 64)] if mode == "bf16_fast"
-              else [(256, 384, 192), (70, 45, 23), (129, 1, 17), (5, 200, 64)])
+              else [(256, 384, 192), (200, 72, 128), (136, 200, 64), (520, 264, 256), (304, 776, 320), (1024, 512, 2048)]
+              if mode == "bf16_big" else [(256, 384, 192), (70, 45, 23), (129, 1, 17), (5, 200, 64)])
+    if mode.startswith("bf16_"):
+        dtype = torch.bfloat16
     lib().vaw_debug_force_generic_gemm(1 if mode == "bf16_generic" else 0)
+    lib().vaw_debug_gemm_tile({"bf16_fast": 0, "bf16_big": 1}.get(mode, -1))
     try:
         for (M, N, K) in shapes:
             A, B = _mk(M, N, K, a_k, b_k, dtype, seed=M + N + K, ints=True)
             Ad, Bd = A.to(DEV), B.to(DEV)
-            if mode == "bf16_fast":
+            if mode in ("bf16_fast", "bf16_big"):
                 assert lib().vaw_gemm_uses_bf16_mfma(BF16, M, N, K, ptr(Ad), Ad.shape[1], ptr(Bd), Bd.shape[1]) == 1
             got = ops.gemm_t(Ad, Bd, a_kmajor=a_k, b_kmajor=b_k, out_dtype=torch.float32).cpu()
             ref = _gemm_ref(A, B, a_k, b_k)
@@ -139,19 +143,33 @@ def test_gemm_layouts_exact_integers(a_k, b_k, mode):
             torch.testing.assert_close(cs.cpu().double(), ref.to(dtype).double().sum(0), rtol=1e-6, atol=1e-3)
     finally:
         lib().vaw_debug_force_generic_gemm(0)
+        lib().vaw_debug_gemm_tile(-1)
 
 
+@pytest.mark.parametrize("tile", [0, 1])
 @pytest.mark.parametrize("a_k,b_k", [(True, True), (True, False), (False, False)])
-def test_gemm_bf16_fast_random_and_large_k(a_k, b_k):
-    for (M, N, K) in [(128, 128, 64), (512, 256, 768), (256, 128, 3072)]:
-        A, B = _mk(M, N, K, a_k, b_k, torch.bfloat16, seed=K)
-        got = ops.gemm_t(A.to(DEV), B.to(DEV), a_kmajor=a_k, b_kmajor=b_k, out_dtype=torch.float32).cpu()
-        ref = _gemm_ref(A, B, a_k, b_k)
-        torch.testing.assert_close(got.double(), ref, rtol=1e-4, atol=1e-3 * math.sqrt(K) * 0.05)
+def test_gemm_bf16_fast_random_and_large_k(a_k, b_k, tile):
+    lib().vaw_debug_gemm_tile(tile)
+    try:
+        for (M, N, K) in [(128, 128, 64), (512, 256, 768), (256, 128, 3072), (768, 768, 16384)]:
+            A, B = _mk(M, N, K, a_k, b_k, torch.bfloat16, seed=K)
+            got = ops.gemm_t(A.to(DEV), B.to(DEV), a_kmajor=a_k, b_kmajor=b_k, out_dtype=torch.float32).cpu()
+            ref = _gemm_ref(A, B, a_k, b_k)
+            torch.testing.assert_close(got.double(), ref, rtol=1e-4, atol=1e-3 * math.sqrt(K) * 0.05)
+    finally:
+        lib().vaw_debug_gemm_tile(-1)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_gemm_epilogues(dtype):
+@pytest.mark.parametrize("dtype,tile", [(torch.float32, -1), (torch.bfloat16, 0), (torch.bfloat16, 1)])
+def test_gemm_epilogues(dtype, tile):
+    lib().vaw_debug_gemm_tile(tile)
+    try:
+        _gemm_epilogues(dtype)
+    finally:
+        lib().vaw_debug_gemm_tile(-1)
+
+
+def _gemm_epilogues(dtype):
     tol = dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
     Bt, T, N, K = 4, 32, 256, 128
     M = Bt * T

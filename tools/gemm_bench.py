@@ -23,6 +23,10 @@ DIT_B4 = [  # (name, layout, M, N, K, epilogue)
     ("qkv wgrad", "wgrad", 2304, 768, M, "f32"), ("proj wgrad", "wgrad", 768, 768, M, "f32"),
     ("fc1 wgrad", "wgrad", 3072, 768, M, "f32"), ("fc2 wgrad", "wgrad", 768, 3072, M, "f32"),
 ]
+UNET64 = [  # a few conv-as-GEMM shapes of UNet_64 at batch 128 (M = B*H*W pixels, K = 9*Ci)
+    ("c192@64 fwd", "fwd", 128 * 64 * 64, 192, 9 * 192, "bias"), ("c384@32 fwd", "fwd", 128 * 32 * 32, 384, 9 * 384, "bias"),
+    ("c576@16 fwd", "fwd", 128 * 16 * 16, 576, 9 * 576, "bias"), ("c768@8 fwd", "fwd", 128 * 8 * 8, 768, 9 * 768, "bias"),
+]
 SQUARE = [("4096^3 fwd", "fwd", 4096, 4096, 4096, "none"), ("4096^3 dgrad", "dgrad", 4096, 4096, 4096, "none"),
           ("4096^3 wgrad", "wgrad", 4096, 4096, 4096, "f32"), ("8192^3 fwd", "fwd", 8192, 8192, 8192, "none")]
 
@@ -66,7 +70,14 @@ if __name__ == "__main__":
     ap.add_argument("--shapes", default="dit_b4")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default=None, help="substring of the shape name")
+    ap.add_argument("--tile", default="auto", help="auto | 128 | 256 | both: bf16 MFMA block tile")
     a = ap.parse_args()
-    for row in {"dit_b4": DIT_B4, "square": SQUARE, "all": DIT_B4 + SQUARE}[a.shapes]:
+    from vaw_amd._lib import lib
+    tiles = {"auto": [-1], "128": [0], "256": [1], "both": [0, 1]}[a.tile]
+    for row in {"dit_b4": DIT_B4, "square": SQUARE, "unet64": UNET64, "all": DIT_B4 + SQUARE}[a.shapes]:
         if a.only is None or a.only in row[0]:
-            run(*row, a.iters)
+            for t in tiles:
+                lib().vaw_debug_gemm_tile(t)
+                if len(tiles) > 1:
+                    print(f"[tile {('128', '256')[t]}] ", end="")
+                run(*row, a.iters)

@@ -99,6 +99,8 @@ def lib():
         L.vaw_debug_force_rowwise_attention.restype = None
         L.vaw_debug_force_generic_gemm.argtypes = [_i]
         L.vaw_debug_force_generic_gemm.restype = None
+        L.vaw_debug_gemm_tile.argtypes = [_i]
+        L.vaw_debug_gemm_tile.restype = None
         _lib = L
     return _lib
 

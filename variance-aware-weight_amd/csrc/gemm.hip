@@ -345,18 +345,21 @@ gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __rest
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA for tile kt has landed
         __syncthreads();                                    // everyone's has; and tile kt-1 is no longer read
         char* cur = smem + (kt & 1) * Cfg::stage_bytes;
-        if (kt + 1 < nk) {
+        if (kt + 1 < nk && e.debug < 4) {
             char* nxt = smem + ((kt + 1) & 1) * Cfg::stage_bytes;
             stage_a(kt0 + kt + 1, nxt);
             stage_b(kt0 + kt + 1, nxt + Cfg::tile_bytes);
         }
+        bf16x8 af[4], bfr[4];
 #pragma unroll
         for (int s = 0; s < BKT / 32; ++s) {
-            bf16x8 af[4], bfr[4];
+            // timing-only ablations: 3 = half the LDS reads, 4 = no global->LDS staging, 5 = neither staging nor LDS reads
+            if (!((e.debug == 3 && s == 1) || (e.debug == 5 && (kt > 0 || s == 1)))) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = load_frag<AK, BKT>(cur, wm + 16 * i, s, lane);
+                for (int i = 0; i < 4; ++i) af[i] = load_frag<AK, BKT>(cur, wm + 16 * i, s, lane);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[j] = load_frag<BKM, BKT>(cur + Cfg::tile_bytes, wn + 16 * j, s, lane);
+                for (int j = 0; j < 4; ++j) bfr[j] = load_frag<BKM, BKT>(cur + Cfg::tile_bytes, wn + 16 * j, s, lane);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -364,7 +367,7 @@ gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __rest
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
     }
-    if (e.debug == 1) {   // keep the accumulators alive with one store per wave-quadrant
+    if (e.debug == 1 || e.debug >= 3) {   // keep the accumulators alive with one store per wave-quadrant
         float t = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -437,6 +440,172 @@ gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __rest
         if (threadIdx.x < nvalid)
             e.colpart[(int64_t)tm * e.N + n0 + threadIdx.x] =
                 ((cp[threadIdx.x] + cp[128 + threadIdx.x]) + cp[256 + threadIdx.x]) + cp[384 + threadIdx.x];
+    }
+}
+
+// =============================================================================================
+// Large-tile variant: 256 x 256 block tile, 8 waves (2 x 4, each 128 x 64 = 8 x 4 MFMA tiles), ONE workgroup per
+// CU, K in 32-deep tiles through a ring of FOUR 32 KiB LDS stages filled by LDS-DMA.
+// Why: the ablations in DESIGN.md ("GEMM main loop") show the 128 x 128 kernel is bound by the vector-memory ->
+// LDS path (64 B/clk/CU) and by LDS bandwidth, not by MFMA issue: per MFMA cycle it moves 2x the global bytes
+// and 1.33x the LDS fragment bytes of this shape.  The loads of K tile t+3 are issued before the MFMAs of tile t and
+// only waited for with a COUNTED s_waitcnt vmcnt(8) (4 LDS-DMA instructions per wave per tile, two tiles may stay
+// in flight) followed by a raw s_barrier (__syncthreads() would drain vmcnt to 0; cdna_hip_programming.md
+// "Pipelining across barriers").
+// Each operand tile is two 128-wide images of the kinds above (same swizzles, same fragment loads).
+// =============================================================================================
+#define BIG_BM 256
+#define BIG_BN 256
+#define BIG_IMG (128 * 32 * 2)                  // one 128 x 32 image: 8 KiB
+#define BIG_STAGE (4 * BIG_IMG)                 // A img0 | A img1 | B img0 | B img1 = 32 KiB
+#define BIG_NSTAGE 4
+#define BIG_CS_LD 260                           // f32 row stride of the epilogue staging image (256 + 4)
+#define BIG_LDS (BIG_NSTAGE * BIG_STAGE + 8 * 256 * 4)   // ring (also the 64 x 260 f32 epilogue image) + column sums
+
+template <bool AK, bool BKM>
+__global__ void __launch_bounds__(512, 1)
+gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb, int nk_total,
+                     int tiles_n, int n_wg, int n_split, EpiDev e) {
+    constexpr int BKT = 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // 0..7
+    int wg;
+    {
+        const int orig = blockIdx.x, xcd = orig & 7, q = n_wg >> 3, r = n_wg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    int tm, tn;
+    {
+        const int tiles_m = n_wg / tiles_n, per_group = 4 * tiles_n;      // 4 row panels of 256 per group
+        const int group = wg / per_group, first_m = group * 4;
+        const int gsize = tiles_m - first_m < 4 ? tiles_m - first_m : 4;
+        const int in_group = wg - group * per_group;
+        tm = first_m + in_group % gsize;
+        tn = in_group / gsize;
+    }
+    const int64_t m0 = (int64_t)tm * BIG_BM, n0 = (int64_t)tn * BIG_BN;
+    const int nk_per = (nk_total + n_split - 1) / n_split;                // nk_total counts 32-deep tiles
+    const int kt0 = blockIdx.y * nk_per;
+    const int nk = kt0 + nk_per <= nk_total ? nk_per : nk_total - kt0;
+    const int mvalid = e.M - m0 < BIG_BM ? (int)(e.M - m0) : BIG_BM;
+    const int nvalid = e.N - n0 < BIG_BN ? (int)(e.N - n0) : BIG_BN;
+    const int wy = wid >> 2, wx = wid & 3;                                // wave tile: rows 128*wy.., cols 64*wx..
+
+    // ---- staging: wave w fills (2 pieces each) image w>>2 of A and image w>>2 of B as sub-wave w&3 ----
+    const int img = wid >> 2, sw = wid & 3;
+    int a_valid = mvalid - 128 * img, b_valid = nvalid - 128 * img;
+    const int a_img = a_valid > 0 ? img : 0, b_img = b_valid > 0 ? img : 0;   // image wholly outside: mirror image 0
+    a_valid = a_valid > 0 ? (a_valid < 128 ? a_valid : 128) : (mvalid < 128 ? mvalid : 128);
+    b_valid = b_valid > 0 ? (b_valid < 128 ? b_valid : 128) : (nvalid < 128 ? nvalid : 128);
+    const bf16_t* a_base = AK ? A + (m0 + 128 * a_img) * lda : A + m0 + 128 * a_img;
+    const bf16_t* b_base = BKM ? B + (n0 + 128 * b_img) * ldb : B + n0 + 128 * b_img;
+    const int64_t a_step = AK ? BKT : (int64_t)BKT * lda;
+    const int64_t b_step = BKM ? BKT : (int64_t)BKT * ldb;
+    auto stage = [&](int ktile, char* dst) {
+        stage_tile<AK, BKT>(a_base + ktile * a_step, lda, dst + img * BIG_IMG, sw, lane, a_valid);
+        stage_tile<BKM, BKT>(b_base + ktile * b_step, ldb, dst + (2 + img) * BIG_IMG, sw, lane, b_valid);
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+
+    stage(kt0, smem);
+    if (nk > 1) stage(kt0 + 1, smem + BIG_STAGE);
+    if (nk > 2) stage(kt0 + 2, smem + 2 * BIG_STAGE);
+    const int a_off = wy * BIG_IMG, b_off = (2 + (wx >> 1)) * BIG_IMG, b_row0 = (wx & 1) * 64;
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt landed; tiles kt+1, kt+2 may still fly (4 LDS-DMA instructions per wave per tile)
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // every wave's pieces of tile kt are in; nobody still reads tile kt-1
+        if (kt + 3 < nk) stage(kt0 + kt + 3, smem + ((kt + 3) & 3) * BIG_STAGE);   // slot of tile kt-1
+        const char* cur = smem + (kt & 3) * BIG_STAGE;
+        bf16x8 af[8], bfr[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = load_frag<BKM, BKT>(cur + b_off, b_row0 + 16 * j, 0, lane);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) af[i] = load_frag<AK, BKT>(cur + a_off, 16 * i, 0, lane);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (e.debug == 1) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (t == 12345.678f) ((float*)e.C)[0] = t;
+        return;
+    }
+    // ---- epilogue: four 64-row quarters through the (now idle) ring; a thread owns 8 consecutive columns ----
+    float* cs = reinterpret_cast<float*>(smem);
+    const int c8 = (threadIdx.x & 31) * 8, r0 = threadIdx.x >> 5;       // 16 row-threads x 32 column groups
+    const bool col_ok = c8 < nvalid;
+    f32x4 b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
+    if (e.bias && n_split == 1 && col_ok) {
+        b0 = load4(e.bias + n0 + c8);
+        b1 = load4(e.bias + n0 + c8 + 4);
+    }
+    f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
+#pragma unroll
+    for (int quarter = 0; quarter < 4; ++quarter) {
+        __syncthreads();
+        if (wy == (quarter >> 1)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        cs[(16 * i + 4 * (lane >> 4) + r) * BIG_CS_LD + 64 * wx + 16 * j + (lane & 15)] =
+                            acc[4 * (quarter & 1) + i][j][r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int row = pass * 16 + r0;
+            if (!col_ok || 64 * quarter + row >= mvalid) continue;
+            const float* src = cs + row * BIG_CS_LD + c8;
+            const int64_t m = m0 + 64 * quarter + row;
+            if (n_split > 1) {
+                float* dst = e.slab + (int64_t)blockIdx.y * e.M * e.N + m * e.N + n0 + c8;
+                store4(dst, load4(src));
+                store4(dst + 4, load4(src + 4));
+            } else {
+                f32x4 v0 = load4(src), v1 = load4(src + 4);
+                epi_row8(e, (unsigned)m, n0 + c8, v0, v1, b0, b1);
+                s0 += v0;
+                s1 += v1;
+            }
+        }
+    }
+    if (e.colpart && n_split == 1) {
+        // 16 row-threads per column group: 2 in-wave (lane bit 5), then the 8 waves through LDS, fixed order
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s0[j] += __shfl_xor(s0[j], 32, 64);
+            s1[j] += __shfl_xor(s1[j], 32, 64);
+        }
+        float* cp = reinterpret_cast<float*>(smem + BIG_NSTAGE * BIG_STAGE);   // [8 waves][256]
+        if (lane < 32) {
+            store4(cp + wid * 256 + c8, s0);
+            store4(cp + wid * 256 + c8 + 4, s1);
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < nvalid && threadIdx.x < 256) {
+            float t = 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) t += cp[w8 * 256 + threadIdx.x];
+            e.colpart[(int64_t)tm * e.N + n0 + threadIdx.x] = t;
+        }
     }
 }
 
@@ -542,8 +711,19 @@ gemm_generic_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ 
             epi_store4<T>(e, m0 + wm + 16 * i + 4 * (lane >> 4), n0 + wn + 16 * j + (lane & 15), acc[i][j]);
 }
 
+// Shapes where the 256 x 256 kernel is the faster one (tools/gemm_bench.py --tile both: +4..16 % on 4096^3 / 8192^3,
+// slower whenever its grid leaves CUs idle or K is short): whole rounds of 256 workgroups, long K, no edge tiles.
+static bool big_tile_pays(int64_t M, int64_t N, int64_t K, int64_t n_wg_big) {
+    if (M % 256 || N % 256 || K < 2048 || n_wg_big < 256) return false;
+    const int64_t rounds = (n_wg_big + 255) / 256;
+    return rounds * 256 * 100 <= n_wg_big * 110;      // at most 10 % of the last round idle
+}
+
 static int g_force_generic = 0;
 extern "C" void vaw_debug_force_generic_gemm(int on) { g_force_generic = on; }
+// bf16 MFMA tile choice: -1 = by shape (default), 0 = always 128 x 128, 1 = always 256 x 256.  Env VAW_GEMM_BIG seeds it.
+static int g_gemm_tile = -2;
+extern "C" void vaw_debug_gemm_tile(int mode) { g_gemm_tile = mode; }
 
 static bool takes_fast_path(vaw_dtype dt, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
                             int64_t ldb) {
@@ -645,6 +825,38 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
         else if (!a_kmajor && b_kmajor) LAUNCH_FAST(false, true, BKTv); \
         else LAUNCH_FAST(false, false, BKTv);                        \
     } while (0)
+        if (g_gemm_tile == -2) { const char* v = getenv("VAW_GEMM_BIG"); g_gemm_tile = v ? atoi(v) : -1; }
+        const int64_t tiles_nb = (N + BIG_BN - 1) / BIG_BN, n_wgb = ((M + BIG_BM - 1) / BIG_BM) * tiles_nb;
+        const bool use_big = bk_env == 0 && (g_gemm_tile == 1 || (g_gemm_tile == -1 && big_tile_pays(M, N, K, n_wgb)));
+        if (use_big) {
+            const int nkb = (int)(K / 32);
+            int splitb = colsum_out ? 1 : pick_split(n_wgb * 2, K, M * N, workspace_floats, plain_f32);
+            if (splitb > 1) {
+                const int per = (nkb + splitb - 1) / splitb;
+                splitb = (nkb + per - 1) / per;
+            }
+            dim3 gridb((unsigned)n_wgb, (unsigned)splitb);
+#define LAUNCH_BIG(AKv, BKv)                                                                                             \
+    do {                                                                                                                 \
+        static bool attr_done = false;                                                                                   \
+        if (!attr_done) {                                                                                                \
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_big_kernel<AKv, BKv>,                                       \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS);                              \
+            attr_done = true;                                                                                            \
+        }                                                                                                                \
+        gemm_bf16_big_kernel<AKv, BKv><<<gridb, 512, BIG_LDS, s>>>(a, lda, b, ldb, nkb, (int)tiles_nb, (int)n_wgb, splitb, e); \
+    } while (0)
+            if (a_kmajor && b_kmajor) LAUNCH_BIG(true, true);
+            else if (a_kmajor && !b_kmajor) LAUNCH_BIG(true, false);
+            else if (!a_kmajor && b_kmajor) LAUNCH_BIG(false, true);
+            else LAUNCH_BIG(false, false);
+            if (splitb > 1)
+                splitk_reduce_kernel<float><<<ceil_div(M * N / 4, 256) > 2048 ? 2048 : ceil_div(M * N / 4, 256), 256, 0, s>>>(
+                    workspace, splitb, M, N, ldc, C, e.alpha, e.beta, 1);
+            VAW_CHECK_LAUNCH("gemm_bf16_big");
+            if (colsum_out) return vaw_reduce_rows(workspace, (M + BIG_BM - 1) / BIG_BM, N, colsum_out, colsum_beta, stream);
+            return VAW_OK;
+        }
         if (bkt == 32) LAUNCH_FAST_BK(32);
         else LAUNCH_FAST_BK(64);
         if (split > 1)
