@@ -279,36 +279,54 @@ gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __rest
             int row = (wid * PW + i) * (64 / CPR) + lane / CPR;
             row = row < mvalid ? row : mvalid - 1;
             const int64_t p = m0 + row;
-            ga_pix[i] = p;
+            ga_pix[i] = p * (CONV == 1 ? cg.Ci : cg.Co) + (((lane % CPR) ^ kmaj_swz<BKT>((wid * PW + i) * (64 / CPR) + lane / CPR)) << 3);
             ga_w[i] = (int)(p % cg.W);
             ga_h[i] = (int)((p / cg.W) % cg.H);
         }
     }
-    int gb_tap[PW], gb_ci[PW];
+    // CONV 3: the pixel (h, w) and source offset of the row each lane stages are carried from K tile to K tile
+    // (64 pixels further on each time) instead of being divided out of the pixel index at every step.
+    int gb_dh[PW], gb_dw[PW], gb_h[PW], gb_w[PW];
+    int64_t gb_off[PW];
+    const int step_w = CONV == 3 ? BKT % cg.W : 0, step_h = CONV == 3 ? (BKT / cg.W) % cg.H : 0;
     if (CONV == 3) {
+        const int nk_per0 = (nk_total + n_split - 1) / n_split;
 #pragma unroll
         for (int i = 0; i < PW; ++i) {
             const int row = (wid * PW + i) * 4 + (lane >> 4);
             const int chunk = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
             const int n = (int)n0 + chunk * 8;
-            gb_tap[i] = n < e.N ? n / cg.Ci : -1;     // -1: column beyond 9*Ci (edge tile) -> zero page
-            gb_ci[i] = n % cg.Ci;
+            const int tap = n < e.N ? n / cg.Ci : -1;     // -1: column beyond 9*Ci (edge tile) -> zero page
+            gb_dh[i] = tap >= 0 ? tap / 3 - 1 : (1 << 20);
+            gb_dw[i] = tap >= 0 ? tap % 3 - 1 : 0;
+            const int64_t p = (int64_t)blockIdx.y * nk_per0 * BKT + row;
+            gb_w[i] = (int)(p % cg.W);
+            gb_h[i] = (int)((p / cg.W) % cg.H);
+            gb_off[i] = tap >= 0 ? (p + (int64_t)gb_dh[i] * cg.W + gb_dw[i]) * cg.Ci + n % cg.Ci : 0;
         }
     }
-    auto stage_a = [&](int ktile, char* dst) {        // ktile counts BKT-deep tiles from k = 0
+    // CONV 1/2: (tap, first channel) of the K tile about to be staged, carried from tile to tile (A and B side alike)
+    const int conv_cin = CONV == 1 ? cg.Ci : cg.Co;
+    int a_tap = 0, a_c0 = 0, b_tap = 0, b_c0 = 0;
+    if (CONV == 1 || CONV == 2) {
+        const int kglob = blockIdx.y * ((nk_total + n_split - 1) / n_split) * BKT;
+        a_tap = b_tap = kglob / conv_cin;
+        a_c0 = b_c0 = kglob - a_tap * conv_cin;
+    }
+    auto stage_a = [&](int ktile, char* dst) {        // ktile counts BKT-deep tiles from k = 0; consecutive calls only
         if (CONV == 1 || CONV == 2) {
-            const int cin = CONV == 1 ? cg.Ci : cg.Co;
-            const int kglob = ktile * BKT;
-            const int tap = kglob / cin, c0 = kglob - tap * cin;
+            const int cin = conv_cin;
+            const int tap = a_tap, c0 = a_c0;
+            a_c0 += BKT;
+            if (a_c0 >= cin) { a_c0 = 0; a_tap += 1; }
             const int dh = tap / 3 - 1, dw = tap % 3 - 1;
+            const bf16_t* a_tap_base = A + ((int64_t)dh * cg.W + dw) * cin + c0;     // uniform: one scalar add per piece
 #pragma unroll
             for (int i = 0; i < PW; ++i) {
                 const int inst = wid * PW + i;
-                const int row = inst * (64 / CPR) + lane / CPR;
-                const int chunk = (lane % CPR) ^ kmaj_swz<BKT>(row);
                 const int hh = ga_h[i] + dh, ww = ga_w[i] + dw;
                 const bool in = hh >= 0 && hh < cg.H && ww >= 0 && ww < cg.W;
-                const bf16_t* src = in ? A + (ga_pix[i] + (int64_t)dh * cg.W + dw) * cin + c0 + chunk * 8 : zero;
+                const bf16_t* src = in ? a_tap_base + ga_pix[i] : zero;   // ga_pix: element offset of (pixel, swizzled chunk)
                 __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(dst + inst * 1024), 16, 0, 0);
             }
         } else {
@@ -317,28 +335,29 @@ gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __rest
     };
     auto stage_b = [&](int ktile, char* dst) {
         if (CONV == 2) {                              // W[co][8-tap][ci]: rows = co, row stride 9*Ci, tap picks the column window
-            const int kglob = ktile * BKT;
-            const int tap = kglob / cg.Co, c0 = kglob - tap * cg.Co;
+            const int tap = b_tap, c0 = b_c0;
+            b_c0 += BKT;
+            if (b_c0 >= cg.Co) { b_c0 = 0; b_tap += 1; }
             stage_tile<false, BKT>(B + (int64_t)c0 * ldb + (8 - tap) * cg.Ci + n0, ldb, dst, wid, lane, nvalid);
-        } else if (CONV == 3) {
-            const int64_t kglob = (int64_t)ktile * BKT;
+        } else if (CONV == 3) {       // called for consecutive K tiles only: the per-lane state advances by one tile
 #pragma unroll
             for (int i = 0; i < PW; ++i) {
                 const int inst = wid * PW + i;
-                const int row = inst * 4 + (lane >> 4);
-                const int64_t p = kglob + row;
-                const int w = (int)(p % cg.W), h = (int)((p / cg.W) % cg.H);
-                const int tap = gb_tap[i];
-                const int dh = tap / 3 - 1, dw = tap % 3 - 1;
-                const int hh = h + dh, ww = w + dw;
-                const bool in = tap >= 0 && hh >= 0 && hh < cg.H && ww >= 0 && ww < cg.W;
-                const bf16_t* src = in ? B + (p + (int64_t)dh * cg.W + dw) * cg.Ci + gb_ci[i] : zero;
+                const int hh = gb_h[i] + gb_dh[i], ww = gb_w[i] + gb_dw[i];
+                const bool in = hh >= 0 && hh < cg.H && ww >= 0 && ww < cg.W;
+                const bf16_t* src = in ? B + gb_off[i] : zero;
                 __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(dst + inst * 1024), 16, 0, 0);
+                gb_off[i] += (int64_t)BKT * cg.Ci;
+                gb_w[i] += step_w;
+                if (gb_w[i] >= cg.W) { gb_w[i] -= cg.W; gb_h[i] += 1; }
+                gb_h[i] += step_h;
+                if (gb_h[i] >= cg.H) gb_h[i] -= cg.H;
             }
         } else {
             stage_tile<BKM, BKT>((BKM ? B + n0 * ldb : B + n0) + ktile * b_step, ldb, dst, wid, lane, nvalid);
         }
     };
+    const bool wave_live = wm < mvalid && wn < nvalid;
     stage_a(kt0, smem);
     stage_b(kt0, smem + Cfg::tile_bytes);
     for (int kt = 0; kt < nk; ++kt) {
@@ -350,6 +369,7 @@ gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __rest
             stage_a(kt0 + kt + 1, nxt);
             stage_b(kt0 + kt + 1, nxt + Cfg::tile_bytes);
         }
+        if (!wave_live) continue;      // this wave's 64 x 64 quadrant lies wholly outside the matrix (edge tile)
         bf16x8 af[4], bfr[4];
 #pragma unroll
         for (int s = 0; s < BKT / 32; ++s) {

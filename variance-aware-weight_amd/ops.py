@@ -178,10 +178,10 @@ _scratch = {}
 
 def scratch_f32(device, n):
     """Grow-only f32 scratch per device for the fixed-order reductions (column sums, gradient norm, split-K
-    slabs).  64 MiB to start with: 16 M floats hold 4 slabs of the largest DiT-XL weight gradient."""
+    slabs).  256 MiB to start with: 64 M floats hold 8 slabs of any weight gradient of the configs up to DiT-XL / ADM."""
     t = _scratch.get(device)
     if t is None or t.numel() < n:
-        t = _scratch[device] = torch.empty(max(n, 1 << 24), device=device, dtype=torch.float32)
+        t = _scratch[device] = torch.empty(max(n, 1 << 26), device=device, dtype=torch.float32)
     return t
 
 
