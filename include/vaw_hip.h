@@ -177,6 +177,16 @@ int vaw_attn_bwd(vaw_dtype dt, const vaw_attn_desc* d_host, const void* q, const
  * UNet pieces  (models/unet.py, tools/nn.py) -- activations are NHWC: [B*H*W pixels, C channels], act dtype
  * ------------------------------------------------------------------------- */
 
+/* conv3x3 (stride 1, pad 1, NHWC) with a narrow side of at most 4 channels: the 3-channel stem and output convs of
+ * models/unet.py:492 (conv_nd(dims, in_channels, ch, 3, padding=1)) and :625 (zero_module(conv_nd(dims, input_ch, out_channels, 3, padding=1))).
+ * Direct f32-accumulating kernels (K = 27..36 is too short for the MFMA tile).  w has the activation dtype.
+ *   mode 0  forward, narrow input:    in [M][Cn]      -> out [M][Cw],  w = [Cw][3][3][Cn], bias [Cw] or NULL
+ *   mode 1  input gradient of a conv with a narrow OUTPUT: in = dy [M][Cn] -> out = dx [M][Cw], w = [Cn][3][3][Cw]
+ *   mode 2  forward, narrow output:   in [M][Cw]      -> out [M][Cn],  w = [Cn][3][3][Cw], bias [Cn] or NULL
+ * Returns VAW_ERR_UNSUPPORTED (nothing launched) when Cn > 4 or Cw % 8 != 0. */
+int vaw_conv3x3_narrow(vaw_dtype dt, int mode, const void* in, const void* w, const float* bias, void* out, int B, int H,
+                       int W, int Cn, int Cw, vaw_stream stream);
+
 /* GroupNorm32 (tools/nn.py:17-19,93-100; G groups, eps) fused with what follows it in ResBlock._forward
  * (unet.py:236-256):  y = act( GN(x)*gamma + beta [ *(1 + scale[b,c]) + shift[b,c] ] ), act = SiLU if silu else id.
  * scale/shift: f32 rows with stride film_ld (the emb_layers output), or both NULL.  mean/rstd: f32 [B*G] saved.

@@ -142,6 +142,41 @@ def test_implicit_gemm_conv3x3_fwd_dgrad_wgrad(B, H, W, Ci, Co):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,Cn,Cw", [(2, 8, 8, 3, 64), (1, 5, 7, 4, 320), (3, 4, 4, 1, 8), (2, 16, 16, 3, 192)])
+def test_conv3x3_narrow_side(dtype, B, H, W, Cn, Cw):
+    """vaw_conv3x3_narrow: the 3-channel stem (narrow in), the 3-channel output conv (narrow out) and that conv's
+    input gradient, vs torch.conv2d.  Small integers: exact in bf16 operands, f32 accumulation."""
+    dt = F32 if dtype == torch.float32 else BF16
+    g = torch.Generator().manual_seed(B * H + Cw + Cn)
+    ri = lambda *s, lo=-2, hi=3: torch.randint(lo, hi, s, generator=g).float()
+    M = B * H * W
+    # narrow in -> wide out (stem)
+    x, w, bias = ri(B, Cn, H, W), ri(Cw, Cn, 3, 3, lo=-1, hi=2), ri(Cw)
+    ref = F.conv2d(x.double(), w.double(), bias.double(), padding=1)
+    xd, wd, bd = _nhwc(x).to(dtype).to(DEV), w.permute(0, 2, 3, 1).contiguous().to(dtype).to(DEV), bias.to(DEV)
+    y = torch.empty(M, Cw, device=DEV, dtype=dtype)
+    assert lib().vaw_conv3x3_narrow(dt, 0, ptr(xd), ptr(wd), ptr(bd), ptr(y), B, H, W, Cn, Cw, stream_ptr()) == 0
+    assert torch.equal(_nchw(y.cpu().double(), B, H, W), ref)
+    # wide in -> narrow out (output conv) and its input gradient
+    x2, w2, b2, dy2 = ri(B, Cw, H, W, lo=-1, hi=2), ri(Cn, Cw, 3, 3, lo=-1, hi=2), ri(Cn), ri(B, Cn, H, W)
+    xr = x2.double().requires_grad_(True)
+    ref2 = F.conv2d(xr, w2.double(), b2.double(), padding=1)
+    (ref2 * dy2.double()).sum().backward()
+    x2d, w2d, b2d = _nhwc(x2).to(dtype).to(DEV), w2.permute(0, 2, 3, 1).contiguous().to(dtype).to(DEV), b2.to(DEV)
+    y2 = torch.empty(M, Cn, device=DEV, dtype=dtype)
+    assert lib().vaw_conv3x3_narrow(dt, 2, ptr(x2d), ptr(w2d), ptr(b2d), ptr(y2), B, H, W, Cn, Cw, stream_ptr()) == 0
+    tol = dict(rtol=0, atol=0) if dtype == torch.float32 else dict(rtol=1e-2, atol=0.5)    # bf16 output rounding of sums > 256
+    torch.testing.assert_close(_nchw(y2.cpu().double(), B, H, W), ref2.detach(), **tol)
+    dy2d = _nhwc(dy2).to(dtype).to(DEV)
+    dx2 = torch.empty(M, Cw, device=DEV, dtype=dtype)
+    assert lib().vaw_conv3x3_narrow(dt, 1, ptr(dy2d), ptr(w2d), None, ptr(dx2), B, H, W, Cn, Cw, stream_ptr()) == 0
+    assert torch.equal(_nchw(dx2.cpu().double(), B, H, W), xr.grad)
+    # declines (nothing launched) off its shapes
+    assert lib().vaw_conv3x3_narrow(dt, 0, ptr(xd), ptr(wd), ptr(bd), ptr(y), B, H, W, 5, Cw, stream_ptr()) == -3
+    assert lib().vaw_conv3x3_narrow(dt, 0, ptr(xd), ptr(wd), ptr(bd), ptr(y), B, H, W, Cn, Cw + 4, stream_ptr()) == -3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_resample_concat_layout(dtype):
     B, C, H = 2, 8, 6
     dt = F32 if dtype == torch.float32 else BF16

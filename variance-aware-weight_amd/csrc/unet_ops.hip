@@ -172,15 +172,22 @@ __global__ void gn_bwd_fold_kernel(const float* __restrict__ part, int nchunk, i
     for (int ch = 0; ch < nchunk; ++ch) t += part[((k * nchunk + ch) * B) * C + bc];
     sums[i] = t;
 }
-__global__ void gn_bwd_group_kernel(const float* __restrict__ sums, const float* __restrict__ gamma, int B, int C, int G,
-                                    float* __restrict__ S1, float* __restrict__ S2, float* __restrict__ dgamma,
-                                    float* __restrict__ dbeta, float gbeta, float* __restrict__ dscale,
-                                    float* __restrict__ dshift, int64_t dfilm_ld) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// Three independent jobs in one launch, told apart by block index (each fully parallel; fixed summation order):
+//   blocks [0, nb1)        S1, S2 per (sample, group)
+//   blocks [nb1, nb1+nb2)  dgamma, dbeta: 16 channels per block, 16 lanes stride the batch, shuffle tree over them
+//   blocks [nb1+nb2, ...)  FiLM gradients copied out per (sample, channel)
+__global__ void __launch_bounds__(256)
+gn_bwd_group_kernel(const float* __restrict__ sums, const float* __restrict__ gamma, int B, int C, int G,
+                    float* __restrict__ S1, float* __restrict__ S2, float* __restrict__ dgamma,
+                    float* __restrict__ dbeta, float gbeta, float* __restrict__ dscale,
+                    float* __restrict__ dshift, int64_t dfilm_ld, int nb1, int nb2) {
     const int cg = C / G;
     const int64_t BC = (int64_t)B * C;
     const float *A = sums, *Bs = sums + BC, *DS = sums + 2 * BC, *DH = sums + 3 * BC;
-    if (i < B * G) {
+    int blk = blockIdx.x;
+    if (blk < nb1) {
+        const int i = blk * 256 + threadIdx.x;
+        if (i >= B * G) return;
         const int b = i / G, g = i % G;
         float s1 = 0.f, s2 = 0.f;
         for (int j = 0; j < cg; ++j) {
@@ -190,20 +197,38 @@ __global__ void gn_bwd_group_kernel(const float* __restrict__ sums, const float*
         }
         S1[i] = s1;
         S2[i] = s2;
+        return;
     }
-    if (i < C) {
+    blk -= nb1;
+    if (blk < nb2) {
+        const int c = blk * 16 + (threadIdx.x & 15), bl = threadIdx.x >> 4;     // 16 channels x 16 batch lanes
         float dg = 0.f, db = 0.f;
-        for (int b = 0; b < B; ++b) {
-            dg += A[(int64_t)b * C + i];
-            db += Bs[(int64_t)b * C + i];
-        }
-        dgamma[i] = (gbeta != 0.f ? gbeta * dgamma[i] : 0.f) + dg;
-        dbeta[i] = (gbeta != 0.f ? gbeta * dbeta[i] : 0.f) + db;
-        if (dscale)
-            for (int b = 0; b < B; ++b) {
-                dscale[(int64_t)b * dfilm_ld + i] = DS[(int64_t)b * C + i];
-                dshift[(int64_t)b * dfilm_ld + i] = DH[(int64_t)b * C + i];
+        if (c < C)
+            for (int b = bl; b < B; b += 16) {
+                dg += A[(int64_t)b * C + c];
+                db += Bs[(int64_t)b * C + c];
             }
+        // lanes of one channel sit 16 apart: in-wave tree over lane bits 4,5, then the 4 waves through LDS
+        dg += __shfl_xor(dg, 16, 64); dg += __shfl_xor(dg, 32, 64);
+        db += __shfl_xor(db, 16, 64); db += __shfl_xor(db, 32, 64);
+        __shared__ float red[2][4][16];
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        if (lane < 16) { red[0][w][lane] = dg; red[1][w][lane] = db; }
+        __syncthreads();
+        if (threadIdx.x < 16 && c < C) {
+            const float tg = (red[0][0][threadIdx.x] + red[0][1][threadIdx.x]) + (red[0][2][threadIdx.x] + red[0][3][threadIdx.x]);
+            const float tb = (red[1][0][threadIdx.x] + red[1][1][threadIdx.x]) + (red[1][2][threadIdx.x] + red[1][3][threadIdx.x]);
+            dgamma[c] = (gbeta != 0.f ? gbeta * dgamma[c] : 0.f) + tg;
+            dbeta[c] = (gbeta != 0.f ? gbeta * dbeta[c] : 0.f) + tb;
+        }
+        return;
+    }
+    blk -= nb2;
+    const int64_t i = (int64_t)blk * 256 + threadIdx.x;
+    if (dscale && i < BC) {
+        const int64_t b = i / C, c = i % C;
+        dscale[b * dfilm_ld + c] = DS[i];
+        dshift[b * dfilm_ld + c] = DH[i];
     }
 }
 
@@ -402,6 +427,150 @@ extern "C" int vaw_conv3x3_wgrad_small(vaw_dtype dt, const void* dy, const void*
 }
 
 // ---------------------------------------------------------------------------------------------
+// conv3x3 with a narrow side (<= 4 channels): the 3-channel stem and the 3-channel output conv.  27 (or 36) taps
+// per output are too short a K for the MFMA tile and the patch matrix would be pure HBM traffic, so these are direct
+// f32-accumulating kernels: weights live in LDS as f32, activations are read once, outputs written in 16-byte pieces.
+//   WIDE_OUT  in [M][S] -> out [M][Cw]; flip=0: forward (w = [Cw][9][S]);  flip=1: input gradient of a conv whose
+//             OUTPUT is narrow: in = dy [M][S], out = dx [M][Cw], w = [S][9][Cw] read with the tap reversed
+//   NARROW_OUT in [M][Cw] -> out [M][S], forward, w = [S][9][Cw]
+// ---------------------------------------------------------------------------------------------
+#define NW_PIX 2          // pixels per thread (the LDS weight reads are shared between them)
+#define NW_BLOCK_PIX 256  // pixels per workgroup
+template <typename T, int S>
+__global__ void __launch_bounds__(256)
+conv3x3_narrow_in_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias, T* __restrict__ out,
+                         int B, int H, int W, int Cw, int flip) {
+    __shared__ float wl[9 * S][256 + 8];             // [tap*S + j][wide channel of this 256-chunk]
+    const int c0 = blockIdx.y * 256, cn = Cw - c0 < 256 ? Cw - c0 : 256;
+    for (int i = threadIdx.x; i < 9 * S * cn; i += 256) {
+        const int c = i % cn, kj = i / cn, tap = kj / S, j = kj % S;
+        wl[kj][c] = flip ? to_f32(w[((int64_t)j * 9 + (8 - tap)) * Cw + c0 + c]) : to_f32(w[((int64_t)(c0 + c) * 9 + tap) * S + j]);
+    }
+    __syncthreads();
+    const int cg = (threadIdx.x & 31) * 8, pl = threadIdx.x >> 5;     // 32 groups of 8 channels x 8 pixel lanes
+    if (cg >= cn) return;                                               // Cw % 8 == 0: a group is in or out as a whole
+    const int64_t M = (int64_t)B * H * W;
+    f32x4 b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
+    if (bias) { b0 = load4(bias + c0 + cg); b1 = load4(bias + c0 + cg + 4); }
+    for (int it = 0; it < NW_BLOCK_PIX / (8 * NW_PIX); ++it) {
+        const int64_t p0 = (int64_t)blockIdx.x * NW_BLOCK_PIX + (it * 8 + pl) * NW_PIX;
+        float patch[NW_PIX][9 * S];
+#pragma unroll
+        for (int q = 0; q < NW_PIX; ++q) {
+            const int64_t p = p0 + q;
+            const int wq = (int)(p % W), hq = (int)((p / W) % H);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int hh = hq + t / 3 - 1, ww = wq + t % 3 - 1;
+                const bool ok = p < M && hh >= 0 && hh < H && ww >= 0 && ww < W;
+                const T* src = in + (p + (int64_t)(t / 3 - 1) * W + (t % 3 - 1)) * S;
+#pragma unroll
+                for (int j = 0; j < S; ++j) patch[q][t * S + j] = ok ? to_f32(src[j]) : 0.f;
+            }
+        }
+        f32x4 a0[NW_PIX], a1[NW_PIX];
+#pragma unroll
+        for (int q = 0; q < NW_PIX; ++q) { a0[q] = b0; a1[q] = b1; }
+#pragma unroll
+        for (int kj = 0; kj < 9 * S; ++kj) {
+            const f32x4 w0 = load4(&wl[kj][cg]), w1 = load4(&wl[kj][cg + 4]);
+#pragma unroll
+            for (int q = 0; q < NW_PIX; ++q) {
+                a0[q] += patch[q][kj] * w0;
+                a1[q] += patch[q][kj] * w1;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NW_PIX; ++q)
+            if (p0 + q < M) {
+                T* dst = out + (p0 + q) * Cw + c0 + cg;
+                store4(dst, a0[q]);
+                store4(dst + 4, a1[q]);
+            }
+    }
+}
+
+template <typename T, int S>
+__global__ void __launch_bounds__(256)
+conv3x3_narrow_out_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias, T* __restrict__ out,
+                          int B, int H, int W, int Cw) {
+    extern __shared__ float wsm[];                   // [S][9][Cw] f32
+    for (int i = threadIdx.x; i < S * 9 * Cw; i += 256) wsm[i] = to_f32(w[i]);
+    __syncthreads();
+    const int sub = threadIdx.x & 7;                 // 8 lanes share a pixel, each takes every 8th 8-channel chunk
+    const int64_t M = (int64_t)B * H * W;
+    const int64_t p = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+    const bool live = p < M;
+    const int wq = live ? (int)(p % W) : 0, hq = live ? (int)((p / W) % H) : 0;
+    float acc[S];
+#pragma unroll
+    for (int j = 0; j < S; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int hh = hq + t / 3 - 1, ww = wq + t % 3 - 1;
+        if (!(live && hh >= 0 && hh < H && ww >= 0 && ww < W)) continue;
+        const T* src = in + (p + (int64_t)(t / 3 - 1) * W + (t % 3 - 1)) * Cw;
+        for (int c = sub * 8; c < Cw; c += 64) {
+            const f32x4 x0 = load4(src + c), x1 = load4(src + c + 4);
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                const float* wr = wsm + ((int64_t)j * 9 + t) * Cw + c;
+                const f32x4 w0 = load4(wr), w1 = load4(wr + 4);
+                acc[j] += ((x0[0] * w0[0] + x0[1] * w0[1]) + (x0[2] * w0[2] + x0[3] * w0[3])) +
+                          ((x1[0] * w1[0] + x1[1] * w1[1]) + (x1[2] * w1[2] + x1[3] * w1[3]));
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+        acc[j] += __shfl_xor(acc[j], 1, 64);
+        acc[j] += __shfl_xor(acc[j], 2, 64);
+        acc[j] += __shfl_xor(acc[j], 4, 64);
+    }
+    if (live && sub == 0) {
+#pragma unroll
+        for (int j = 0; j < S; ++j) out[p * S + j] = from_f32<T>(acc[j] + (bias ? bias[j] : 0.f));
+    }
+}
+
+template <typename T, int S>
+static void launch_narrow_out(const T* in, const T* w, const float* bias, T* out, int B, int H, int W, int Cw, int64_t M,
+                              size_t lds, hipStream_t s) {
+    (void)hipFuncSetAttribute((const void*)conv3x3_narrow_out_kernel<T, S>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    conv3x3_narrow_out_kernel<T, S><<<ceil_div(M, 32), 256, lds, s>>>(in, w, bias, out, B, H, W, Cw);
+}
+
+extern "C" int vaw_conv3x3_narrow(vaw_dtype dt, int mode, const void* in, const void* w, const float* bias, void* out, int B, int H,
+                                  int W, int Cn, int Cw, vaw_stream stream) {
+    VAW_CHECK_ARG(mode >= 0 && mode <= 2 && in && w && out && B > 0 && H > 0 && W > 0 && Cn > 0 && Cw > 0, "conv3x3_narrow: bad arguments");
+    if (Cn > 4 || Cw % 8 || (mode == 2 && (int64_t)Cn * 9 * Cw * 4 > 96 * 1024)) return VAW_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t M = (int64_t)B * H * W;
+    if (mode == 2) {
+        const size_t lds = (size_t)Cn * 9 * Cw * 4;
+#define NO_LAUNCH(Sv) BY_DTYPE(dt, (launch_narrow_out<T, Sv>((const T*)in, (const T*)w, bias, (T*)out, B, H, W, Cw, M, lds, s)))
+        switch (Cn) {
+            case 1: NO_LAUNCH(1); break;
+            case 2: NO_LAUNCH(2); break;
+            case 3: NO_LAUNCH(3); break;
+            default: NO_LAUNCH(4); break;
+        }
+    } else {
+        dim3 grid(ceil_div(M, NW_BLOCK_PIX), ceil_div(Cw, 256));
+#define NI_LAUNCH(Sv) \
+    BY_DTYPE(dt, (conv3x3_narrow_in_kernel<T, Sv><<<grid, 256, 0, s>>>((const T*)in, (const T*)w, bias, (T*)out, B, H, W, Cw, mode)))
+        switch (Cn) {
+            case 1: NI_LAUNCH(1); break;
+            case 2: NI_LAUNCH(2); break;
+            case 3: NI_LAUNCH(3); break;
+            default: NI_LAUNCH(4); break;
+        }
+    }
+    VAW_CHECK_LAUNCH("conv3x3_narrow");
+    return VAW_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // resampling, concat, layout
 // ---------------------------------------------------------------------------------------------
 // mode 0: out[b,h,w,:] = mean of the 2x2 block of in (in is 2H x 2W)          (avg_pool2d; also nearest-upsample^T * 1/4 * 4)
@@ -506,9 +675,9 @@ extern "C" int vaw_groupnorm_bwd(vaw_dtype dt, const void* dout, const void* x, 
     dim3 grid(ceil_div(C, 64), B, nch);
     BY_DTYPE(dt, (gn_bwd_sums_kernel<T><<<grid, 256, 0, s>>>((const T*)dout, (const T*)x, mean, rstd, gamma, beta, scale, shift, film_ld, silu, HW, C, G, B, nch, part)));
     gn_bwd_fold_kernel<<<ceil_div(4 * BC, 256), 256, 0, s>>>(part, nch, B, C, sums);
-    const int n2 = B * G > C ? B * G : C;
-    gn_bwd_group_kernel<<<ceil_div(n2, 128), 128, 0, s>>>(sums, gamma, B, C, G, S1, S2, dgamma, dbeta, grad_beta,
-                                                           scale ? dscale : nullptr, dshift, dfilm_ld);
+    const int nb1 = (int)ceil_div(B * G, 256), nb2 = (int)ceil_div(C, 16), nb3 = scale && dscale ? (int)ceil_div(BC, 256) : 0;
+    gn_bwd_group_kernel<<<nb1 + nb2 + nb3, 256, 0, s>>>(sums, gamma, B, C, G, S1, S2, dgamma, dbeta, grad_beta,
+                                                         scale ? dscale : nullptr, dshift, dfilm_ld, nb1, nb2);
     BY_DTYPE(dt, (gn_bwd_apply_kernel<T><<<grid, 256, 0, s>>>((const T*)dout, (const T*)x, mean, rstd, gamma, beta, scale, shift, film_ld, silu, S1, S2, (const T*)dx_add, (T*)dx, HW, C, G)));
     VAW_CHECK_LAUNCH("groupnorm_bwd");
     return VAW_OK;

@@ -280,7 +280,14 @@ class UNetModel(FlatModule):
         wp, bp = self._w(name + ".weight"), self._p32(name + ".bias")
         rp = ptr(resid.t) if resid is not None else None
         geo = (a.B, a.H, a.W, Ci, Co)
-        if not ops.conv3x3(dt, 0, ptr(a.t), None, wp, ptr(y.t), *geo, bias=bp, resid=rp):
+        narrow = resid is None and min(Ci, Co) <= 4 and max(Ci, Co) % 8 == 0     # 3-channel stem / output conv
+        if narrow:
+            rc = lib.vaw_conv3x3_narrow(dt, 0 if Ci <= 4 else 2, ptr(a.t), wp, bp, ptr(y.t), a.B, a.H, a.W, min(Ci, Co), max(Ci, Co),
+                                        L.stream_ptr())
+            narrow = rc != -3
+            if narrow:
+                L.check(rc, "conv3x3_narrow")
+        if not narrow and not ops.conv3x3(dt, 0, ptr(a.t), None, wp, ptr(y.t), *geo, bias=bp, resid=rp):
             col = self._new(M, K)           # explicit patch matrix: f32 parity mode and channel counts off the 64 grid
             L.check(lib.vaw_im2col3x3(dt, ptr(a.t), ptr(col), a.B, a.H, a.W, Ci, L.stream_ptr()), "im2col")
             ops.gemm(dt, 1, 1, M, Co, K, ptr(col), K, wp, K, ptr(y.t), Co, bias=bp, resid=rp, resid_is_act=True)
@@ -303,7 +310,13 @@ class UNetModel(FlatModule):
                 ops.gemm(dt, 0, 0, Co, K, M, ptr(dy), Co, ptr(colb), K, gw, K, beta=self._beta, out_f32=True)
             if need_dx:
                 dx = self._new(M, Ci)
-                if not ops.conv3x3(dt, 1, ptr(dy), None, wp, ptr(dx), *geo):
+                done = False
+                if Co <= 4 and Ci % 8 == 0:
+                    rc = lib.vaw_conv3x3_narrow(dt, 1, ptr(dy), wp, None, ptr(dx), a.B, a.H, a.W, Co, Ci, L.stream_ptr())
+                    done = rc != -3
+                    if done:
+                        L.check(rc, "conv3x3_narrow")
+                if not done and not ops.conv3x3(dt, 1, ptr(dy), None, wp, ptr(dx), *geo):
                     if colb is None:
                         colb = self._new(M, K)
                     ops.gemm(dt, 1, 0, M, K, Co, ptr(dy), Co, wp, K, ptr(colb), K)     # d(col)
