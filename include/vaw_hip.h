@@ -208,7 +208,9 @@ int vaw_col2im3x3(vaw_dtype dt, const void* dcol, void* dx, int B, int H, int W,
 /* conv3x3 (stride 1, pad 1) as IMPLICIT GEMM on the bf16 MFMA kernel: the patch matrix is never written; padding taps
  * read a zero page.  mode 0: out[M,Co] = conv(act=x[M,Ci]; w) with the vaw_gemm epilogue (bias, residual, column sums);
  * mode 1: out = dx[M,Ci] from act = dy[M,Co]; mode 2: out = dW[Co][9][Ci] f32 = beta*dW + dy^T . patches(x) with
- * act = dy, act2 = x (split-K through the workspace).  w: [Co][3][3][Ci] act dtype.  Returns VAW_ERR_UNSUPPORTED
+ * act = dy, act2 = x (split-K through the workspace); in mode 2 ep->colsum_out, if set, receives the conv's BIAS
+ * gradient colsum_beta*old + sum over pixels of dy[.,co] (taken from the dy tiles already in LDS, fixed order).
+ * w: [Co][3][3][Ci] act dtype.  Returns VAW_ERR_UNSUPPORTED
  * (nothing launched) for shapes that need the explicit vaw_im2col3x3 + vaw_gemm path: f32, Ci or Co not a multiple
  * of 64 (mode 0 / 1), ... */
 int vaw_conv3x3(vaw_dtype dt, int mode, const void* act, const void* act2, const void* w, void* out, int B, int H, int W,

@@ -36,6 +36,7 @@ struct EpiDev {
     void* C;
     float* slab;   // split-K partial sums [n_split][M][N] f32 (workspace), or NULL
     int debug;        // measurement only (VAW_GEMM_DEBUG): 1 = skip the epilogue, 2 = skip the K loop
+    float* rowpart;   // CONV 3 only: [n_split][M] f32 partial row sums of A = dy^T over this split's pixels (the conv's bias gradient)
     float* colpart;   // [M/128][N] f32: per-row-tile column sums of the OUTPUT (bias gradient of the next layer), or NULL
 };
 
@@ -358,6 +359,9 @@ gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __rest
         }
     };
     const bool wave_live = wm < mvalid && wn < nvalid;
+    const bool do_rowsum = CONV == 3 && e.rowpart != nullptr && tn == 0 && wn == 0;   // one column of tiles, its two left waves
+    f32x4 accr[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    const bf16x8 ones8 = {(bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f};
     stage_a(kt0, smem);
     stage_b(kt0, smem + Cfg::tile_bytes);
     for (int kt = 0; kt < nk; ++kt) {
@@ -385,7 +389,20 @@ gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __rest
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            if (CONV == 3 && do_rowsum) {     // A . ones: every column of the 16 x 16 result is the row sum
+#pragma unroll
+                for (int i = 0; i < 4; ++i) accr[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones8, accr[i], 0, 0, 0);
+            }
         }
+    }
+    if (CONV == 3 && do_rowsum && (lane & 15) == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm + 16 * i + 4 * (lane >> 4) + r;
+                if (row < mvalid) e.rowpart[(int64_t)blockIdx.y * e.M + m0 + row] = accr[i][r];
+            }
     }
     if (e.debug == 1 || e.debug >= 3) {   // keep the accumulators alive with one store per wave-quadrant
         float t = 0.f;
@@ -953,17 +970,23 @@ extern "C" int vaw_conv3x3(vaw_dtype dt, int mode, const void* act, const void* 
     const bool epi_aligned = e.gate_ld % 4 == 0 && ((((uintptr_t)e.bias | (uintptr_t)e.aux_in | (uintptr_t)e.aux_out |
                                                      (uintptr_t)e.gate | (uintptr_t)e.resid | (uintptr_t)e.rowadd) & 15) == 0);
     if (!epi_aligned) return VAW_ERR_UNSUPPORTED;
-    VAW_CHECK_ARG(!colsum_out || (workspace && workspace_floats >= ((M + 127) / 128) * N), "conv3x3: colsum_out needs a workspace");
+    VAW_CHECK_ARG(!colsum_out || mode == 2 || (workspace && workspace_floats >= ((M + 127) / 128) * N), "conv3x3: colsum_out needs a workspace");
     hipStream_t s = (hipStream_t)stream;
     const int tiles_n = (int)((N + BN - 1) / BN);
     const int64_t n_wg = ((M + BM - 1) / BM) * tiles_n;
     const int nk_total = (int)(K / 64);
     const bool plain_f32 = mode == 2 && !e.bias && !e.act;
-    int split = colsum_out ? 1 : pick_split(n_wg, K, M * N, workspace_floats, plain_f32);
-    if (colsum_out) e.colpart = workspace;
+    const bool bias_grad = mode == 2 && colsum_out;      // mode 2: colsum_out = sum over pixels of dy (row sums of A = dy^T)
+    int split = (colsum_out && !bias_grad) ? 1 : pick_split(n_wg, K, M * N, workspace_floats - (bias_grad ? 64 * M : 0), plain_f32);
+    if (colsum_out && !bias_grad) e.colpart = workspace;
     if (split > 1) {
         const int per = (nk_total + split - 1) / split;
         split = (nk_total + per - 1) / per;
+    }
+    float* rowpart = nullptr;
+    if (bias_grad) {
+        VAW_CHECK_ARG(workspace && workspace_floats >= (split > 1 ? split * M * N : 0) + split * M, "conv3x3: bias gradient needs a workspace");
+        rowpart = e.rowpart = workspace + (split > 1 ? split * M * N : 0);
     }
     dim3 grid((unsigned)n_wg, (unsigned)split);
     const ConvGeom cg{H, W, Ci, Co};
@@ -986,6 +1009,7 @@ extern "C" int vaw_conv3x3(vaw_dtype dt, int mode, const void* act, const void* 
         splitk_reduce_kernel<float><<<ceil_div(M * N / 4, 256) > 2048 ? 2048 : ceil_div(M * N / 4, 256), 256, 0, s>>>(
             workspace, split, M, N, ldc, out, e.alpha, e.beta, 1);
     VAW_CHECK_LAUNCH("conv3x3");
+    if (bias_grad) return vaw_reduce_rows(rowpart, split, M, colsum_out, colsum_beta, stream);
     if (colsum_out) return vaw_reduce_rows(workspace, (M + BM - 1) / BM, N, colsum_out, colsum_beta, stream);
     return VAW_OK;
 }

@@ -295,19 +295,23 @@ class UNetModel(FlatModule):
 
         def bw():
             dy = y.grad
-            ops.colsum(dt, ptr(dy), M, Co, Co, self._g(name + ".bias"), self._beta, device=self._flat.device)
             need_dx = a.grad is not None or self._needs_grad(a)
-            gw = self._g(name + ".weight")
+            gw, gb = self._g(name + ".weight"), self._g(name + ".bias")
             colb = None
-            if min(Ci, Co) <= 4:       # 3-channel stem / output conv: dedicated skinny weight-gradient kernel
-                need = lib.vaw_conv3x3_wgrad_small_workspace_floats(a.B, a.H, a.W, Ci, Co)
-                ws = ops.scratch_f32(self._flat.device, need)
-                L.check(lib.vaw_conv3x3_wgrad_small(dt, ptr(dy), ptr(a.t), gw, self._beta, a.B, a.H, a.W, Ci, Co, ptr(ws),
-                                                    ws.numel(), L.stream_ptr()), "conv3x3_wgrad_small")
-            elif not ops.conv3x3(dt, 2, ptr(dy), ptr(a.t), None, gw, *geo, beta=self._beta):
-                colb = self._new(M, K)
-                L.check(lib.vaw_im2col3x3(dt, ptr(a.t), ptr(colb), a.B, a.H, a.W, Ci, L.stream_ptr()), "im2col")
-                ops.gemm(dt, 0, 0, Co, K, M, ptr(dy), Co, ptr(colb), K, gw, K, beta=self._beta, out_f32=True)
+            # the bias gradient rides on the implicit weight-gradient GEMM (row sums of the dy tiles it stages anyway)
+            fused = min(Ci, Co) > 4 and ops.conv3x3(dt, 2, ptr(dy), ptr(a.t), None, gw, *geo, beta=self._beta, colsum_out=gb,
+                                                    colsum_beta=self._beta)
+            if not fused:
+                ops.colsum(dt, ptr(dy), M, Co, Co, gb, self._beta, device=self._flat.device)
+                if min(Ci, Co) <= 4:       # 3-channel stem / output conv: dedicated skinny weight-gradient kernel
+                    need = lib.vaw_conv3x3_wgrad_small_workspace_floats(a.B, a.H, a.W, Ci, Co)
+                    ws = ops.scratch_f32(self._flat.device, need)
+                    L.check(lib.vaw_conv3x3_wgrad_small(dt, ptr(dy), ptr(a.t), gw, self._beta, a.B, a.H, a.W, Ci, Co, ptr(ws),
+                                                        ws.numel(), L.stream_ptr()), "conv3x3_wgrad_small")
+                else:
+                    colb = self._new(M, K)
+                    L.check(lib.vaw_im2col3x3(dt, ptr(a.t), ptr(colb), a.B, a.H, a.W, Ci, L.stream_ptr()), "im2col")
+                    ops.gemm(dt, 0, 0, Co, K, M, ptr(dy), Co, ptr(colb), K, gw, K, beta=self._beta, out_f32=True)
             if need_dx:
                 dx = self._new(M, Ci)
                 done = False
