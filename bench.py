@@ -33,6 +33,8 @@ WORKLOADS = {
     # per-GPU batch and train GFLOP/img from BASELINE.md §3 (BASELINE.json configs 4, 1, 2, 3)
     "dit_b4": dict(kind="dit", model="DiT-B", patch=4, batch=256, gflop_per_img=33.37, desc="DiT-B/4, 4x32x32 latents, 1000 classes"),
     "dit_b2": dict(kind="dit", model="DiT-B", patch=2, batch=256, gflop_per_img=138.0, desc="DiT-B/2, 4x32x32 latents, 1000 classes"),
+    "dit_xl2": dict(kind="dit", model="DiT-XL", patch=2, batch=128, gflop_per_img=711.7,
+                    desc="DiT-XL/2, 4x32x32 latents, 1000 classes (BASELINE config 5 at its per-GPU batch 1024/8; bf16, not fp8)"),
     "dit_s4": dict(kind="dit", model="DiT-S", patch=4, batch=256, gflop_per_img=None, desc="DiT-S/4 (smoke)"),
     "unet32": dict(kind="unet", size=32, classes=0, batch=16, gflop_per_img=9.91,
                    desc="CIFAR-10-shaped UNet (32x32, base 64 ch, mult 1,2,2,2, 10.4 M params), BASELINE config 1"),

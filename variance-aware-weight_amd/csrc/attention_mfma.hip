@@ -1,5 +1,5 @@
 // bf16 MFMA attention for token-major q/k/v rows (DiT's timm Attention AND the UNet's QKVAttention once its
-// activations are NHWC): head dim HD in {32, 64, 96, 128}, any sequence length T that is a multiple of 64.
+// activations are NHWC): head dim up to 128 in steps of 8 (padded with zero columns to HD in {32, 64, 96, 128}), any sequence length T that is a multiple of 64.
 //
 // Everything is computed TRANSPOSED so that no probability tile ever crosses lanes or LDS:
 //   S^T[key][query] = K . Q^T  lands in the 16x16 accumulator layout with the QUERY on the lane (col = l&15) and
@@ -26,7 +26,9 @@ struct AttnMfmaArgs {
     int64_t q_sb, q_sh, q_st;   // element strides of q/k/v (and dq/dk/dv); channel stride is 1
     int64_t o_sb, o_sh, o_st;   // element strides of o / d_o
     float scale;
+    int hd;        // true head dim (multiple of 8, <= the template's HD): LDS columns hd..HD-1 are zero-filled
 };
+__device__ __attribute__((aligned(64))) const unsigned char attn_zero_page[64] = {0};
 
 template <int HD>
 __device__ __forceinline__ int swz(int row) {
@@ -37,7 +39,8 @@ __device__ __forceinline__ int img_off(int row, int chunk) { return row * (2 * H
 
 // 64 token rows starting at g (row stride stride_t elements) -> LDS image rows [0,64); all 4 waves cooperate
 template <int HD>
-__device__ __forceinline__ void stage_block(const bf16_t* __restrict__ g, int64_t stride_t, char* img, int wid, int lane) {
+__device__ __forceinline__ void stage_block(const bf16_t* __restrict__ g, int64_t stride_t, char* img, int wid, int lane,
+                                            int hd) {
     constexpr int CPR = HD / 8;      // 16-byte chunks per row; the image is CPR wave-instructions of 1 KiB
 #pragma unroll
     for (int i = 0; i < CPR / 4; ++i) {
@@ -45,8 +48,9 @@ __device__ __forceinline__ void stage_block(const bf16_t* __restrict__ g, int64_
         const int idx = inst * 64 + lane;
         const int row = idx / CPR;
         const int chunk = (idx % CPR) ^ swz<HD>(row);
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(g + (int64_t)row * stride_t + chunk * 8),
-                                         (lds_ptr_t)(img + inst * 1024), 16, 0, 0);
+        const bf16_t* src = chunk * 8 < hd ? g + (int64_t)row * stride_t + chunk * 8
+                                           : reinterpret_cast<const bf16_t*>(attn_zero_page);   // padded head dim (72 -> 96)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(img + inst * 1024), 16, 0, 0);
     }
 }
 
@@ -103,7 +107,7 @@ attn_fwd_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __rest
     const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
     const int qb = blockIdx.x * 64;
     const int64_t base = b * a.q_sb + h * a.q_sh;
-    stage_block<HD>(q + base + (int64_t)qb * a.q_st, a.q_st, qimg, wid, lane);
+    stage_block<HD>(q + base + (int64_t)qb * a.q_st, a.q_st, qimg, wid, lane, a.hd);
     bf16x8 qf[KS];
     f32x4 ot[DT];
 #pragma unroll
@@ -111,8 +115,8 @@ attn_fwd_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __rest
     float m = -INFINITY, l = 0.f;
     for (int kb = 0; kb < a.T; kb += 64) {
         __syncthreads();                                     // previous block's reads of kimg / vimg are done
-        stage_block<HD>(k + base + (int64_t)kb * a.q_st, a.q_st, kimg, wid, lane);
-        stage_block<HD>(v + base + (int64_t)kb * a.q_st, a.q_st, vimg, wid, lane);
+        stage_block<HD>(k + base + (int64_t)kb * a.q_st, a.q_st, kimg, wid, lane, a.hd);
+        stage_block<HD>(v + base + (int64_t)kb * a.q_st, a.q_st, vimg, wid, lane, a.hd);
         DMA_WAIT_SYNC();
         if (kb == 0) {
 #pragma unroll
@@ -154,7 +158,8 @@ attn_fwd_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __rest
     const int qi = qb + 16 * wid + (lane & 15);
     bf16_t* orow = o + b * a.o_sb + h * a.o_sh + (int64_t)qi * a.o_st + 4 * (lane >> 4);
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) store4(orow + 16 * dt, ot[dt] * inv);
+    for (int dt = 0; dt < DT; ++dt)
+        if (16 * dt + 4 * (lane >> 4) < a.hd) store4(orow + 16 * dt, ot[dt] * inv);
     if ((lane >> 4) == 0) lse[(int64_t)bh * a.T + qi] = m + __logf(l);
 }
 
@@ -177,8 +182,8 @@ attn_bwd_dq_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __r
     const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
     const int qb = blockIdx.x * 64;
     const int64_t base = b * a.q_sb + h * a.q_sh, obase = b * a.o_sb + h * a.o_sh;
-    stage_block<HD>(q + base + (int64_t)qb * a.q_st, a.q_st, qimg, wid, lane);
-    stage_block<HD>(d_o + obase + (int64_t)qb * a.o_st, a.o_st, gimg, wid, lane);
+    stage_block<HD>(q + base + (int64_t)qb * a.q_st, a.q_st, qimg, wid, lane, a.hd);
+    stage_block<HD>(d_o + obase + (int64_t)qb * a.o_st, a.o_st, gimg, wid, lane, a.hd);
     const int qi = qb + 16 * wid + li;
     // delta_i = sum_d dO[i,d] * O[i,d]: lane (li, g) takes a quarter of the row
     float dl = 0.f;
@@ -187,6 +192,7 @@ attn_bwd_dq_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __r
         const bf16_t* op = o + obase + (int64_t)qi * a.o_st + g * (HD / 4);
 #pragma unroll
         for (int d = 0; d < HD / 4; d += 4) {
+            if (g * (HD / 4) + d >= a.hd) continue;
             const f32x4 x = load4(gp + d), y = load4(op + d);
             dl += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
         }
@@ -200,8 +206,8 @@ attn_bwd_dq_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __r
     for (int dt = 0; dt < DT; ++dt) acc[dt] = f32x4{0, 0, 0, 0};
     for (int kb = 0; kb < a.T; kb += 64) {
         __syncthreads();
-        stage_block<HD>(k + base + (int64_t)kb * a.q_st, a.q_st, kimg, wid, lane);
-        stage_block<HD>(v + base + (int64_t)kb * a.q_st, a.q_st, vimg, wid, lane);
+        stage_block<HD>(k + base + (int64_t)kb * a.q_st, a.q_st, kimg, wid, lane, a.hd);
+        stage_block<HD>(v + base + (int64_t)kb * a.q_st, a.q_st, vimg, wid, lane, a.hd);
         DMA_WAIT_SYNC();
         if (kb == 0) {
 #pragma unroll
@@ -231,7 +237,8 @@ attn_bwd_dq_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __r
     }
     bf16_t* row = dq + base + (int64_t)qi * a.q_st + 4 * g;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) store4(row + 16 * dt, acc[dt]);
+    for (int dt = 0; dt < DT; ++dt)
+        if (16 * dt + 4 * g < a.hd) store4(row + 16 * dt, acc[dt]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -255,16 +262,16 @@ attn_bwd_dkv_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __
     const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
     const int jb = blockIdx.x * 64;
     const int64_t base = b * a.q_sb + h * a.q_sh, obase = b * a.o_sb + h * a.o_sh;
-    stage_block<HD>(k + base + (int64_t)jb * a.q_st, a.q_st, kimg, wid, lane);
-    stage_block<HD>(v + base + (int64_t)jb * a.q_st, a.q_st, vimg, wid, lane);
+    stage_block<HD>(k + base + (int64_t)jb * a.q_st, a.q_st, kimg, wid, lane, a.hd);
+    stage_block<HD>(v + base + (int64_t)jb * a.q_st, a.q_st, vimg, wid, lane, a.hd);
     bf16x8 kf[KS], vf[KS];
     f32x4 av[DT], ak[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) av[dt] = ak[dt] = f32x4{0, 0, 0, 0};
     for (int ib = 0; ib < a.T; ib += 64) {
         __syncthreads();
-        stage_block<HD>(q + base + (int64_t)ib * a.q_st, a.q_st, qimg, wid, lane);
-        stage_block<HD>(d_o + obase + (int64_t)ib * a.o_st, a.o_st, gimg, wid, lane);
+        stage_block<HD>(q + base + (int64_t)ib * a.q_st, a.q_st, qimg, wid, lane, a.hd);
+        stage_block<HD>(d_o + obase + (int64_t)ib * a.o_st, a.o_st, gimg, wid, lane, a.hd);
         if (threadIdx.x < 64) {
             lse_s[threadIdx.x] = lse[(int64_t)bh * a.T + ib + threadIdx.x];
             del_s[threadIdx.x] = delta[(int64_t)bh * a.T + ib + threadIdx.x];
@@ -308,6 +315,7 @@ attn_bwd_dkv_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __
     const int64_t off = base + (int64_t)(jb + 16 * wid + li) * a.q_st + 4 * g;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
+        if (16 * dt + 4 * g >= a.hd) continue;
         store4(dv + off + 16 * dt, av[dt]);
         store4(dk + off + 16 * dt, ak[dt]);
     }
@@ -319,22 +327,22 @@ attn_bwd_dkv_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 bool vaw_attn_mfma_ok(vaw_dtype dt, const vaw_attn_desc* d, const void* q, const void* k, const void* v, const void* o) {
-    const bool hd_ok = d->hd == 32 || d->hd == 64 || d->hd == 96 || d->hd == 128;
+    const bool hd_ok = d->hd >= 8 && d->hd <= 128 && d->hd % 8 == 0;      // padded up to 32 / 64 / 96 / 128 in LDS
     return dt == VAW_BF16 && hd_ok && d->T % 64 == 0 && d->q_sd == 1 && d->o_sd == 1 && d->q_st % 8 == 0 && d->q_sh % 8 == 0 &&
            d->q_sb % 8 == 0 && d->o_st % 8 == 0 && d->o_sh % 8 == 0 && d->o_sb % 8 == 0 && aligned16(q) && aligned16(k) &&
            aligned16(v) && aligned16(o) && (int64_t)d->B * d->H < 65536;
 }
 
 static AttnMfmaArgs mk_args(const vaw_attn_desc* d) {
-    AttnMfmaArgs a{d->B, d->H, d->T, d->q_sb, d->q_sh, d->q_st, d->o_sb, d->o_sh, d->o_st, d->scale};
+    AttnMfmaArgs a{d->B, d->H, d->T, d->q_sb, d->q_sh, d->q_st, d->o_sb, d->o_sh, d->o_st, d->scale, d->hd};
     return a;
 }
 
 #define DISPATCH_HD(hd, ...)                                \
-    switch (hd) {                                           \
-        case 32: { constexpr int HD = 32; __VA_ARGS__ } break;   \
-        case 64: { constexpr int HD = 64; __VA_ARGS__ } break;   \
-        case 96: { constexpr int HD = 96; __VA_ARGS__ } break;   \
+    switch (((hd) + 31) / 32) {                             \
+        case 1: { constexpr int HD = 32; __VA_ARGS__ } break;    \
+        case 2: { constexpr int HD = 64; __VA_ARGS__ } break;    \
+        case 3: { constexpr int HD = 96; __VA_ARGS__ } break;    \
         default: { constexpr int HD = 128; __VA_ARGS__ } break;  \
     }
 
