@@ -56,6 +56,21 @@ int vaw_wmse_fwd(const float* model_out, const float* x0, const float* noise, co
 int vaw_wmse_bwd(const float* model_out, const float* x0, const float* noise, const float* ca, const float* cb,
                  const float* w, const float* gmse, float* dout, int B, int64_t per_sample, vaw_stream stream);
 
+/* Variational-bound term of the learned-variance objective and the KL losses: _vb_terms_bpd
+ * (gaussian_diffusion.py:775-808) = q_posterior_mean_variance :254-276 + the training side of p_mean_variance
+ * :278-384 + normal_kl / discretized_gaussian_log_likelihood (tools/losses.py:12-76) + mean_flat / ln 2, fused.
+ *   vb[b] = scale * mean_flat(t[b]==0 ? decoder NLL : KL(q(x_{t-1}|x_t,x_0) || p(x_{t-1}|x_t))) / ln 2
+ * coef: f32 [B][8] per-sample table rows {posterior_mean_coef1, posterior_mean_coef2, posterior_log_variance_clipped,
+ * log(beta_t) (LEARNED_RANGE upper end) or the fixed model log variance, pa, pb (pred_xstart = pa*x_t + pb*mean_out),
+ * t==0 ? 1 : 0, unused}.  mean_mode 0: model mean = posterior mean of pred_xstart, 1: mean_out itself (PREVIOUS_X).
+ * var_mode 0: fixed, 1: LEARNED (var_out = log variance), 2: LEARNED_RANGE (var_out in [-1,1]).  All tensors f32,
+ * [B, per_sample] contiguous.  bwd: d_var / d_mean (either may be NULL: the MSE+vb objective detaches the mean). */
+int vaw_vb_fwd(const float* mean_out, const float* var_out, const float* x0, const float* x_t, const float* coef,
+               int mean_mode, int var_mode, float scale, float* vb, int B, int64_t per_sample, vaw_stream stream);
+int vaw_vb_bwd(const float* mean_out, const float* var_out, const float* x0, const float* x_t, const float* coef,
+               int mean_mode, int var_mode, float scale, const float* gvb, float* d_mean, float* d_var, int B,
+               int64_t per_sample, vaw_stream stream);
+
 /* ---------------------------------------------------------------------------
  * Dense layers  (nn.Linear / Conv2d(k=p,s=p) / Conv1d(k=1) in models/dit.py, models/unet.py;
  * cuBLAS in the reference).  One GEMM entry point, MFMA inside.

@@ -7,10 +7,13 @@ Follows /root/reference/tools/gaussian_diffusion.py:
   * q_sample                  :234-252
   * sample_t                  :810-816
   * compute_target            :818-832
-  * training_losses (MSE)     :834-930
+  * training_losses (MSE, learned-variance vb term, KL)  :834-930
+  * q_posterior_mean_variance :254-276, p_mean_variance (training side) :278-384, _predict_xstart_* :386-410
+  * _vb_terms_bpd             :775-808
+and tools/losses.py:12-76 (normal_kl, approx_standard_normal_cdf, discretized_gaussian_log_likelihood)
   * compute_mse_loss_weight   :1092-1148
   * FlowMatching training     :1151-1340
-and tools/nn.py:86-90 (mean_flat).  Pinned by tests/golden/diffusion_*.npz.
+and tools/nn.py:86-90 (mean_flat).  Pinned by tests/golden/diffusion_*.npz, objective.pt, vb_objective.pt.
 """
 import enum
 import math
@@ -138,6 +141,30 @@ def compute_mse_loss_weight(mean_type, wt, t, alpha, sigma, p2_k=1.0, p2_gamma=1
     return w
 
 
+def normal_kl(mean1, logvar1, mean2, logvar2):
+    """tools/losses.py:12-39"""
+    return 0.5 * (-1.0 + logvar2 - logvar1 + torch.exp(logvar1 - logvar2) + ((mean1 - mean2) ** 2) * torch.exp(-logvar2))
+
+
+def approx_standard_normal_cdf(x):
+    """tools/losses.py:42-47"""
+    return 0.5 * (1.0 + torch.tanh(np.sqrt(2.0 / np.pi) * (x + 0.044715 * torch.pow(x, 3))))
+
+
+def discretized_gaussian_log_likelihood(x, *, means, log_scales):
+    """tools/losses.py:50-76: bins of width 2/255 around x in [-1, 1], open-ended beyond +-0.999."""
+    assert x.shape == means.shape == log_scales.shape
+    centered_x = x - means
+    inv_stdv = torch.exp(-log_scales)
+    cdf_plus = approx_standard_normal_cdf(inv_stdv * (centered_x + 1.0 / 255.0))
+    cdf_min = approx_standard_normal_cdf(inv_stdv * (centered_x - 1.0 / 255.0))
+    log_cdf_plus = torch.log(cdf_plus.clamp(min=1e-12))
+    log_one_minus_cdf_min = torch.log((1.0 - cdf_min).clamp(min=1e-12))
+    cdf_delta = cdf_plus - cdf_min
+    return torch.where(x < -0.999, log_cdf_plus,
+                       torch.where(x > 0.999, log_one_minus_cdf_min, torch.log(cdf_delta.clamp(min=1e-12))))
+
+
 class GaussianDiffusion:
     def __init__(self, *, args, betas, model_mean_type, model_var_type, loss_type,
                  rescale_timesteps=False, device="cpu"):
@@ -215,17 +242,79 @@ class GaussianDiffusion:
         sigma = extract(self.sqrt_one_minus_alphas_cumprod, t, t.shape)
         w = compute_mse_loss_weight(self.model_mean_type, self.mse_loss_weight_type, t, alpha, sigma,
                                     self.p2_k, self.p2_gamma)
+        if self.loss_type in (LossType.KL, LossType.RESCALED_KL):                    # reference :865-876
+            raw = model(x_t, self._scale_timesteps(t), **model_kwargs)
+            loss = self._vb_terms_bpd(raw[0] if isinstance(raw, tuple) else raw, x_start, x_t, t)
+            if self.loss_type == LossType.RESCALED_KL:
+                loss = loss * self.num_timesteps
+            return {"loss": loss}
         if self.loss_type not in (LossType.MSE, LossType.RESCALED_MSE):
             raise NotImplementedError(self.loss_type)
-        if self.model_var_type in (ModelVarType.LEARNED, ModelVarType.LEARNED_RANGE):
-            raise NotImplementedError("learned variance is SURVEY §8(f) item 2, not built yet")
         raw = model(x_t, self._scale_timesteps(t), **model_kwargs)
         out = raw[0] if isinstance(raw, tuple) else raw
+        terms = {}
+        if self.model_var_type in (ModelVarType.LEARNED, ModelVarType.LEARNED_RANGE):   # reference :887-906
+            B, C = x_t.shape[:2]
+            assert out.shape == (B, C * 2, *x_t.shape[2:])
+            out, var_values = torch.split(out, C, dim=1)
+            # the bound trains the variance only: the mean prediction enters it detached
+            terms["vb"] = self._vb_terms_bpd(torch.cat([out.detach(), var_values], dim=1), x_start, x_t, t)
+            if self.loss_type == LossType.RESCALED_MSE:
+                terms["vb"] = terms["vb"] * (self.num_timesteps / 1000.0)
         target = self.compute_target(x_start, noise, t, alpha, sigma)
         assert out.shape == target.shape == x_start.shape
-        terms = {"mse": w * mean_flat((target - out) ** 2)}
-        terms["loss"] = terms["mse"]
+        terms["mse"] = w * mean_flat((target - out) ** 2)
+        terms["loss"] = terms["mse"] + terms["vb"] if "vb" in terms else terms["mse"]
         return terms
+
+    # ---- variational bound (reference :254-276, :278-384, :775-808) -----------------------------------------
+    def q_posterior_mean_variance(self, x_start, x_t, t):
+        assert x_start.shape == x_t.shape
+        mean = (extract(self.posterior_mean_coef1, t, x_t.shape) * x_start
+                + extract(self.posterior_mean_coef2, t, x_t.shape) * x_t)
+        return mean, extract(self.posterior_variance, t, x_t.shape), extract(self.posterior_log_variance_clipped, t, x_t.shape)
+
+    def model_mean_log_variance(self, model_output, x, t):
+        """The training-side half of p_mean_variance (no clipping, no denoised_fn): (mean, log variance) of p(x_{t-1}|x_t)."""
+        B, C = x.shape[:2]
+        if self.model_var_type in (ModelVarType.LEARNED, ModelVarType.LEARNED_RANGE):
+            assert model_output.shape == (B, C * 2, *x.shape[2:])
+            model_output, var_values = torch.split(model_output, C, dim=1)
+            if self.model_var_type == ModelVarType.LEARNED:
+                log_var = var_values
+            else:
+                min_log = extract(self.posterior_log_variance_clipped, t, x.shape)
+                max_log = extract(np.log(self.betas), t, x.shape)
+                frac = (var_values + 1) / 2                    # [-1, 1] -> [min_var, max_var]
+                log_var = frac * max_log + (1 - frac) * min_log
+        else:
+            tab = {ModelVarType.FIXED_LARGE: np.log(np.append(self.posterior_variance[1], self.betas[1:])),
+                   ModelVarType.FIXED_SMALL: self.posterior_log_variance_clipped}[self.model_var_type]
+            log_var = extract(tab, t, x.shape)
+        mt = self.model_mean_type
+        if mt == ModelMeanType.PREVIOUS_X:
+            return model_output, log_var
+        if mt == ModelMeanType.START_X:
+            pred = model_output
+        elif mt == ModelMeanType.EPSILON:
+            pred = (extract(self.sqrt_recip_alphas_cumprod, t, x.shape) * x
+                    - extract(self.sqrt_recipm1_alphas_cumprod, t, x.shape) * model_output)
+        elif mt == ModelMeanType.VELOCITY:
+            # reference :394-399 gathers with t.shape, which cannot broadcast against an image batch
+            raise RuntimeError("VELOCITY with a variational-bound term: the reference's _predict_xstart_from_v fails to broadcast")
+        else:
+            raise NotImplementedError(mt)
+        mean, _, _ = self.q_posterior_mean_variance(pred, x, t)
+        return mean, log_var
+
+    def _vb_terms_bpd(self, model_output, x_start, x_t, t):
+        """[N] bits per dim: KL(q(x_{t-1}|x_t,x_0) || p(x_{t-1}|x_t)) for t > 0, the decoder NLL at t = 0."""
+        true_mean, _, true_log_var = self.q_posterior_mean_variance(x_start, x_t, t)
+        mean, log_var = self.model_mean_log_variance(model_output, x_t, t)
+        kl = mean_flat(normal_kl(true_mean, true_log_var, mean, log_var)) / np.log(2.0)
+        nll = -discretized_gaussian_log_likelihood(x_start, means=mean, log_scales=0.5 * log_var)
+        nll = mean_flat(nll) / np.log(2.0)
+        return torch.where(t == 0, nll, kl)
 
 
 class FlowMatching:

@@ -206,6 +206,40 @@ def gen_objective(gd):
     torch.save(out, os.path.join(HERE, "objective.pt"))
 
 
+def gen_vb(gd):
+    """Learned-variance / variational-bound objectives (reference gaussian_diffusion.py:775-808, 886-906, tools/losses.py):
+    the model is a leaf tensor P (so d loss / d output is pinned too).  t = 0 exercises the decoder-NLL branch and
+    x0 holds values beyond +-0.999 for the open-ended bins of discretized_gaussian_log_likelihood."""
+    g = torch.Generator().manual_seed(11)
+    x0 = torch.rand(4, 3, 8, 8, generator=g) * 2 - 1
+    x0[0, 0, 0, 0], x0[0, 0, 0, 1], x0[0, 1, 2, 3], x0[0, 2, 5, 5] = -1.0, 1.0, -0.9995, 0.9999
+    noise = torch.randn(4, 3, 8, 8, generator=g)
+    P6 = torch.cat([torch.randn(4, 3, 8, 8, generator=g) * 0.5, torch.rand(4, 3, 8, 8, generator=g) * 2 - 1], 1)
+    t = torch.tensor([0, 17, 500, 999])
+    out = {"x0": x0, "noise": noise, "t": t, "P": P6}
+    for sched in ("cosine", "linear"):
+        betas = gd.get_named_beta_schedule(sched, 1000)
+        # VELOCITY is absent: the reference's _predict_xstart_from_v (:394-399) extracts its coefficients with
+        # t.shape instead of x_t.shape and fails to broadcast (RuntimeError) for any image batch
+        for mt in ("EPSILON", "START_X"):
+            for vt in ("LEARNED_RANGE", "LEARNED", "FIXED_LARGE", "FIXED_SMALL"):
+                learned = vt.startswith("LEARNED")
+                for lt in ("MSE", "RESCALED_MSE", "KL", "RESCALED_KL"):
+                    if not learned and lt in ("MSE", "RESCALED_MSE"):
+                        continue                       # the plain objective, pinned by objective.pt
+                    d = gd.GaussianDiffusion(args=base_args(weight_type="lambda", learn_sigma=learned), betas=betas,
+                                             model_mean_type=gd.ModelMeanType[mt], model_var_type=gd.ModelVarType[vt],
+                                             loss_type=gd.LossType[lt], rescale_timesteps=True, device="cpu")
+                    P = (P6 if learned else P6[:, :3]).clone().requires_grad_(True)
+                    terms = d.training_losses(lambda x, ts, **kw: P, x0, None, t=t, noise=noise)
+                    terms["loss"].sum().backward()
+                    key = f"{sched}/{mt}/{vt}/{lt}"
+                    for k, v in terms.items():
+                        out[f"{key}/{k}"] = v.detach().float()
+                    out[f"{key}/dP"] = P.grad.clone()
+    torch.save(out, os.path.join(HERE, "vb_objective.pt"))
+
+
 def fwd_bwd(model, x, t, y, gout):
     x = x.clone().requires_grad_(True)
     model.zero_grad()
@@ -295,7 +329,7 @@ def synth_loader(B, C, H, n_batches, num_classes, seed=123, latent=False):
     return batches
 
 
-def run_trainer(make_model, args, batches, steps, betas2=(0.9, 0.95)):
+def run_trainer(make_model, args, batches, steps, betas2=(0.9, 0.95), var_type="FIXED_LARGE"):
     import copy
     import random
     from tools import gaussian_diffusion as gd
@@ -307,7 +341,7 @@ def run_trainer(make_model, args, batches, steps, betas2=(0.9, 0.95)):
     opt = torch.optim.AdamW(model.parameters(), lr=args.lr, betas=betas2, weight_decay=0.0, eps=1e-8)
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=get_lr_lambda(args))
     diff = gd.GaussianDiffusion(args=args, betas=gd.get_named_beta_schedule(args.path_type, 1000),
-                                model_mean_type=gd.ModelMeanType.EPSILON, model_var_type=gd.ModelVarType.FIXED_LARGE,
+                                model_mean_type=gd.ModelMeanType.EPSILON, model_var_type=gd.ModelVarType[var_type],
                                 loss_type=gd.LossType.MSE, rescale_timesteps=True, device="cpu")
     tr = Trainer(args, torch.device("cpu"), model, ema_model, opt, sched, diff, batches, Pbar())
     losses = [tr.train_step(s) for s in range(1, steps + 1)]
@@ -340,6 +374,24 @@ def gen_trainer():
     rec["dit_b4_b8"] = run_trainer(dit_b4, base_args(in_chans=4, class_cond=True, dataset="Latent", image_size=32),
                                    latb, 3)
     json.dump(rec, open(os.path.join(HERE, "trainer.json"), "w"), indent=1)
+
+
+def gen_trainer_vb():
+    """Trainer trajectories with the learned-variance objective (learn_sigma=True, LEARNED_RANGE: loss = mse + vb)."""
+    from models import unet as U
+    from models.dit import DiT
+    rec = {}
+    tiny_dit = lambda: DiT(image_size=8, patch_size=2, in_channels=4, hidden_size=64, depth=2, num_heads=2,
+                           class_dropout_prob=0.0, num_classes=10, learn_sigma=True)
+    lat = synth_loader(8, 8, 8, 3, 10, latent=True)
+    rec["dit_tiny_learn_sigma"] = run_trainer(tiny_dit, base_args(in_chans=4, class_cond=True, dataset="Latent", image_size=8,
+                                                                   lr=1e-3, learn_sigma=True), lat, 6, var_type="LEARNED_RANGE")
+    tiny_unet = lambda: U.UNetModel(16, 3, 32, 6, 1, attention_resolutions=(2,), channel_mult=(1, 2), num_heads=2,
+                                    use_scale_shift_norm=True, resblock_updown=True, use_new_attention_order=True)
+    b8 = synth_loader(8, 3, 16, 3, 0)
+    rec["unet_tiny_learn_sigma"] = run_trainer(tiny_unet, base_args(image_size=16, lr=1e-3, learn_sigma=True), b8, 5,
+                                               var_type="LEARNED_RANGE")
+    json.dump(rec, open(os.path.join(HERE, "trainer_vb.json"), "w"), indent=1)
 
 
 def gen_misc():
@@ -378,7 +430,7 @@ def main():
     from tools import gaussian_diffusion as gd
     jobs = {"tables": lambda: gen_tables(gd), "weights": lambda: gen_loss_weights(gd),
             "objective": lambda: gen_objective(gd), "dit": gen_dit_tiny, "unet": gen_unet_tiny, "misc": gen_misc,
-            "trainer": gen_trainer}
+            "trainer": gen_trainer, "vb": lambda: gen_vb(gd), "trainer_vb": gen_trainer_vb}
     for name in (sys.argv[1:] or list(jobs)):
         jobs[name]()
         print("wrote", name)

@@ -79,7 +79,7 @@ def test_dit_tiny_bf16_close_to_reference(tag):
             assert abs(float(p.grad.double().norm()) - gl2) <= 5e-2 * gl2 + 1e-4, k
 
 
-def _run_trainer(model, args, batches, steps, fused):
+def _run_trainer(model, args, batches, steps, fused, var_type="FIXED_LARGE"):
     ema_model = copy.deepcopy(model)
     if fused:
         opt = vaw_amd.FusedAdamW(model, lr=args.lr, betas=(0.9, 0.95), weight_decay=0.0, eps=1e-8)
@@ -88,7 +88,7 @@ def _run_trainer(model, args, batches, steps, fused):
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=vaw_amd.get_lr_lambda(args))
     diff = vaw_amd.GaussianDiffusion(args=args, betas=vaw_amd.get_named_beta_schedule(args.path_type, 1000),
                                      model_mean_type=vaw_amd.ModelMeanType.EPSILON,
-                                     model_var_type=vaw_amd.ModelVarType.FIXED_LARGE, loss_type=vaw_amd.LossType.MSE,
+                                     model_var_type=vaw_amd.ModelVarType[var_type], loss_type=vaw_amd.LossType.MSE,
                                      rescale_timesteps=True)
     tr = vaw_amd.Trainer(args, torch.device(DEV), model, ema_model, opt, sched, diff, batches, Pbar())
     losses = [tr.train_step(s) for s in range(1, steps + 1)]
@@ -107,6 +107,19 @@ def test_trainer_trajectory_tiny_dit_fp32_vs_reference(fused):
     model = vaw_amd.DiT(image_size=8, patch_size=2, in_channels=4, hidden_size=64, depth=2, num_heads=2,
                         class_dropout_prob=0.0, num_classes=10, learn_sigma=False, compute_dtype="fp32").to(DEV)
     losses, psum, esum = _run_trainer(model, args, synth_loader(8, 8, 8, 3, 10, latent=True), 6, fused)
+    np.testing.assert_allclose(losses, exp["losses"], rtol=1e-4)
+    assert psum == pytest.approx(exp["param_abs_sum"], rel=1e-5)
+    assert esum == pytest.approx(exp["ema_abs_sum"], rel=1e-6)
+
+
+def test_trainer_trajectory_tiny_dit_learned_variance_vs_reference():
+    """learn_sigma=True + LEARNED_RANGE (loss = mse + vb): 6 reference steps, 1e-4 relative."""
+    exp = load_json("trainer_vb.json")["dit_tiny_learn_sigma"]
+    args = base_args(in_chans=4, class_cond=True, dataset="Latent", image_size=8, lr=1e-3, cpu_rng=True, learn_sigma=True)
+    random.seed(42); np.random.seed(42); torch.manual_seed(42)
+    model = vaw_amd.DiT(image_size=8, patch_size=2, in_channels=4, hidden_size=64, depth=2, num_heads=2,
+                        class_dropout_prob=0.0, num_classes=10, learn_sigma=True, compute_dtype="fp32").to(DEV)
+    losses, psum, esum = _run_trainer(model, args, synth_loader(8, 8, 8, 3, 10, latent=True), 6, True, var_type="LEARNED_RANGE")
     np.testing.assert_allclose(losses, exp["losses"], rtol=1e-4)
     assert psum == pytest.approx(exp["param_abs_sum"], rel=1e-5)
     assert esum == pytest.approx(exp["ema_abs_sum"], rel=1e-6)

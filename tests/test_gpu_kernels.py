@@ -68,6 +68,35 @@ def test_training_losses_vs_golden(mt, wt):
             torch.testing.assert_close(p.compute_target(x0, noise, t).cpu(), g[f"{sched}/{mt}/target"], rtol=1e-6, atol=1e-7)
 
 
+VB_CASES = [(sched, mt, vt, lt) for sched in ("cosine", "linear") for mt in ("EPSILON", "START_X")
+            for vt in ("LEARNED_RANGE", "LEARNED", "FIXED_LARGE", "FIXED_SMALL") for lt in ("MSE", "RESCALED_MSE", "KL", "RESCALED_KL")
+            if vt.startswith("LEARNED") or lt in ("KL", "RESCALED_KL")]
+
+
+def test_variational_bound_objectives_vs_reference_golden():
+    """Learned-variance vb term + pure KL losses on the fused vaw_vb_fwd/bwd kernels vs the values and output gradients
+    the unmodified reference produced (tests/golden/vb_objective.pt): t = 0 takes the decoder-NLL branch, x0 holds
+    values in the open-ended bins.  Tolerance 1e-4 relative (north star), far looser than the observed error."""
+    g = load_pt("vb_objective.pt")
+    x0, noise, t = (g[k].to(DEV) for k in ("x0", "noise", "t"))
+    for sched, mt, vt, lt in VB_CASES:
+        learned = vt.startswith("LEARNED")
+        d = vaw_amd.GaussianDiffusion(args=base_args(weight_type="lambda", learn_sigma=learned),
+                                      betas=vaw_amd.get_named_beta_schedule(sched, 1000),
+                                      model_mean_type=vaw_amd.ModelMeanType[mt], model_var_type=vaw_amd.ModelVarType[vt],
+                                      loss_type=vaw_amd.LossType[lt], rescale_timesteps=True)
+        P = (g["P"] if learned else g["P"][:, :3]).clone().to(DEV).requires_grad_(True)
+        terms = d.training_losses(lambda x, ts, **kw: P, x0, None, t=t, noise=noise)
+        terms["loss"].sum().backward()
+        key = f"{sched}/{mt}/{vt}/{lt}"
+        # near-zero KLs (t = 999: five O(1) terms cancelling to 1e-6) carry f32 rounding of the O(1) terms: absolute floor
+        floor = 2e-6 * (1000.0 if lt == "RESCALED_KL" else 1.0)
+        for k, v in terms.items():
+            torch.testing.assert_close(v.detach().cpu(), g[f"{key}/{k}"], rtol=1e-4, atol=floor, msg=f"{key}/{k}")
+        ref = g[f"{key}/dP"]
+        torch.testing.assert_close(P.grad.cpu(), ref, rtol=1e-4, atol=1e-5 * float(ref.abs().max()), msg=key + "/dP")
+
+
 def test_wmse_backward_matches_autograd():
     o, p = _pair("cosine", "VELOCITY", "min_snr_5")
     x0, noise = _rand(6, 3, 9, 5, seed=4), _rand(6, 3, 9, 5, seed=5)

@@ -253,7 +253,7 @@ def test_unet_tiny_bf16_close_to_reference():
             assert abs(float(p.grad.double().norm()) - gl2) <= 8e-2 * gl2 + 1e-3, k
 
 
-def _run_trainer(model, args, batches, steps, fused):
+def _run_trainer(model, args, batches, steps, fused, var_type="FIXED_LARGE"):
     ema_model = copy.deepcopy(model)
     if fused:
         opt = vaw_amd.FusedAdamW(model, lr=args.lr, betas=(0.9, 0.95), weight_decay=0.0, eps=1e-8)
@@ -262,7 +262,7 @@ def _run_trainer(model, args, batches, steps, fused):
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=vaw_amd.get_lr_lambda(args))
     diff = vaw_amd.GaussianDiffusion(args=args, betas=vaw_amd.get_named_beta_schedule(args.path_type, 1000),
                                      model_mean_type=vaw_amd.ModelMeanType.EPSILON,
-                                     model_var_type=vaw_amd.ModelVarType.FIXED_LARGE, loss_type=vaw_amd.LossType.MSE,
+                                     model_var_type=vaw_amd.ModelVarType[var_type], loss_type=vaw_amd.LossType.MSE,
                                      rescale_timesteps=True)
     tr = vaw_amd.Trainer(args, torch.device(DEV), model, ema_model, opt, sched, diff, batches, Pbar())
     losses = [tr.train_step(s) for s in range(1, steps + 1)]
@@ -291,6 +291,21 @@ def test_trainer_trajectory_cfg1_unet_fp32_vs_reference(name, args, steps, fused
     random.seed(42); np.random.seed(42); torch.manual_seed(42)
     model = CFG1().to(DEV)
     losses, psum, esum = _run_trainer(model, args, synth_loader(16, 3, 32, 4, 0), steps, fused)
+    np.testing.assert_allclose(losses, exp["losses"], rtol=1e-4)
+    assert psum == pytest.approx(exp["param_abs_sum"], rel=1e-5)
+    assert esum == pytest.approx(exp["ema_abs_sum"], rel=1e-6)
+
+
+def test_trainer_trajectory_tiny_unet_learned_variance_vs_reference():
+    """UNet with a 6-channel output (learn_sigma) + LEARNED_RANGE: loss = mse + vb; 5 reference steps, 1e-4 relative.
+    Also covers attention at 8x8 inside the Trainer and an output conv that is neither narrow (<= 4) nor MFMA-shaped."""
+    exp = load_json("trainer_vb.json")["unet_tiny_learn_sigma"]
+    args = base_args(image_size=16, lr=1e-3, learn_sigma=True, cpu_rng=True)
+    random.seed(42); np.random.seed(42); torch.manual_seed(42)
+    model = vaw_amd.UNetModel(16, 3, 32, 6, 1, attention_resolutions=(2,), channel_mult=(1, 2), num_heads=2,
+                              use_scale_shift_norm=True, resblock_updown=True, use_new_attention_order=True,
+                              compute_dtype="fp32").to(DEV)
+    losses, psum, esum = _run_trainer(model, args, synth_loader(8, 3, 16, 3, 0), 5, True, var_type="LEARNED_RANGE")
     np.testing.assert_allclose(losses, exp["losses"], rtol=1e-4)
     assert psum == pytest.approx(exp["param_abs_sum"], rel=1e-5)
     assert esum == pytest.approx(exp["ema_abs_sum"], rel=1e-6)

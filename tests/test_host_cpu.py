@@ -99,16 +99,33 @@ def test_loss_weight_function_and_device_table():
 
 def test_unsupported_objectives_raise():
     x = torch.zeros(2, 3, 4, 4)
-    d = vaw_amd.GaussianDiffusion(args=base_args(), betas=vaw_amd.get_named_beta_schedule("cosine", 10),
-                                  model_mean_type=vaw_amd.ModelMeanType.EPSILON,
-                                  model_var_type=vaw_amd.ModelVarType.LEARNED_RANGE, loss_type=vaw_amd.LossType.MSE)
-    with pytest.raises(NotImplementedError):
-        d.training_losses(lambda *a, **k: x, x, t=torch.zeros(2, dtype=torch.long), noise=x)
+    # learned variance / KL losses are built on the HIP path: on CPU tensors they fail loudly, never fall back
     d = vaw_amd.GaussianDiffusion(args=base_args(), betas=vaw_amd.get_named_beta_schedule("cosine", 10),
                                   model_mean_type=vaw_amd.ModelMeanType.EPSILON,
                                   model_var_type=vaw_amd.ModelVarType.FIXED_LARGE, loss_type=vaw_amd.LossType.KL)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(vaw_amd.VawError):
         d.training_losses(lambda *a, **k: x, x, t=torch.zeros(2, dtype=torch.long), noise=x)
+    # the per-timestep table of the variational-bound kernel = the reference's float64 tables cast like _extract_into_tensor
+    for vt, mt in (("LEARNED_RANGE", "EPSILON"), ("FIXED_LARGE", "START_X"), ("FIXED_SMALL", "EPSILON")):
+        kw = dict(args=base_args(), betas=vaw_amd.get_named_beta_schedule("linear", 50), loss_type=vaw_amd.LossType.MSE)
+        d = vaw_amd.GaussianDiffusion(model_mean_type=vaw_amd.ModelMeanType[mt], model_var_type=vaw_amd.ModelVarType[vt], **kw)
+        o = od.GaussianDiffusion(args=base_args(), betas=od.get_named_beta_schedule("linear", 50), loss_type=od.LossType.MSE,
+                                 model_mean_type=od.ModelMeanType[mt], model_var_type=od.ModelVarType[vt])
+        tab, tall = d._vb_table(), torch.arange(50)
+        ex = lambda arr: od.extract(arr, tall, tall.shape)
+        assert torch.equal(tab[:, 0], ex(o.posterior_mean_coef1)) and torch.equal(tab[:, 1], ex(o.posterior_mean_coef2))
+        assert torch.equal(tab[:, 2], ex(o.posterior_log_variance_clipped))
+        aux = {"LEARNED_RANGE": np.log(o.betas), "FIXED_SMALL": o.posterior_log_variance_clipped,
+               "FIXED_LARGE": np.log(np.append(o.posterior_variance[1], o.betas[1:]))}[vt]
+        assert torch.equal(tab[:, 3], ex(aux))
+        if mt == "EPSILON":
+            assert torch.equal(tab[:, 4], ex(o.sqrt_recip_alphas_cumprod)) and torch.equal(tab[:, 5], -ex(o.sqrt_recipm1_alphas_cumprod))
+        assert tab[:, 6].tolist() == [1.0] + [0.0] * 49
+    d = vaw_amd.GaussianDiffusion(args=base_args(), betas=vaw_amd.get_named_beta_schedule("cosine", 10),
+                                  model_mean_type=vaw_amd.ModelMeanType.VELOCITY,
+                                  model_var_type=vaw_amd.ModelVarType.FIXED_LARGE, loss_type=vaw_amd.LossType.KL)
+    with pytest.raises(RuntimeError):       # as the reference (:394-399)
+        d._vb_terms_bpd(x, None, x, x, torch.zeros(2, dtype=torch.long))
     with pytest.raises(NotImplementedError):
         _prod(time_dist=["lognorm", 0, 1]).sample_t(x)
     with pytest.raises(NotImplementedError):

@@ -99,6 +99,35 @@ def test_objective_bit_exact():
     assert torch.equal(fm.sample_t(x0), g["flow/lognorm_t"])
 
 
+VB_CASES = [(sched, mt, vt, lt) for sched in ("cosine", "linear") for mt in ("EPSILON", "START_X")
+            for vt in ("LEARNED_RANGE", "LEARNED", "FIXED_LARGE", "FIXED_SMALL") for lt in ("MSE", "RESCALED_MSE", "KL", "RESCALED_KL")
+            if vt.startswith("LEARNED") or lt in ("KL", "RESCALED_KL")]
+
+
+def test_variational_bound_objectives_vs_reference():
+    """Learned-variance vb term and the pure KL losses (reference :775-808, :865-906, tools/losses.py) incl. the
+    decoder-NLL branch at t = 0 and d loss / d model_output; the oracle's op order is the reference's, so bit-exact."""
+    g = load_pt("vb_objective.pt")
+    x0, noise, t = g["x0"], g["noise"], g["t"]
+    for sched, mt, vt, lt in VB_CASES:
+        learned = vt.startswith("LEARNED")
+        d = od.GaussianDiffusion(args=base_args(weight_type="lambda", learn_sigma=learned),
+                                 betas=od.get_named_beta_schedule(sched, 1000), model_mean_type=od.ModelMeanType[mt],
+                                 model_var_type=od.ModelVarType[vt], loss_type=od.LossType[lt], rescale_timesteps=True)
+        P = (g["P"] if learned else g["P"][:, :3]).clone().requires_grad_(True)
+        terms = d.training_losses(lambda x, ts, **kw: P, x0, None, t=t, noise=noise)
+        terms["loss"].sum().backward()
+        key = f"{sched}/{mt}/{vt}/{lt}"
+        for k, v in terms.items():
+            assert torch.equal(v.detach().float(), g[f"{key}/{k}"]), (key, k)
+        torch.testing.assert_close(P.grad, g[f"{key}/dP"], rtol=1e-6, atol=1e-9, msg=key)
+    d = od.GaussianDiffusion(args=base_args(learn_sigma=True), betas=od.get_named_beta_schedule("cosine", 1000),
+                             model_mean_type=od.ModelMeanType.VELOCITY, model_var_type=od.ModelVarType.LEARNED_RANGE,
+                             loss_type=od.LossType.MSE, rescale_timesteps=True)
+    with pytest.raises(RuntimeError):            # the reference cannot broadcast here either (:394-399)
+        d.training_losses(lambda x, ts, **kw: g["P"], x0, None, t=t, noise=noise)
+
+
 def _fwd_bwd(m, x, t, y, gout):
     x = x.clone().requires_grad_(True)
     m.zero_grad()
@@ -154,14 +183,14 @@ def test_unet_factory_param_counts():
     assert sum(p.numel() for p in ounet.ADM_64(num_classes=1000, class_cond=True).parameters()) == g["nparams/ADM_64_c1000"]
 
 
-def _run_trainer(make_model, args, batches, steps, betas2=(0.9, 0.95)):
+def _run_trainer(make_model, args, batches, steps, betas2=(0.9, 0.95), var_type="FIXED_LARGE"):
     random.seed(42); np.random.seed(42); torch.manual_seed(42)
     model = make_model()
     ema_model = copy.deepcopy(model)
     opt = torch.optim.AdamW(model.parameters(), lr=args.lr, betas=betas2, weight_decay=0.0, eps=1e-8)
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=otr.get_lr_lambda(args))
     diff = od.GaussianDiffusion(args=args, betas=od.get_named_beta_schedule(args.path_type, 1000),
-                                model_mean_type=od.ModelMeanType.EPSILON, model_var_type=od.ModelVarType.FIXED_LARGE,
+                                model_mean_type=od.ModelMeanType.EPSILON, model_var_type=od.ModelVarType[var_type],
                                 loss_type=od.LossType.MSE, rescale_timesteps=True)
     tr = otr.Trainer(args, torch.device("cpu"), model, ema_model, opt, sched, diff, batches, Pbar())
     losses = [tr.train_step(s) for s in range(1, steps + 1)]
@@ -191,6 +220,27 @@ def test_trainer_trajectories(name, make, args, loader, steps):
     assert psum == pytest.approx(exp["param_abs_sum"], rel=1e-7)
     assert esum == pytest.approx(exp["ema_abs_sum"], rel=1e-9)
     assert lr == pytest.approx(exp["lr_last"], rel=1e-12)
+
+
+TINY_DIT_LS = lambda: odit.DiT(image_size=8, patch_size=2, in_channels=4, hidden_size=64, depth=2, num_heads=2,
+                               class_dropout_prob=0.0, num_classes=10, learn_sigma=True)
+TINY_UNET_LS = lambda: ounet.UNetModel(16, 3, 32, 6, 1, attention_resolutions=(2,), channel_mult=(1, 2), num_heads=2,
+                                       use_scale_shift_norm=True, resblock_updown=True, use_new_attention_order=True)
+
+
+@pytest.mark.parametrize("name,make,args,loader,steps", [
+    ("dit_tiny_learn_sigma", TINY_DIT_LS, base_args(in_chans=4, class_cond=True, dataset="Latent", image_size=8, lr=1e-3,
+                                                    learn_sigma=True), lambda: synth_loader(8, 8, 8, 3, 10, latent=True), 6),
+    ("unet_tiny_learn_sigma", TINY_UNET_LS, base_args(image_size=16, lr=1e-3, learn_sigma=True),
+     lambda: synth_loader(8, 3, 16, 3, 0), 5),
+])
+def test_trainer_trajectories_learned_variance(name, make, args, loader, steps):
+    """loss = mse + vb with a 2C-channel model output (LEARNED_RANGE), reference Trainer trajectories."""
+    exp = load_json("trainer_vb.json")[name]
+    losses, psum, esum, lr = _run_trainer(make, args, loader(), steps, var_type="LEARNED_RANGE")
+    np.testing.assert_allclose(losses, exp["losses"], rtol=2e-6)
+    assert psum == pytest.approx(exp["param_abs_sum"], rel=1e-7)
+    assert esum == pytest.approx(exp["ema_abs_sum"], rel=1e-9)
 
 
 def test_misc_lr_resampler_latent():

@@ -124,6 +124,135 @@ extern "C" int vaw_wmse_bwd(const float* model_out, const float* x0, const float
 }
 
 // ---------------------------------------------------------------------------------------------
+// Variational-bound term (learned variance / KL losses): one pass over (x0, x_t, model mean, model var values) per
+// sample, bits per dim.  coef[b][8] = {c1, c2, plv, lv_aux, pa, pb, is_t0, -}: posterior mean coefficients, the
+// clipped posterior log variance (true log variance and the lower end of the learned range), log(beta_t) (upper end
+// of the range) or the fixed model log variance, pred_xstart = pa*x_t + pb*mean_out, and the t == 0 flag.
+//   mean_mode 0: model mean = c1*pred_xstart + c2*x_t      1: model mean = mean_out (PREVIOUS_X)
+//   var_mode  0: log variance = lv_aux (fixed)   1: = var values (LEARNED)   2: interpolated (LEARNED_RANGE)
+// ---------------------------------------------------------------------------------------------
+#define VB_NCOEF 8
+struct VbElem {
+    float val;      // KL or decoder NLL of this element, nats
+    float d_lv;     // d val / d model log variance
+    float d_mean;   // d val / d model mean
+};
+__device__ __forceinline__ float vb_cdf(float z, float& dcdf) {
+    const float k = 0.7978845608028654f;                       // sqrt(2/pi)
+    const float th = tanhf(k * (z + 0.044715f * (z * z * z)));
+    dcdf = 0.5f * (1.f - th * th) * k * (1.f + 3.f * 0.044715f * z * z);
+    return 0.5f * (1.f + th);
+}
+__device__ __forceinline__ VbElem vb_elem(float x0, float true_mean, float true_lv, float mean, float lv, bool t0) {
+    VbElem r;
+    if (!t0) {                                                  // normal_kl (tools/losses.py:12-39)
+        const float e2 = expf(-lv), d = true_mean - mean, ratio = expf(true_lv - lv);
+        r.val = 0.5f * (-1.0f + lv - true_lv + ratio + (d * d) * e2);
+        r.d_lv = 0.5f * (1.f - ratio - (d * d) * e2);
+        r.d_mean = -d * e2;
+        return r;
+    }
+    // -discretized_gaussian_log_likelihood(x0; mean, 0.5*lv) (tools/losses.py:50-76)
+    const float cx = x0 - mean, inv = expf(-(0.5f * lv));
+    const float pin = inv * (cx + 1.0f / 255.0f), mnn = inv * (cx - 1.0f / 255.0f);
+    float dp, dm;
+    const float cp = vb_cdf(pin, dp), cm = vb_cdf(mnn, dm);
+    float lp, g_pin = 0.f, g_min = 0.f;                         // d log_prob / d plus_in, / d min_in
+    if (x0 < -0.999f) {
+        lp = logf(fmaxf(cp, 1e-12f));
+        if (cp >= 1e-12f) g_pin = dp / cp;
+    } else if (x0 > 0.999f) {
+        const float q = 1.f - cm;
+        lp = logf(fmaxf(q, 1e-12f));
+        if (q >= 1e-12f) g_min = -dm / q;
+    } else {
+        const float dl = cp - cm;
+        lp = logf(fmaxf(dl, 1e-12f));
+        if (dl >= 1e-12f) { g_pin = dp / dl; g_min = -dm / dl; }
+    }
+    r.val = -lp;
+    r.d_lv = 0.5f * (g_pin * pin + g_min * mnn);               // d plus_in / d lv = -plus_in / 2
+    r.d_mean = inv * (g_pin + g_min);                           // d plus_in / d mean = -inv_stdv
+    return r;
+}
+__device__ __forceinline__ void vb_model(const float* c, int mean_mode, int var_mode, float xt, float m, float v, float& mean,
+                                         float& lv) {
+    mean = mean_mode == 1 ? m : c[0] * (c[4] * xt + c[5] * m) + c[1] * xt;
+    if (var_mode == 1) lv = v;
+    else if (var_mode == 2) { const float frac = (v + 1.f) / 2.f; lv = frac * c[3] + (1.f - frac) * c[2]; }
+    else lv = c[3];
+}
+
+__global__ void vb_fwd_kernel(const float* __restrict__ mean_out, const float* __restrict__ var_out, const float* __restrict__ x0,
+                              const float* __restrict__ xt, const float* __restrict__ coef, int mean_mode, int var_mode,
+                              float scale, float* __restrict__ vb, int64_t n) {
+    __shared__ float scratch[16];
+    const int b = blockIdx.x;
+    float c[VB_NCOEF];
+#pragma unroll
+    for (int i = 0; i < VB_NCOEF; ++i) c[i] = coef[b * VB_NCOEF + i];
+    const bool t0 = c[6] != 0.f;
+    const int64_t base = (int64_t)b * n;
+    float acc = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const float x = x0[base + i], z = xt[base + i];
+        float mean, lv;
+        vb_model(c, mean_mode, var_mode, z, mean_out[base + i], var_out ? var_out[base + i] : 0.f, mean, lv);
+        acc += vb_elem(x, c[0] * x + c[1] * z, c[2], mean, lv, t0).val;
+    }
+    const float tot = block_sum(acc, scratch);
+    if (threadIdx.x == 0) vb[b] = scale * ((tot / (float)n) / 0.6931471805599453f);
+}
+
+__global__ void vb_bwd_kernel(const float* __restrict__ mean_out, const float* __restrict__ var_out, const float* __restrict__ x0,
+                              const float* __restrict__ xt, const float* __restrict__ coef, int mean_mode, int var_mode,
+                              float scale, const float* __restrict__ gvb, float* __restrict__ d_mean, float* __restrict__ d_var,
+                              int64_t n) {
+    const int b = blockIdx.y;
+    float c[VB_NCOEF];
+#pragma unroll
+    for (int i = 0; i < VB_NCOEF; ++i) c[i] = coef[b * VB_NCOEF + i];
+    const bool t0 = c[6] != 0.f;
+    const float g = gvb[b] * scale / ((float)n * 0.6931471805599453f);
+    const float dlv_dv = var_mode == 2 ? 0.5f * (c[3] - c[2]) : 1.f;
+    const float dmean_dm = mean_mode == 1 ? 1.f : c[0] * c[5];
+    const int64_t base = (int64_t)b * n;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = x0[base + i], z = xt[base + i];
+        float mean, lv;
+        vb_model(c, mean_mode, var_mode, z, mean_out[base + i], var_out ? var_out[base + i] : 0.f, mean, lv);
+        const VbElem e = vb_elem(x, c[0] * x + c[1] * z, c[2], mean, lv, t0);
+        if (d_var) d_var[base + i] = g * e.d_lv * dlv_dv;
+        if (d_mean) d_mean[base + i] = g * e.d_mean * dmean_dm;
+    }
+}
+
+extern "C" int vaw_vb_fwd(const float* mean_out, const float* var_out, const float* x0, const float* x_t, const float* coef,
+                          int mean_mode, int var_mode, float scale, float* vb, int B, int64_t per_sample, vaw_stream stream) {
+    VAW_CHECK_ARG(B > 0 && per_sample > 0 && mean_out && x0 && x_t && coef && vb, "vb_fwd: bad arguments");
+    VAW_CHECK_ARG((mean_mode == 0 || mean_mode == 1) && var_mode >= 0 && var_mode <= 2 && (var_mode == 0 || var_out),
+                  "vb_fwd: bad modes (learned variance needs var_out)");
+    vb_fwd_kernel<<<B, 1024, 0, (hipStream_t)stream>>>(mean_out, var_out, x0, x_t, coef, mean_mode, var_mode, scale, vb, per_sample);
+    VAW_CHECK_LAUNCH("vb_fwd");
+    return VAW_OK;
+}
+
+extern "C" int vaw_vb_bwd(const float* mean_out, const float* var_out, const float* x0, const float* x_t, const float* coef,
+                          int mean_mode, int var_mode, float scale, const float* gvb, float* d_mean, float* d_var, int B,
+                          int64_t per_sample, vaw_stream stream) {
+    VAW_CHECK_ARG(B > 0 && per_sample > 0 && mean_out && x0 && x_t && coef && gvb && (d_mean || d_var), "vb_bwd: bad arguments");
+    VAW_CHECK_ARG((mean_mode == 0 || mean_mode == 1) && var_mode >= 0 && var_mode <= 2 && (var_mode == 0 || var_out) &&
+                      (var_mode != 0 || !d_var),
+                  "vb_bwd: bad modes");
+    int gx = stream_grid(per_sample, 256);
+    dim3 grid(gx > 64 ? 64 : gx, B);
+    vb_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(mean_out, var_out, x0, x_t, coef, mean_mode, var_mode, scale, gvb, d_mean,
+                                                         d_var, per_sample);
+    VAW_CHECK_LAUNCH("vb_bwd");
+    return VAW_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Small conditioning-path kernels ([B, D]-sized)
 // ---------------------------------------------------------------------------------------------
 template <typename T>

@@ -132,11 +132,6 @@ def compute_mse_loss_weight(model_mean_type, mse_loss_weight_type, t, alpha, sig
     return w
 
 
-def _unsupported_objective(what):
-    return NotImplementedError(f"{what}: learned-variance / variational-bound objectives are not on the built "
-                               "hot path yet (SURVEY.md §8f item 2)")
-
-
 class GaussianDiffusion:
     def __init__(self, *, args, betas, model_mean_type, model_var_type, loss_type, rescale_timesteps=False,
                  device="cuda"):
@@ -199,8 +194,42 @@ class GaussianDiffusion:
             else:
                 raise KeyError(mt)
             tb = {k: v.contiguous().to(device) for k, v in dict(a=a, s=s, w=w, ca=ca, cb=cb).items()}
+            tb["vb"] = self._vb_table().to(device)
             self._dev[key] = tb
         return tb
+
+    def _vb_table(self):
+        """[T, 8] f32 rows for vaw_vb_fwd: the float64 tables of q_posterior_mean_variance / p_mean_variance
+        (:254-276, :304-330, :386-392) cast to f32 exactly as _extract_into_tensor does."""
+        f = lambda arr: torch.from_numpy(np.asarray(arr, dtype=np.float64)).float()
+        T = self.num_timesteps
+        vt, mt = self.model_var_type, self.model_mean_type
+        if vt == ModelVarType.FIXED_LARGE:
+            lv_aux = f(np.log(np.append(self.posterior_variance[1], self.betas[1:])))
+        elif vt == ModelVarType.FIXED_SMALL:
+            lv_aux = f(self.posterior_log_variance_clipped)
+        else:
+            lv_aux = f(np.log(self.betas))
+        if mt == ModelMeanType.EPSILON:
+            pa, pb = f(self.sqrt_recip_alphas_cumprod), -f(self.sqrt_recipm1_alphas_cumprod)
+        else:                                   # START_X: pred = model output; PREVIOUS_X ignores pa/pb
+            pa, pb = torch.zeros(T), torch.ones(T)
+        t0 = torch.zeros(T)
+        t0[0] = 1.0
+        return torch.stack([f(self.posterior_mean_coef1), f(self.posterior_mean_coef2), f(self.posterior_log_variance_clipped),
+                            lv_aux, pa, pb, t0, torch.zeros(T)], dim=1).contiguous()
+
+    def _vb_terms_bpd(self, mean_out, var_out, x_start, x_t, t, scale=1.0):
+        """reference :775-808 on the fused kernel.  mean_out / var_out: the two halves of the model output."""
+        mt, vt = self.model_mean_type, self.model_var_type
+        if mt == ModelMeanType.VELOCITY:
+            # the reference gathers with t.shape in _predict_xstart_from_v (:394-399) and cannot broadcast
+            raise RuntimeError("VELOCITY with a variational-bound term: the reference's _predict_xstart_from_v fails to broadcast")
+        if mt not in (ModelMeanType.EPSILON, ModelMeanType.START_X, ModelMeanType.PREVIOUS_X):
+            raise NotImplementedError(mt)
+        var_mode = {ModelVarType.LEARNED: 1, ModelVarType.LEARNED_RANGE: 2}.get(vt, 0)
+        coef = self._tables(x_start.device)["vb"][t]
+        return ops.vb_terms(mean_out, var_out, x_start, x_t, coef, 1 if mt == ModelMeanType.PREVIOUS_X else 0, var_mode, scale)
 
     def _scale_timesteps(self, t):
         if self.rescale_timesteps:
@@ -234,12 +263,9 @@ class GaussianDiffusion:
             noise = torch.randn_like(x_start)       # drawn BEFORE t, as the reference (:849-852)
         if t is None:
             t = self.sample_t(x_start)
-        if self.loss_type not in (LossType.MSE, LossType.RESCALED_MSE):
-            if self.loss_type in (LossType.KL, LossType.RESCALED_KL):
-                raise _unsupported_objective(str(self.loss_type))
+        kl_loss = self.loss_type in (LossType.KL, LossType.RESCALED_KL)
+        if not kl_loss and self.loss_type not in (LossType.MSE, LossType.RESCALED_MSE):
             raise NotImplementedError(self.loss_type)
-        if self.model_var_type in (ModelVarType.LEARNED, ModelVarType.LEARNED_RANGE):
-            raise _unsupported_objective(str(self.model_var_type))
         if getattr(self.args, "learn_align", False):
             raise NotImplementedError("learn_align: feature-alignment teachers are out of scope (SURVEY.md §2.1 row 12)")
         x_start = x_start.contiguous()
@@ -248,9 +274,23 @@ class GaussianDiffusion:
         x_t = ops.qsample(x_start, noise, t, tb["a"], tb["s"])
         raw_output = model(x_t, self._scale_timesteps(t), **model_kwargs)
         model_output = raw_output[0] if isinstance(raw_output, tuple) else raw_output
+        learned = self.model_var_type in (ModelVarType.LEARNED, ModelVarType.LEARNED_RANGE)
+        var_values = None
+        if learned:
+            B, C = x_t.shape[:2]
+            assert model_output.shape == (B, C * 2, *x_t.shape[2:])
+            model_output, var_values = torch.split(model_output, C, dim=1)
+        if kl_loss:                                                           # reference :865-876
+            scale = float(self.num_timesteps) if self.loss_type == LossType.RESCALED_KL else 1.0
+            return {"loss": self._vb_terms_bpd(model_output, var_values, x_start, x_t, t, scale)}
+        terms = {}
+        if learned:                                                           # reference :887-906
+            # the bound trains the variance only: the mean prediction enters it detached
+            scale = self.num_timesteps / 1000.0 if self.loss_type == LossType.RESCALED_MSE else 1.0
+            terms["vb"] = self._vb_terms_bpd(model_output.detach(), var_values, x_start, x_t, t, scale)
         assert model_output.shape == x_start.shape
-        terms = {"mse": ops.weighted_mse(model_output, x_start, noise, tb["ca"][t], tb["cb"][t], tb["w"][t])}
-        terms["loss"] = terms["mse"]
+        terms["mse"] = ops.weighted_mse(model_output, x_start, noise, tb["ca"][t], tb["cb"][t], tb["w"][t])
+        terms["loss"] = terms["mse"] + terms["vb"] if "vb" in terms else terms["mse"]
         return terms
 
 

@@ -74,6 +74,48 @@ def weighted_mse(model_out, x0, noise, ca, cb, w):
     return _WeightedMSE.apply(model_out, x0, noise, ca, cb, w)
 
 
+class _VbTerms(torch.autograd.Function):
+    """vb[b] of reference _vb_terms_bpd (gaussian_diffusion.py:775-808), one fused pass; d/d(var values) and, when the
+    mean prediction is not detached (pure KL losses), d/d(mean output)."""
+
+    @staticmethod
+    def forward(ctx, mean_out, var_out, x0, x_t, coef, mean_mode, var_mode, scale):
+        need_cuda(mean_out, x0, x_t, coef)
+        _f32c(mean_out, x0, x_t, coef)
+        B = x0.shape[0]
+        assert mean_out.shape == x0.shape == x_t.shape and coef.shape == (B, 8)
+        if var_out is not None:
+            need_cuda(var_out)
+            _f32c(var_out)
+            assert var_out.shape == x0.shape
+        vb = torch.empty(B, device=x0.device, dtype=torch.float32)
+        check(L.lib().vaw_vb_fwd(ptr(mean_out), ptr(var_out) if var_out is not None else None, ptr(x0), ptr(x_t), ptr(coef),
+                                 mean_mode, var_mode, scale, ptr(vb), B, x0.numel() // B, stream_ptr()), "vaw_vb_fwd")
+        ctx.save_for_backward(mean_out, var_out, x0, x_t, coef)
+        ctx.modes = (mean_mode, var_mode, scale)
+        return vb
+
+    @staticmethod
+    def backward(ctx, gvb):
+        mean_out, var_out, x0, x_t, coef = ctx.saved_tensors
+        mean_mode, var_mode, scale = ctx.modes
+        gvb = gvb.contiguous().float()
+        d_mean = torch.empty_like(mean_out) if ctx.needs_input_grad[0] else None
+        d_var = torch.empty_like(var_out) if (var_out is not None and ctx.needs_input_grad[1]) else None
+        B = x0.shape[0]
+        if d_mean is not None or d_var is not None:
+            check(L.lib().vaw_vb_bwd(ptr(mean_out), ptr(var_out) if var_out is not None else None, ptr(x0), ptr(x_t), ptr(coef),
+                                     mean_mode, var_mode, scale, ptr(gvb), ptr(d_mean) if d_mean is not None else None,
+                                     ptr(d_var) if d_var is not None else None, B, x0.numel() // B, stream_ptr()), "vaw_vb_bwd")
+        return d_mean, d_var, None, None, None, None, None, None
+
+
+def vb_terms(mean_out, var_out, x0, x_t, coef, mean_mode, var_mode, scale=1.0):
+    """Per-sample variational-bound term in bits/dim; see vaw_vb_fwd in include/vaw_hip.h."""
+    return _VbTerms.apply(mean_out.contiguous(), None if var_out is None else var_out.contiguous(), x0, x_t, coef,
+                          int(mean_mode), int(var_mode), float(scale))
+
+
 # ---- dense -------------------------------------------------------------------------------------
 def gemm(dt, a_kmajor, b_kmajor, M, N, K, A, lda, B, ldb, Cp, ldc, *, bias=None, act=0, aux_in=None, aux_out=None,
          gate=None, gate_ld=0, resid=None, rowadd=None, rows_per_batch=0, alpha=1.0, beta=0.0, out_f32=False,
