@@ -160,12 +160,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    # VAW_REHEARSE_ONE_GPU=1: every rank on cuda:0 over gloo -- exercises the N-rank control flow (buckets, side stream,
+    # barriers, max-over-ranks timing) on a one-GPU box; the numbers it prints are NOT a multi-GPU measurement
+    rehearse = os.environ.get("VAW_REHEARSE_ONE_GPU") == "1"
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     parallel = world > 1
     if parallel:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        vaw_amd.dist_util.setup_dist()
+        vaw_amd.dist_util.setup_dist(backend="gloo" if rehearse else None, device_index=local)
     args = workload_args(wl, parallel=parallel, amp=not a.fp32)
     model, ema_model = build(vaw_amd, wl, args, device, rank)
     if a.fp32:

@@ -17,13 +17,15 @@ def dist_barrier():
         dist.barrier()
 
 
-def setup_dist(backend=None):
+def setup_dist(backend=None, device_index=None):
+    """device_index: GPU for this rank (default LOCAL_RANK).  A rehearsal of the N-rank path on a one-GPU box passes
+    backend="gloo", device_index=0."""
     if dist.is_initialized():
         return
     local_rank = int(os.getenv("LOCAL_RANK", 0))
     use_gpu = torch.cuda.is_available()
     if use_gpu:
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(local_rank if device_index is None else device_index)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "12345")
     os.environ.setdefault("RANK", str(local_rank))

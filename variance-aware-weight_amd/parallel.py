@@ -35,7 +35,7 @@ class DistributedDataParallel(nn.Module):
         module.ensure_flat()
         self._cuda = module._flat.is_cuda
         self._comm = torch.cuda.Stream() if self._cuda else None
-        self._backend_avg = self._cuda           # RCCL has ReduceOp.AVG; gloo does not
+        self._backend_avg = dist.get_backend(process_group) == "nccl"     # RCCL has ReduceOp.AVG; gloo does not
         if broadcast:
             dist.broadcast(module._flat, src=0, group=process_group)     # one collective for all parameters
         self._ranges = self._stage_ranges()
@@ -67,16 +67,16 @@ class DistributedDataParallel(nn.Module):
         rng = self._ranges.get(stage)
         if rng is not None and rng[1] > rng[0]:
             g = self.module.flat_grads()[rng[0]:rng[1]]
+            op = dist.ReduceOp.AVG if self._backend_avg else dist.ReduceOp.SUM
             if self._cuda:
                 ev = torch.cuda.Event()
                 ev.record()
                 with torch.cuda.stream(self._comm):
                     self._comm.wait_event(ev)
-                    w = dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
-                self._pending.append((w, None))
+                    w = dist.all_reduce(g, op=op, group=self.pg, async_op=True)
             else:
-                w = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-                self._pending.append((w, g))
+                w = dist.all_reduce(g, op=op, group=self.pg, async_op=True)
+            self._pending.append((w, None if self._backend_avg else g))
         if stage == 0:
             self.finish()
 
