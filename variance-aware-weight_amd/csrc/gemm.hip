@@ -18,6 +18,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include <type_traits>
 
 struct EpiDev {
     const float* bias;
@@ -35,10 +36,15 @@ struct EpiDev {
     int64_t M, N, ldc;
     void* C;
     float* slab;   // split-K partial sums [n_split][M][N] f32 (workspace), or NULL
-    int debug;        // measurement only (VAW_GEMM_DEBUG): 1 = skip the epilogue, 2 = skip the K loop
+    int debug;        // measurement only (VAW_GEMM_DEBUG): 1 = skip the epilogue, 2 = skip the K loop (ablations 3-5 of DESIGN.md §5 lived here)
     float* rowpart;   // CONV 3 only: [n_split][M] f32 partial row sums of A = dy^T over this split's pixels (the conv's bias gradient)
     float* colpart;   // [M/128][N] f32: per-row-tile column sums of the OUTPUT (bias gradient of the next layer), or NULL
 };
+
+// Streaming (non-temporal) 16-byte stores for the epilogue: the output tile is written once and not re-read by this
+// launch, so it should not evict the operand panels other workgroups of the XCD are re-reading from L2.
+__device__ __forceinline__ void nt_store(float* p, f32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p)); }
+__device__ __forceinline__ void nt_store(bf16_t* p, bf16x8 v) { __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(p)); }
 
 // One accumulator fragment row: 4 consecutive rows (m..m+3) at one column n.
 template <typename TO>
@@ -80,7 +86,7 @@ __device__ __forceinline__ void epi_row8(const EpiDev& e, unsigned m, int64_t n,
         // the saved branch value is the bf16-rounded one, and so is what the activation sees (fwd/bwd consistent)
         const bf16x8 r = {(bf16_t)v0[0], (bf16_t)v0[1], (bf16_t)v0[2], (bf16_t)v0[3],
                           (bf16_t)v1[0], (bf16_t)v1[1], (bf16_t)v1[2], (bf16_t)v1[3]};
-        *reinterpret_cast<bf16x8*>((bf16_t*)e.aux_out + off) = r;
+        nt_store((bf16_t*)e.aux_out + off, r);
         v0 = f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
         v1 = f32x4{(float)r[4], (float)r[5], (float)r[6], (float)r[7]};
     }
@@ -119,12 +125,12 @@ __device__ __forceinline__ void epi_row8(const EpiDev& e, unsigned m, int64_t n,
             v0 += e.beta * load4(c);
             v1 += e.beta * load4(c + 4);
         }
-        store4(c, v0);
-        store4(c + 4, v1);
+        nt_store(c, v0);
+        nt_store(c + 4, v1);
     } else {
         bf16_t* c = (bf16_t*)e.C + off;
         bf16x8 r = {(bf16_t)v0[0], (bf16_t)v0[1], (bf16_t)v0[2], (bf16_t)v0[3], (bf16_t)v1[0], (bf16_t)v1[1], (bf16_t)v1[2], (bf16_t)v1[3]};
-        *reinterpret_cast<bf16x8*>(c) = r;
+        nt_store(c, r);
         v0 = f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};   // what a later reader of C sees
         v1 = f32x4{(float)r[4], (float)r[5], (float)r[6], (float)r[7]};
     }
@@ -229,17 +235,28 @@ __device__ __attribute__((aligned(64))) const unsigned char vaw_zero_page[64] = 
 template <bool AK, bool BKM, int BKT, int CONV>
 __global__ void __launch_bounds__(256, BKT == 64 ? 2 : 3)
 gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb, int nk_total,
-                 int tiles_n, int n_wg, int n_split, EpiDev e, ConvGeom cg) {
+                 int tiles_n, int n_wg, int n_split, EpiDev e, ConvGeom cg, int xcd_parts) {
     using Cfg = FastCfg<BKT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A tile | B tile]; reused by the epilogue
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // XCD-aware remap (bijective for any grid): blocks b, b+8, ... share an XCD; give each XCD a contiguous
-    // run of tiles so A row-panels are re-read from that XCD's L2.
-    int wg;
-    {
+    // XCD-aware remap: workgroups b, b+8, ... share an XCD (round-robin dispatch) and its 4 MiB L2.
+    //   xcd_parts == 0: 2-D grid (tiles, splits); each XCD gets a contiguous run of tiles (bijective for any grid) so
+    //     A row-panels are re-read from that XCD's L2.
+    //   xcd_parts == 8 / n_split (n_split in {2, 4, 8}; 1-D grid of 8 * ceil(n_wg / xcd_parts) workgroups): XCD x works on
+    //     ONE K range (x % n_split) of ONE contiguous part of the tiles (x / n_split), so the workgroups sharing an L2
+    //     walk the same K range in step and every operand panel of that range is fetched once for all of them
+    //     (split-K weight gradients: measured HBM fetch was 3x the operand bytes with the tile-run mapping).
+    int wg, split_idx;
+    if (xcd_parts > 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, per = (n_wg + xcd_parts - 1) / xcd_parts;
+        split_idx = xcd % n_split;
+        wg = (xcd / n_split) * per + j;
+        if (j >= per || wg >= n_wg) return;      // padding workgroups of the last part (uniform: before any barrier)
+    } else {
         const int orig = blockIdx.x, xcd = orig & 7, q = n_wg >> 3, r = n_wg & 7;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        split_idx = blockIdx.y;
     }
     // Within an XCD's run, walk the tiles in groups of 8 row panels (row fastest): the workgroups resident on
     // an XCD then touch ~8 A panels + ~8 B panels (3 MB at K=768), which stay in its 4 MiB L2.
@@ -255,9 +272,9 @@ gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __rest
     const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
     const int64_t a_step = AK ? BKT : (int64_t)BKT * lda;       // step along k: +BKT (k-major) or +BKT*lda
     const int64_t b_step = BKM ? BKT : (int64_t)BKT * ldb;
-    // split-K: blockIdx.y owns k-tiles [kt0, kt0 + nk)   (nk_total counts BKT-deep tiles)
+    // split-K: split_idx owns k-tiles [kt0, kt0 + nk)   (nk_total counts BKT-deep tiles)
     const int nk_per = (nk_total + n_split - 1) / n_split;
-    const int kt0 = blockIdx.y * nk_per;
+    const int kt0 = split_idx * nk_per;
     const int nk = e.debug == 2 ? 1 : (kt0 + nk_per <= nk_total ? nk_per : nk_total - kt0);
     const int wm = (wid >> 1) * 64, wn = (wid & 1) * 64;
     const int mvalid = e.M - m0 < BM ? (int)(e.M - m0) : BM;     // edge tiles: rows / columns that exist
@@ -300,7 +317,7 @@ gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __rest
             const int tap = n < e.N ? n / cg.Ci : -1;     // -1: column beyond 9*Ci (edge tile) -> zero page
             gb_dh[i] = tap >= 0 ? tap / 3 - 1 : (1 << 20);
             gb_dw[i] = tap >= 0 ? tap % 3 - 1 : 0;
-            const int64_t p = (int64_t)blockIdx.y * nk_per0 * BKT + row;
+            const int64_t p = (int64_t)split_idx * nk_per0 * BKT + row;
             gb_w[i] = (int)(p % cg.W);
             gb_h[i] = (int)((p / cg.W) % cg.H);
             gb_off[i] = tap >= 0 ? (p + (int64_t)gb_dh[i] * cg.W + gb_dw[i]) * cg.Ci + n % cg.Ci : 0;
@@ -310,7 +327,7 @@ gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __rest
     const int conv_cin = CONV == 1 ? cg.Ci : cg.Co;
     int a_tap = 0, a_c0 = 0, b_tap = 0, b_c0 = 0;
     if (CONV == 1 || CONV == 2) {
-        const int kglob = blockIdx.y * ((nk_total + n_split - 1) / n_split) * BKT;
+        const int kglob = split_idx * ((nk_total + n_split - 1) / n_split) * BKT;
         a_tap = b_tap = kglob / conv_cin;
         a_c0 = b_c0 = kglob - a_tap * conv_cin;
     }
@@ -364,47 +381,51 @@ gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __rest
     const bf16x8 ones8 = {(bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f};
     stage_a(kt0, smem);
     stage_b(kt0, smem + Cfg::tile_bytes);
-    for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA for tile kt has landed
-        __syncthreads();                                    // everyone's has; and tile kt-1 is no longer read
-        char* cur = smem + (kt & 1) * Cfg::stage_bytes;
-        if (kt + 1 < nk && e.debug < 4) {
-            char* nxt = smem + ((kt + 1) & 1) * Cfg::stage_bytes;
-            stage_a(kt0 + kt + 1, nxt);
-            stage_b(kt0 + kt + 1, nxt + Cfg::tile_bytes);
-        }
-        if (!wave_live) continue;      // this wave's 64 x 64 quadrant lies wholly outside the matrix (edge tile)
-        bf16x8 af[4], bfr[4];
+    // The K loop exists twice (compile-time flag): the few waves that also take row sums of A (CONV 3 bias gradient) run
+    // their own copy, so the common copy's schedule and register use are untouched by it.
+    auto k_loop = [&](auto with_rowsum) {
+        constexpr bool RS = decltype(with_rowsum)::value;
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA for tile kt has landed
+            __syncthreads();                                    // everyone's has; and tile kt-1 is no longer read
+            char* cur = smem + (kt & 1) * Cfg::stage_bytes;
+            if (kt + 1 < nk) {
+                char* nxt = smem + ((kt + 1) & 1) * Cfg::stage_bytes;
+                stage_a(kt0 + kt + 1, nxt);
+                stage_b(kt0 + kt + 1, nxt + Cfg::tile_bytes);
+            }
+            if (!wave_live) continue;      // this wave's 64 x 64 quadrant lies wholly outside the matrix (edge tile)
 #pragma unroll
-        for (int s = 0; s < BKT / 32; ++s) {
-            // timing-only ablations: 3 = half the LDS reads, 4 = no global->LDS staging, 5 = neither staging nor LDS reads
-            if (!((e.debug == 3 && s == 1) || (e.debug == 5 && (kt > 0 || s == 1)))) {
+            for (int s = 0; s < BKT / 32; ++s) {
+                bf16x8 af[4], bfr[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) af[i] = load_frag<AK, BKT>(cur, wm + 16 * i, s, lane);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) bfr[j] = load_frag<BKM, BKT>(cur + Cfg::tile_bytes, wn + 16 * j, s, lane);
-            }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-            if (CONV == 3 && do_rowsum) {     // A . ones: every column of the 16 x 16 result is the row sum
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                if (RS) {     // A . ones: every column of the 16 x 16 result is the row sum
 #pragma unroll
-                for (int i = 0; i < 4; ++i) accr[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones8, accr[i], 0, 0, 0);
+                    for (int i = 0; i < 4; ++i) accr[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones8, accr[i], 0, 0, 0);
+                }
             }
         }
-    }
+    };
+    if (CONV == 3 && do_rowsum) k_loop(std::true_type{});
+    else k_loop(std::false_type{});
     if (CONV == 3 && do_rowsum && (lane & 15) == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = wm + 16 * i + 4 * (lane >> 4) + r;
-                if (row < mvalid) e.rowpart[(int64_t)blockIdx.y * e.M + m0 + row] = accr[i][r];
+                if (row < mvalid) e.rowpart[(int64_t)split_idx * e.M + m0 + row] = accr[i][r];
             }
     }
-    if (e.debug == 1 || e.debug >= 3) {   // keep the accumulators alive with one store per wave-quadrant
+    if (e.debug == 1) {   // keep the accumulators alive with one store per wave-quadrant
         float t = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -438,14 +459,14 @@ gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __rest
         }
         __syncthreads();
         if (n_split > 1) {
-            float* slab = e.slab + (int64_t)blockIdx.y * e.M * e.N;
+            float* slab = e.slab + (int64_t)split_idx * e.M * e.N;
 #pragma unroll
             for (int pass = 0; pass < 4; ++pass) {
                 const int row = pass * 16 + r0;
                 if (!col_ok || 64 * half + row >= mvalid) continue;
                 const float* src = cs + row * CS_LD + c8;
                 float* dst = slab + (m0 + 64 * half + row) * e.N + n0 + c8;
-                store4(dst, load4(src));
+                store4(dst, load4(src));        // split-K partials are re-read at once by the reduce: keep them cached
                 store4(dst + 4, load4(src + 4));
             }
         } else {
@@ -614,7 +635,7 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __
             const int64_t m = m0 + 64 * quarter + row;
             if (n_split > 1) {
                 float* dst = e.slab + (int64_t)blockIdx.y * e.M * e.N + m * e.N + n0 + c8;
-                store4(dst, load4(src));
+                store4(dst, load4(src));        // split-K partials are re-read at once by the reduce: keep them cached
                 store4(dst + 4, load4(src + 4));
             } else {
                 f32x4 v0 = load4(src), v1 = load4(src + 4);
@@ -785,6 +806,13 @@ static int pick_split(int64_t tiles, int64_t K, int64_t MN, int64_t ws_floats, b
     return s < 2 ? 1 : (int)s;
 }
 
+// split-K launches whose split count divides 8 use the K-range-per-XCD mapping of gemm_bf16_kernel (xcd_parts = 8 / split)
+static int xcd_parts_for(int split) {
+    static int on = -1;
+    if (on < 0) { const char* v = getenv("VAW_GEMM_XCDSPLIT"); on = v ? atoi(v) : 1; }
+    return (on && (split == 2 || split == 4 || split == 8)) ? 8 / split : 0;
+}
+
 extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int64_t N, int64_t K, const void* A,
                         int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const vaw_epilogue* ep,
                         float* workspace, int64_t workspace_floats, vaw_stream stream) {
@@ -842,7 +870,9 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
         }
         const bf16_t* a = (const bf16_t*)A;
         const bf16_t* b = (const bf16_t*)B;
+        const int xparts = xcd_parts_for(split);
         dim3 grid((unsigned)n_wg, (unsigned)split);
+        if (xparts) grid = dim3((unsigned)(8 * ((n_wg + xparts - 1) / xparts)), 1);
 #define LAUNCH_FAST(AKv, BKv, BKTv)                                                                                   \
     do {                                                                                                              \
         static bool attr_done = false;                                                                                \
@@ -853,7 +883,7 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
             attr_done = true;                                                                                         \
         }                                                                                                             \
         gemm_bf16_kernel<AKv, BKv, BKTv, 0><<<grid, 256, lds, s>>>(a, lda, b, ldb, nk_total, tiles_n, (int)n_wg, split, e, \
-                                                                    ConvGeom{});                                     \
+                                                                    ConvGeom{}, xparts);                             \
     } while (0)
 #define LAUNCH_FAST_BK(BKTv)                                         \
     do {                                                             \
@@ -988,7 +1018,9 @@ extern "C" int vaw_conv3x3(vaw_dtype dt, int mode, const void* act, const void* 
         VAW_CHECK_ARG(workspace && workspace_floats >= (split > 1 ? split * M * N : 0) + split * M, "conv3x3: bias gradient needs a workspace");
         rowpart = e.rowpart = workspace + (split > 1 ? split * M * N : 0);
     }
+    const int xparts = xcd_parts_for(split);
     dim3 grid((unsigned)n_wg, (unsigned)split);
+    if (xparts) grid = dim3((unsigned)(8 * ((n_wg + xparts - 1) / xparts)), 1);
     const ConvGeom cg{H, W, Ci, Co};
     const int lds = FastCfg<64>::lds_bytes;
 #define LAUNCH_CONV(AKv, BKv, CV, Aptr, LDA, Bptr, LDB)                                                                  \
@@ -1000,7 +1032,7 @@ extern "C" int vaw_conv3x3(vaw_dtype dt, int mode, const void* act, const void* 
             attr_done = true;                                                                                            \
         }                                                                                                                \
         gemm_bf16_kernel<AKv, BKv, 64, CV><<<grid, 256, lds, s>>>((const bf16_t*)(Aptr), LDA, (const bf16_t*)(Bptr), LDB, \
-                                                                  nk_total, tiles_n, (int)n_wg, split, e, cg);           \
+                                                                  nk_total, tiles_n, (int)n_wg, split, e, cg, xparts);   \
     } while (0)
     if (mode == 0) LAUNCH_CONV(true, true, 1, act, (int64_t)Ci, w, 9LL * Ci);
     else if (mode == 1) LAUNCH_CONV(true, false, 2, act, (int64_t)Co, w, 9LL * Ci);
