@@ -94,6 +94,11 @@ typedef struct {
                             * the epilogue (no second pass over C); needs the workspace */
     float colsum_beta;
     int resid_is_act;      /* 1: resid has the act dtype (UNet skip connections), 0: f32 (DiT residual stream) */
+    float* rowsum_a_out;   /* f32[M] or NULL: rowsum_a_out = rowsum_a_beta*rowsum_a_out + sum_k op(A)[m,k].  For the weight
+                            * gradient dW = dy^T x (a_kmajor = 0) this is the layer's BIAS gradient sum_rows dy, taken from
+                            * the dy tiles the MFMA kernel stages anyway (one extra MFMA against a ones operand, fixed
+                            * order); other layouts / the generic kernel honour it with a separate pass.  Needs the workspace */
+    float rowsum_a_beta;
 } vaw_epilogue;
 
 /* C[M,N] = epilogue( alpha * op(A)[M,K] . op(B)[K,N] )
@@ -223,8 +228,8 @@ int vaw_col2im3x3(vaw_dtype dt, const void* dcol, void* dx, int B, int H, int W,
 /* conv3x3 (stride 1, pad 1) as IMPLICIT GEMM on the bf16 MFMA kernel: the patch matrix is never written; padding taps
  * read a zero page.  mode 0: out[M,Co] = conv(act=x[M,Ci]; w) with the vaw_gemm epilogue (bias, residual, column sums);
  * mode 1: out = dx[M,Ci] from act = dy[M,Co]; mode 2: out = dW[Co][9][Ci] f32 = beta*dW + dy^T . patches(x) with
- * act = dy, act2 = x (split-K through the workspace); in mode 2 ep->colsum_out, if set, receives the conv's BIAS
- * gradient colsum_beta*old + sum over pixels of dy[.,co] (taken from the dy tiles already in LDS, fixed order).
+ * act = dy, act2 = x (split-K through the workspace); in mode 2 ep->rowsum_a_out, if set, receives the conv's BIAS
+ * gradient rowsum_a_beta*old + sum over pixels of dy[.,co] (taken from the dy tiles already in LDS, fixed order).
  * w: [Co][3][3][Ci] act dtype.  Returns VAW_ERR_UNSUPPORTED
  * (nothing launched) for shapes that need the explicit vaw_im2col3x3 + vaw_gemm path: f32, Ci or Co not a multiple
  * of 64 (mode 0 / 1), ... */

@@ -238,6 +238,13 @@ def _gemm_epilogues(dtype):
     cs = torch.full((N,), 2.0, device=DEV)
     got = ops.gemm_t(d(A), d(W), act=2, aux_in=d(h), colsum_out=cs, colsum_beta=0.5)
     torch.testing.assert_close(cs.cpu().double(), 1.0 + got.cpu().double().sum(0), rtol=1e-4, atol=1e-3)
+    # wgrad with the bias gradient on the same launch: row sums of A^T (= column sums of the stored [K][M] operand)
+    Xb, Yb = _mk(N, K, 4 * M, False, False, dtype, seed=19)
+    rs = torch.full((N,), 3.0, device=DEV)
+    got = ops.gemm_t(d(Xb), d(Yb), a_kmajor=False, b_kmajor=False, out_dtype=torch.float32, rowsum_a_out=rs, rowsum_a_beta=2.0)
+    torch.testing.assert_close(got.cpu().double(), Xb.double().t() @ Yb.double(),
+                               **(dict(rtol=1e-4, atol=1e-4) if dtype == torch.float32 else dict(rtol=2e-2, atol=1e-1)))
+    torch.testing.assert_close(rs.cpu().double(), 6.0 + Xb.double().sum(0), rtol=1e-5, atol=1e-3)
     # wgrad accumulate: C = 1*C + A^T B
     X, Y = _mk(N, K, M, False, False, dtype, seed=17)
     c0 = _rand(N, K, seed=18)

@@ -138,7 +138,7 @@ def test_implicit_gemm_conv3x3_fwd_dgrad_wgrad(B, H, W, Ci, Co):
     assert torch.equal(dw.cpu().double().permute(0, 3, 1, 2), 1.0 + wr.grad)                           # exact, and beta=1 accumulated
     # bias gradient fused into the weight-gradient launch (row sums of the staged dy tiles), beta accumulates
     dw2, db = torch.zeros(Co, 3, 3, Ci, device=DEV), torch.full((Co,), 2.0, device=DEV)
-    assert ops.conv3x3(BF16, 2, ptr(dyd), ptr(xd), None, ptr(dw2), B, H, W, Ci, Co, colsum_out=ptr(db), colsum_beta=0.5)
+    assert ops.conv3x3(BF16, 2, ptr(dyd), ptr(xd), None, ptr(dw2), B, H, W, Ci, Co, rowsum_a_out=ptr(db), rowsum_a_beta=0.5)
     assert torch.equal(dw2.cpu().double().permute(0, 3, 1, 2), wr.grad)
     assert torch.equal(db.cpu().double(), 1.0 + dy.double().sum((0, 2, 3)))
     # unsupported shapes decline without launching

@@ -17,7 +17,7 @@ _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 class Epilogue(C.Structure):
     _fields_ = [("bias", _p), ("act", _i), ("aux_in", _p), ("aux_out", _p), ("gate", _p), ("gate_ld", _l),
                 ("resid", _p), ("rowadd", _p), ("rows_per_batch", _i), ("alpha", _f), ("beta", _f), ("out_f32", _i),
-                ("colsum_out", _p), ("colsum_beta", _f), ("resid_is_act", _i)]
+                ("colsum_out", _p), ("colsum_beta", _f), ("resid_is_act", _i), ("rowsum_a_out", _p), ("rowsum_a_beta", _f)]
 
 
 class AttnDesc(C.Structure):

@@ -37,7 +37,8 @@ struct EpiDev {
     void* C;
     float* slab;   // split-K partial sums [n_split][M][N] f32 (workspace), or NULL
     int debug;        // measurement only (VAW_GEMM_DEBUG): 1 = skip the epilogue, 2 = skip the K loop (ablations 3-5 of DESIGN.md §5 lived here)
-    float* rowpart;   // CONV 3 only: [n_split][M] f32 partial row sums of A = dy^T over this split's pixels (the conv's bias gradient)
+    float* rowpart;   // mn-major A only (CONV 3 / plain weight gradients): [n_split][M] f32 partial row sums of A = dy^T
+                      // over this split's K range (the layer's bias gradient)
     float* colpart;   // [M/128][N] f32: per-row-tile column sums of the OUTPUT (bias gradient of the next layer), or NULL
 };
 
@@ -376,7 +377,8 @@ gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __rest
         }
     };
     const bool wave_live = wm < mvalid && wn < nvalid;
-    const bool do_rowsum = CONV == 3 && e.rowpart != nullptr && tn == 0 && wn == 0;   // one column of tiles, its two left waves
+    constexpr bool CAN_ROWSUM = CONV == 3 || (CONV == 0 && !AK);
+    const bool do_rowsum = CAN_ROWSUM && e.rowpart != nullptr && tn == 0 && wn == 0;   // one column of tiles, its two left waves
     f32x4 accr[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     const bf16x8 ones8 = {(bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f};
     stage_a(kt0, smem);
@@ -414,9 +416,9 @@ gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __rest
             }
         }
     };
-    if (CONV == 3 && do_rowsum) k_loop(std::true_type{});
+    if (CAN_ROWSUM && do_rowsum) k_loop(std::true_type{});
     else k_loop(std::false_type{});
-    if (CONV == 3 && do_rowsum && (lane & 15) == 0) {
+    if (CAN_ROWSUM && do_rowsum && (lane & 15) == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -806,6 +808,13 @@ static int pick_split(int64_t tiles, int64_t K, int64_t MN, int64_t ws_floats, b
     return s < 2 ? 1 : (int)s;
 }
 
+// rowsum_a_out without the fused path: A stored [K][M] (a_kmajor = 0) is a column sum over its K rows.
+static int rowsum_a_separate(vaw_dtype dt, int a_kmajor, int64_t M, int64_t K, const void* A, int64_t lda, float* out, float beta,
+                             float* workspace, int64_t workspace_floats, vaw_stream stream) {
+    VAW_CHECK_ARG(!a_kmajor, "gemm: rowsum_a_out is defined for a_kmajor = 0 (weight-gradient layout) only");
+    return vaw_colsum(dt, A, K, M, lda, out, beta, workspace, workspace_floats, stream);
+}
+
 // split-K launches whose split count divides 8 use the K-range-per-XCD mapping of gemm_bf16_kernel (xcd_parts = 8 / split)
 static int xcd_parts_for(int split) {
     static int on = -1;
@@ -828,6 +837,9 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
     }
     float* colsum_out = ep ? ep->colsum_out : nullptr;
     const float colsum_beta = ep ? ep->colsum_beta : 0.f;
+    float* rowsum_out = ep ? ep->rowsum_a_out : nullptr;
+    const float rowsum_beta = ep ? ep->rowsum_a_beta : 0.f;
+    VAW_CHECK_ARG(!rowsum_out || (workspace && workspace_floats >= 64 * M), "gemm: rowsum_a_out needs a workspace");
     VAW_CHECK_ARG(e.act >= 0 && e.act <= 2, "gemm: unknown act %d", e.act);
     VAW_CHECK_ARG(e.act != 2 || e.aux_in, "gemm: act=2 needs aux_in");
     VAW_CHECK_ARG(!(e.gate || e.rowadd) || e.rpb > 0, "gemm: gate/rowadd need rows_per_batch");
@@ -862,12 +874,15 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
         // the input-gradient layout (k-major x mn-major, 768 output tiles = exactly 3 per CU), the 64-deep one elsewhere
         const int bkt = bk_env == 32 || bk_env == 64 ? bk_env : ((a_kmajor && !b_kmajor && K <= 4096) ? 32 : 64);
         const int nk_total = (int)(K / bkt);
-        int split = colsum_out ? 1 : pick_split(n_wg, K, M * N, workspace_floats, plain_f32);
+        const bool fused_rowsum = rowsum_out && !a_kmajor && !colsum_out;     // row sums of A ride on the MFMA kernel
+        int split = colsum_out ? 1 : pick_split(n_wg, K, M * N, workspace_floats - (fused_rowsum ? 64 * M : 0), plain_f32);
         if (colsum_out) e.colpart = workspace;
         if (split > 1) {   // no empty splits
             const int per = (nk_total + split - 1) / split;
             split = (nk_total + per - 1) / per;
         }
+        float* rowpart = nullptr;
+        if (fused_rowsum) rowpart = e.rowpart = workspace + (split > 1 ? (int64_t)split * M * N : 0);
         const bf16_t* a = (const bf16_t*)A;
         const bf16_t* b = (const bf16_t*)B;
         const int xparts = xcd_parts_for(split);
@@ -894,7 +909,7 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
     } while (0)
         if (g_gemm_tile == -2) { const char* v = getenv("VAW_GEMM_BIG"); g_gemm_tile = v ? atoi(v) : -1; }
         const int64_t tiles_nb = (N + BIG_BN - 1) / BIG_BN, n_wgb = ((M + BIG_BM - 1) / BIG_BM) * tiles_nb;
-        const bool use_big = bk_env == 0 && (g_gemm_tile == 1 || (g_gemm_tile == -1 && big_tile_pays(M, N, K, n_wgb)));
+        const bool use_big = bk_env == 0 && !fused_rowsum && (g_gemm_tile == 1 || (g_gemm_tile == -1 && big_tile_pays(M, N, K, n_wgb)));
         if (use_big) {
             const int nkb = (int)(K / 32);
             int splitb = colsum_out ? 1 : pick_split(n_wgb * 2, K, M * N, workspace_floats, plain_f32);
@@ -921,6 +936,10 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
                 splitk_reduce_kernel<float><<<ceil_div(M * N / 4, 256) > 2048 ? 2048 : ceil_div(M * N / 4, 256), 256, 0, s>>>(
                     workspace, splitb, M, N, ldc, C, e.alpha, e.beta, 1);
             VAW_CHECK_LAUNCH("gemm_bf16_big");
+            if (rowsum_out) {
+                const int rc = rowsum_a_separate(dt, a_kmajor, M, K, A, lda, rowsum_out, rowsum_beta, workspace, workspace_floats, stream);
+                if (rc != VAW_OK) return rc;
+            }
             if (colsum_out) return vaw_reduce_rows(workspace, (M + BIG_BM - 1) / BIG_BM, N, colsum_out, colsum_beta, stream);
             return VAW_OK;
         }
@@ -930,6 +949,13 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
             splitk_reduce_kernel<float><<<ceil_div(M * N / 4, 256) > 2048 ? 2048 : ceil_div(M * N / 4, 256), 256, 0, s>>>(
                 workspace, split, M, N, ldc, C, e.alpha, e.beta, 1);
         VAW_CHECK_LAUNCH("gemm_bf16");
+        if (fused_rowsum) {
+            const int rc = vaw_reduce_rows(rowpart, split, M, rowsum_out, rowsum_beta, stream);
+            if (rc != VAW_OK) return rc;
+        } else if (rowsum_out) {
+            const int rc = rowsum_a_separate(dt, a_kmajor, M, K, A, lda, rowsum_out, rowsum_beta, workspace, workspace_floats, stream);
+            if (rc != VAW_OK) return rc;
+        }
         if (colsum_out) return vaw_reduce_rows(workspace, (M + BM - 1) / BM, N, colsum_out, colsum_beta, stream);
         return VAW_OK;
     }
@@ -956,6 +982,10 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
         splitk_reduce_kernel<float><<<ceil_div(M * N / 4, 256) > 2048 ? 2048 : ceil_div(M * N / 4, 256), 256, 0, s>>>(
             workspace, split, M, N, ldc, C, e.alpha, e.beta, 1);
     VAW_CHECK_LAUNCH("gemm_generic");
+    if (rowsum_out) {
+        const int rc = rowsum_a_separate(dt, a_kmajor, M, K, A, lda, rowsum_out, rowsum_beta, workspace, workspace_floats, stream);
+        if (rc != VAW_OK) return rc;
+    }
     if (colsum_out)   // generic path: a separate pass over the output just written
         return vaw_colsum(e.out_f32 ? VAW_F32 : dt, C, M, N, ldc, colsum_out, colsum_beta, workspace, workspace_floats, stream);
     return VAW_OK;
@@ -1000,13 +1030,17 @@ extern "C" int vaw_conv3x3(vaw_dtype dt, int mode, const void* act, const void* 
     const bool epi_aligned = e.gate_ld % 4 == 0 && ((((uintptr_t)e.bias | (uintptr_t)e.aux_in | (uintptr_t)e.aux_out |
                                                      (uintptr_t)e.gate | (uintptr_t)e.resid | (uintptr_t)e.rowadd) & 15) == 0);
     if (!epi_aligned) return VAW_ERR_UNSUPPORTED;
-    VAW_CHECK_ARG(!colsum_out || mode == 2 || (workspace && workspace_floats >= ((M + 127) / 128) * N), "conv3x3: colsum_out needs a workspace");
+    VAW_CHECK_ARG(!colsum_out || (workspace && workspace_floats >= ((M + 127) / 128) * N), "conv3x3: colsum_out needs a workspace");
     hipStream_t s = (hipStream_t)stream;
     const int tiles_n = (int)((N + BN - 1) / BN);
     const int64_t n_wg = ((M + BM - 1) / BM) * tiles_n;
     const int nk_total = (int)(K / 64);
     const bool plain_f32 = mode == 2 && !e.bias && !e.act;
-    const bool bias_grad = mode == 2 && colsum_out;      // mode 2: colsum_out = sum over pixels of dy (row sums of A = dy^T)
+    float* rowsum_out = ep ? ep->rowsum_a_out : nullptr;
+    const float rowsum_beta = ep ? ep->rowsum_a_beta : 0.f;
+    VAW_CHECK_ARG(!rowsum_out || mode == 2, "conv3x3: rowsum_a_out (bias gradient) belongs to mode 2");
+    VAW_CHECK_ARG(!(colsum_out && mode == 2), "conv3x3: mode 2 takes rowsum_a_out, not colsum_out");
+    const bool bias_grad = rowsum_out != nullptr;        // sum over pixels of dy (row sums of A = dy^T)
     int split = (colsum_out && !bias_grad) ? 1 : pick_split(n_wg, K, M * N, workspace_floats - (bias_grad ? 64 * M : 0), plain_f32);
     if (colsum_out && !bias_grad) e.colpart = workspace;
     if (split > 1) {
@@ -1041,7 +1075,7 @@ extern "C" int vaw_conv3x3(vaw_dtype dt, int mode, const void* act, const void* 
         splitk_reduce_kernel<float><<<ceil_div(M * N / 4, 256) > 2048 ? 2048 : ceil_div(M * N / 4, 256), 256, 0, s>>>(
             workspace, split, M, N, ldc, out, e.alpha, e.beta, 1);
     VAW_CHECK_LAUNCH("conv3x3");
-    if (bias_grad) return vaw_reduce_rows(rowpart, split, M, colsum_out, colsum_beta, stream);
+    if (bias_grad) return vaw_reduce_rows(rowpart, split, M, rowsum_out, rowsum_beta, stream);
     if (colsum_out) return vaw_reduce_rows(workspace, (M + BM - 1) / BM, N, colsum_out, colsum_beta, stream);
     return VAW_OK;
 }

@@ -349,11 +349,10 @@ class DiT(FlatModule):
         return d
 
     def _wgrad(self, dt, name, dy, x, Nw, Kw, M, beta, bias=True):
-        """dW[Nw,Kw] (+)= dy[M,Nw]^T x[M,Kw];  db[Nw] (+)= colsum(dy) unless the producer of dy already
-        delivered it (bias=False).  name = '<module>.' prefix."""
-        ops.gemm(dt, 0, 0, Nw, Kw, M, dy, Nw, x, Kw, self._g(name + "weight"), Kw, beta=beta, out_f32=True)
-        if bias:
-            ops.colsum(dt, dy, M, Nw, Nw, self._g(name + "bias"), beta)
+        """dW[Nw,Kw] (+)= dy[M,Nw]^T x[M,Kw];  db[Nw] (+)= colsum(dy), on the same launch (row sums of the staged dy^T
+        tiles), unless the producer of dy already delivered it (bias=False).  name = '<module>.' prefix."""
+        ops.gemm(dt, 0, 0, Nw, Kw, M, dy, Nw, x, Kw, self._g(name + "weight"), Kw, beta=beta, out_f32=True,
+                 rowsum_a_out=self._g(name + "bias") if bias else None, rowsum_a_beta=beta)
 
     def _backward_impl(self, dout, need_dx):
         ws = self._ws_cur

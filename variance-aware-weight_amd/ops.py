@@ -119,17 +119,17 @@ def vb_terms(mean_out, var_out, x0, x_t, coef, mean_mode, var_mode, scale=1.0):
 # ---- dense -------------------------------------------------------------------------------------
 def gemm(dt, a_kmajor, b_kmajor, M, N, K, A, lda, B, ldb, Cp, ldc, *, bias=None, act=0, aux_in=None, aux_out=None,
          gate=None, gate_ld=0, resid=None, rowadd=None, rows_per_batch=0, alpha=1.0, beta=0.0, out_f32=False,
-         colsum_out=None, colsum_beta=0.0, resid_is_act=False):
+         colsum_out=None, colsum_beta=0.0, resid_is_act=False, rowsum_a_out=None, rowsum_a_beta=0.0):
     """Raw-pointer GEMM; A, B, Cp, bias... are integers (device addresses).  See vaw_gemm in the header."""
     e = Epilogue(bias or None, act, aux_in or None, aux_out or None, gate or None, gate_ld, resid or None,
                  rowadd or None, rows_per_batch, alpha, beta, 1 if out_f32 else 0, colsum_out or None, colsum_beta,
-                 1 if resid_is_act else 0)
+                 1 if resid_is_act else 0, rowsum_a_out or None, rowsum_a_beta)
     tr = gemm_trace
     if tr is not None:
         e0, e1 = tr.events()
         e0.record()
     ws_ptr, ws_n = 0, 0
-    if colsum_out or (out_f32 and beta_or_plain(bias, act, aux_out, gate, resid, rowadd) and K >= 2048):
+    if colsum_out or rowsum_a_out or (out_f32 and beta_or_plain(bias, act, aux_out, gate, resid, rowadd) and K >= 2048):
         ws = scratch_f32(torch.device("cuda", torch.cuda.current_device()), 0)
         ws_ptr, ws_n = ws.data_ptr(), ws.numel()
     check(L.lib().vaw_gemm(dt, 1 if a_kmajor else 0, 1 if b_kmajor else 0, M, N, K, A, lda, B, ldb, Cp, ldc,
@@ -145,11 +145,11 @@ def beta_or_plain(bias, act, aux_out, gate, resid, rowadd):
 
 
 def conv3x3(dt, mode, act, act2, w, out, B, H, W, Ci, Co, *, bias=None, resid=None, resid_is_act=True, beta=0.0,
-            colsum_out=None, colsum_beta=0.0):
+            colsum_out=None, colsum_beta=0.0, rowsum_a_out=None, rowsum_a_beta=0.0):
     """Implicit-GEMM conv3x3 (vaw_conv3x3).  Returns False -- nothing launched -- when the shape needs the explicit
     im2col + GEMM path.  mode 0 forward, 1 input gradient, 2 weight gradient (f32 out, beta accumulates)."""
     e = Epilogue(bias or None, 0, None, None, None, 0, resid or None, None, 0, 1.0, beta, 1 if mode == 2 else 0,
-                 colsum_out or None, colsum_beta, 1 if resid_is_act else 0)
+                 colsum_out or None, colsum_beta, 1 if resid_is_act else 0, rowsum_a_out or None, rowsum_a_beta)
     ws = scratch_f32(torch.device("cuda", torch.cuda.current_device()), 0)
     tr = gemm_trace
     if tr is not None:
@@ -195,7 +195,7 @@ gemm_trace = None
 
 def gemm_t(A, B, *, a_kmajor=True, b_kmajor=True, out_dtype=None, bias=None, act=0, aux_in=None, want_aux=False,
            gate=None, resid=None, rowadd=None, rows_per_batch=0, alpha=1.0, beta=0.0, out=None, colsum_out=None,
-           colsum_beta=0.0):
+           colsum_beta=0.0, rowsum_a_out=None, rowsum_a_beta=0.0):
     """Tensor-level GEMM for tests and small call sites: A, B 2-D contiguous, same dtype."""
     need_cuda(A, B)
     assert A.dim() == 2 and B.dim() == 2 and A.is_contiguous() and B.is_contiguous() and A.dtype == B.dtype
@@ -211,7 +211,8 @@ def gemm_t(A, B, *, a_kmajor=True, b_kmajor=True, out_dtype=None, bias=None, act
     gemm(dt, a_kmajor, b_kmajor, M, N, K, ptr(A), A.shape[1], ptr(B), B.shape[1], ptr(out), N, bias=ptr(bias), act=act,
          aux_in=ptr(aux_in), aux_out=ptr(aux), gate=ptr(gate), gate_ld=(gate.shape[-1] if gate is not None else 0),
          resid=ptr(resid), rowadd=ptr(rowadd), rows_per_batch=rows_per_batch, alpha=alpha, beta=beta,
-         out_f32=(out.dtype == torch.float32), colsum_out=ptr(colsum_out), colsum_beta=colsum_beta)
+         out_f32=(out.dtype == torch.float32), colsum_out=ptr(colsum_out), colsum_beta=colsum_beta,
+         rowsum_a_out=ptr(rowsum_a_out), rowsum_a_beta=rowsum_a_beta)
     return (out, aux) if want_aux else out
 
 

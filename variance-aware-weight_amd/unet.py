@@ -299,8 +299,8 @@ class UNetModel(FlatModule):
             gw, gb = self._g(name + ".weight"), self._g(name + ".bias")
             colb = None
             # the bias gradient rides on the implicit weight-gradient GEMM (row sums of the dy tiles it stages anyway)
-            fused = min(Ci, Co) > 4 and ops.conv3x3(dt, 2, ptr(dy), ptr(a.t), None, gw, *geo, beta=self._beta, colsum_out=gb,
-                                                    colsum_beta=self._beta)
+            fused = min(Ci, Co) > 4 and ops.conv3x3(dt, 2, ptr(dy), ptr(a.t), None, gw, *geo, beta=self._beta, rowsum_a_out=gb,
+                                                    rowsum_a_beta=self._beta)
             if not fused:
                 ops.colsum(dt, ptr(dy), M, Co, Co, gb, self._beta, device=self._flat.device)
                 if min(Ci, Co) <= 4:       # 3-channel stem / output conv: dedicated skinny weight-gradient kernel
@@ -341,8 +341,9 @@ class UNetModel(FlatModule):
 
         def bw():
             dy = y.grad
-            ops.gemm(dt, 0, 0, Co, Ci, M, ptr(dy), Co, ptr(a.t), Ci, self._g(wname), Ci, beta=self._beta, out_f32=True)
-            ops.colsum(dt, ptr(dy), M, Co, Co, self._g(bname), self._beta, device=self._flat.device)
+            # weight gradient; the bias gradient (row sums of dy^T) rides on the same launch
+            ops.gemm(dt, 0, 0, Co, Ci, M, ptr(dy), Co, ptr(a.t), Ci, self._g(wname), Ci, beta=self._beta, out_f32=True,
+                     rowsum_a_out=self._g(bname), rowsum_a_beta=self._beta)
             dx = self._new(M, Ci)
             ops.gemm(dt, 1, 0, M, Ci, Co, ptr(dy), Co, self._w(wname), Ci, ptr(dx), Ci)
             self._acc(a, dx)
