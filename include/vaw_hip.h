@@ -71,6 +71,15 @@ int vaw_vb_bwd(const float* mean_out, const float* var_out, const float* x0, con
                int mean_mode, int var_mode, float scale, const float* gvb, float* d_mean, float* d_var, int B,
                int64_t per_sample, vaw_stream stream);
 
+/* One reverse-process step of the sampling side, fused: p_mean_variance (gaussian_diffusion.py:278-384, no
+ * denoised_fn / cond_fn) followed by p_sample (:461-505, kind 1) or ddim_sample (:603-651, kind 2); kind 0 only
+ * fills pred_xstart / mean / log_variance.  coef: f32 [B][16] per-sample rows of the timestep tables (layout in
+ * csrc/elementwise.hip; built by vaw_amd.GaussianDiffusion._sample_table with the reference's f64 -> f32 casts).
+ * noise: the randn_like(x) draw of the step (caller's RNG).  Outputs may be NULL.  All f32 [B, per_sample]. */
+int vaw_sample_step(int kind, const float* mean_out, const float* var_out, const float* x, const float* noise,
+                    const float* coef, int mean_mode, int var_mode, int clip_denoised, float eta, float* sample,
+                    float* pred_xstart, float* mean, float* log_variance, int B, int64_t per_sample, vaw_stream stream);
+
 /* ---------------------------------------------------------------------------
  * Dense layers  (nn.Linear / Conv2d(k=p,s=p) / Conv1d(k=1) in models/dit.py, models/unet.py;
  * cuBLAS in the reference).  One GEMM entry point, MFMA inside.

@@ -10,6 +10,7 @@ Follows /root/reference/tools/gaussian_diffusion.py:
   * training_losses (MSE, learned-variance vb term, KL)  :834-930
   * q_posterior_mean_variance :254-276, p_mean_variance (training side) :278-384, _predict_xstart_* :386-410
   * _vb_terms_bpd             :775-808
+  * sampling: p_mean_variance :278-384, p_sample(+loops) :461-601, ddim_sample(+loops) :603-790 (no cond_fn)
 and tools/losses.py:12-76 (normal_kl, approx_standard_normal_cdf, discretized_gaussian_log_likelihood)
   * compute_mse_loss_weight   :1092-1148
   * FlowMatching training     :1151-1340
@@ -306,6 +307,112 @@ class GaussianDiffusion:
             raise NotImplementedError(mt)
         mean, _, _ = self.q_posterior_mean_variance(pred, x, t)
         return mean, log_var
+
+    # ---- sampling side (reference :278-384, :411-416, :461-560, :603-790) --------------------------------------
+    def p_mean_variance(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None):
+        """{mean, variance, log_variance, pred_xstart} of p(x_{t-1} | x_t)."""
+        model_kwargs = model_kwargs or {}
+        B, C = x.shape[:2]
+        assert t.shape == (B,)
+        out = model(x, self._scale_timesteps(t), **model_kwargs)
+        out = out[0] if isinstance(out, tuple) else out
+        mean_out = out
+        if self.model_var_type in (ModelVarType.LEARNED, ModelVarType.LEARNED_RANGE):
+            assert out.shape == (B, C * 2, *x.shape[2:])
+            mean_out = torch.split(out, C, dim=1)[0]
+        _, log_var = self._model_log_variance(out, x, t)
+
+        def process(v):
+            if denoised_fn is not None:
+                v = denoised_fn(v)
+            return v.clamp(-1, 1) if clip_denoised else v
+
+        mt = self.model_mean_type
+        if mt == ModelMeanType.PREVIOUS_X:
+            pred = process(extract(1.0 / self.posterior_mean_coef1, t, x.shape) * mean_out
+                           - extract(self.posterior_mean_coef2 / self.posterior_mean_coef1, t, x.shape) * x)
+            mean = mean_out
+        elif mt in (ModelMeanType.START_X, ModelMeanType.EPSILON):
+            if mt == ModelMeanType.START_X:
+                pred = process(mean_out)
+            else:
+                pred = process(extract(self.sqrt_recip_alphas_cumprod, t, x.shape) * x
+                               - extract(self.sqrt_recipm1_alphas_cumprod, t, x.shape) * mean_out)
+            mean, _, _ = self.q_posterior_mean_variance(pred, x, t)
+        elif mt == ModelMeanType.VELOCITY:
+            raise RuntimeError("VELOCITY: the reference's _predict_xstart_from_v fails to broadcast (:394-399)")
+        else:
+            raise NotImplementedError(mt)
+        assert mean.shape == log_var.shape == pred.shape == x.shape
+        return {"mean": mean, "variance": torch.exp(log_var), "log_variance": log_var, "pred_xstart": pred}
+
+    def _model_log_variance(self, model_output, x, t):
+        """(mean half of the output, log variance) -- the variance branch of p_mean_variance (:304-330)."""
+        B, C = x.shape[:2]
+        if self.model_var_type in (ModelVarType.LEARNED, ModelVarType.LEARNED_RANGE):
+            model_output, var_values = torch.split(model_output, C, dim=1)
+            if self.model_var_type == ModelVarType.LEARNED:
+                return model_output, var_values
+            min_log = extract(self.posterior_log_variance_clipped, t, x.shape)
+            max_log = extract(np.log(self.betas), t, x.shape)
+            frac = (var_values + 1) / 2
+            return model_output, frac * max_log + (1 - frac) * min_log
+        tab = {ModelVarType.FIXED_LARGE: np.log(np.append(self.posterior_variance[1], self.betas[1:])),
+               ModelVarType.FIXED_SMALL: self.posterior_log_variance_clipped}[self.model_var_type]
+        return model_output, extract(tab, t, x.shape)
+
+    def _predict_eps_from_xstart(self, x_t, t, pred_xstart):
+        return ((extract(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t - pred_xstart)
+                / extract(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape))
+
+    def p_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None):
+        out = self.p_mean_variance(model, x, t, clip_denoised=clip_denoised, denoised_fn=denoised_fn, model_kwargs=model_kwargs)
+        noise = torch.randn_like(x)
+        nonzero_mask = (t != 0).float().view(-1, *([1] * (len(x.shape) - 1)))
+        sample = out["mean"] + nonzero_mask * torch.exp(0.5 * out["log_variance"]) * noise
+        return {"sample": sample, "pred_xstart": out["pred_xstart"]}
+
+    def ddim_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None, eta=0.0):
+        out = self.p_mean_variance(model, x, t, clip_denoised=clip_denoised, denoised_fn=denoised_fn, model_kwargs=model_kwargs)
+        eps = self._predict_eps_from_xstart(x, t, out["pred_xstart"])
+        alpha_bar = extract(self.alphas_cumprod, t, x.shape)
+        alpha_bar_prev = extract(self.alphas_cumprod_prev, t, x.shape)
+        sigma = eta * torch.sqrt((1 - alpha_bar_prev) / (1 - alpha_bar)) * torch.sqrt(1 - alpha_bar / alpha_bar_prev)
+        noise = torch.randn_like(x)
+        mean_pred = out["pred_xstart"] * torch.sqrt(alpha_bar_prev) + torch.sqrt(1 - alpha_bar_prev - sigma ** 2) * eps
+        nonzero_mask = (t != 0).float().view(-1, *([1] * (len(x.shape) - 1)))
+        return {"sample": mean_pred + nonzero_mask * sigma * noise, "pred_xstart": out["pred_xstart"]}
+
+    def _loop(self, step, model, shape, noise, device, **kw):
+        img = noise if noise is not None else torch.randn(*shape, device=device)
+        for i in list(range(self.num_timesteps))[::-1]:
+            t = torch.tensor([i] * shape[0], device=device)
+            with torch.no_grad():
+                out = step(model, img, t, **kw)
+                yield out
+                img = out["sample"]
+
+    def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, model_kwargs=None,
+                                  device="cpu"):
+        return self._loop(self.p_sample, model, shape, noise, device, clip_denoised=clip_denoised, denoised_fn=denoised_fn,
+                          model_kwargs=model_kwargs)
+
+    def ddim_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, model_kwargs=None,
+                                     device="cpu", eta=0.0):
+        return self._loop(self.ddim_sample, model, shape, noise, device, clip_denoised=clip_denoised, denoised_fn=denoised_fn,
+                          model_kwargs=model_kwargs, eta=eta)
+
+    def p_sample_loop(self, model, shape, **kw):
+        final = None
+        for final in self.p_sample_loop_progressive(model, shape, **kw):
+            pass
+        return final["sample"]
+
+    def ddim_sample_loop(self, model, shape, **kw):
+        final = None
+        for final in self.ddim_sample_loop_progressive(model, shape, **kw):
+            pass
+        return final["sample"]
 
     def _vb_terms_bpd(self, model_output, x_start, x_t, t):
         """[N] bits per dim: KL(q(x_{t-1}|x_t,x_0) || p(x_{t-1}|x_t)) for t > 0, the decoder NLL at t = 0."""

@@ -86,3 +86,26 @@ class Pbar:
 
 def fake_model(x, t, **kw):
     return 0.5 * x + 1e-3 * t.view(-1, 1, 1, 1).float() + (0.01 * kw["y"].view(-1, 1, 1, 1).float() if "y" in kw else 0)
+
+
+def sampling_model(x, t, **kw):
+    """The stand-in denoiser of tests/golden/make_goldens.py::gen_sampling (same arithmetic, any device)."""
+    tt = t.float().view(-1, 1, 1, 1)
+    m = 0.6 * torch.tanh(x) + 0.1 * torch.sin(tt * 0.01)
+    if "y" in kw and kw["y"] is not None:
+        m = m + 0.02 * kw["y"].view(-1, 1, 1, 1).float()
+    return m
+
+
+def sampling_model_2c(x, t, **kw):
+    return torch.cat([sampling_model(x, t, **kw), 0.8 * torch.cos(3.0 * x)], dim=1)
+
+
+SAMPLING_CASES = [  # name, schedule, mean type, var type, respacing, kind, eta, clip_denoised
+    ("ddim25_eps_fixed", "cosine", "EPSILON", "FIXED_LARGE", "ddim25", "ddim", 0.0, True),
+    ("ddim10_eps_range_eta", "linear", "EPSILON", "LEARNED_RANGE", "10", "ddim", 0.7, True),
+    ("ddim20_x0_small_noclip", "cosine", "START_X", "FIXED_SMALL", "20", "ddim", 0.0, False),
+    ("p50_eps_range", "linear", "EPSILON", "LEARNED_RANGE", "50", "p", 0.0, True),
+    ("p20_x0_large", "cosine", "START_X", "FIXED_LARGE", "20", "p", 0.0, True),
+    ("p15_eps_learned", "cosine", "EPSILON", "LEARNED", "15", "p", 0.0, False),
+]

@@ -394,6 +394,68 @@ def gen_trainer_vb():
     json.dump(rec, open(os.path.join(HERE, "trainer_vb.json"), "w"), indent=1)
 
 
+def sampling_model(x, t, **kw):
+    """Deterministic stand-in denoiser for the sampling goldens: bounded, depends on x, t (as the wrapped model sees it) and y;
+    2C channels when asked (second half = variance values in [-1, 1])."""
+    tt = t.float().view(-1, 1, 1, 1)
+    m = 0.6 * torch.tanh(x) + 0.1 * torch.sin(tt * 0.01)
+    if "y" in kw and kw["y"] is not None:
+        m = m + 0.02 * kw["y"].view(-1, 1, 1, 1).float()
+    return m
+
+
+def sampling_model_2c(x, t, **kw):
+    m = sampling_model(x, t, **kw)
+    return torch.cat([m, 0.8 * torch.cos(3.0 * x)], dim=1)
+
+
+def gen_sampling(gd):
+    """Sampling side: space_timesteps, SpacedDiffusion wrapping, p_sample / ddim_sample loops with
+    the CPU RNG stream, IntervalCFG.  Reference: tools/respace.py, gaussian_diffusion.py:278-384,461-560,603-790,
+    tools/sampler.py:10-48."""
+    from tools import respace as R
+    from tools.sampler import IntervalCFG
+    out = {}
+    out["space"] = {str(k): sorted(R.space_timesteps(1000, k)) for k in ("ddim25", "ddim50", "10", "10,15,20", "250")}
+    out["space_300_10_15_20"] = sorted(R.space_timesteps(300, [10, 15, 20]))
+    shape = (3, 3, 8, 8)
+    y = torch.tensor([1, 5, 9])
+    res = {}
+    for name, sched, mt, vt, respacing, kind, eta, clip in [
+        ("ddim25_eps_fixed", "cosine", "EPSILON", "FIXED_LARGE", "ddim25", "ddim", 0.0, True),
+        ("ddim10_eps_range_eta", "linear", "EPSILON", "LEARNED_RANGE", "10", "ddim", 0.7, True),
+        ("ddim20_x0_small_noclip", "cosine", "START_X", "FIXED_SMALL", "20", "ddim", 0.0, False),
+        ("p50_eps_range", "linear", "EPSILON", "LEARNED_RANGE", "50", "p", 0.0, True),
+        ("p20_x0_large", "cosine", "START_X", "FIXED_LARGE", "20", "p", 0.0, True),
+        ("p15_eps_learned", "cosine", "EPSILON", "LEARNED", "15", "p", 0.0, False),
+    ]:
+        learned = vt.startswith("LEARNED")
+        d = R.SpacedDiffusion(use_timesteps=R.space_timesteps(1000, respacing), args=base_args(learn_sigma=learned, amp=False),
+                              betas=gd.get_named_beta_schedule(sched, 1000), model_mean_type=gd.ModelMeanType[mt],
+                              model_var_type=gd.ModelVarType[vt], loss_type=gd.LossType.MSE, rescale_timesteps=True, device="cpu")
+        model = sampling_model_2c if learned else sampling_model
+        torch.manual_seed(123)
+        loop = d.ddim_sample_loop_progressive if kind == "ddim" else d.p_sample_loop_progressive
+        kw = dict(clip_denoised=clip, model_kwargs={"y": y}, device="cpu")
+        if kind == "ddim":
+            kw["eta"] = eta
+        traj = [o["sample"].clone() for o in loop(model, shape, **kw)]
+        res[name] = {"final": traj[-1], "first": traj[0], "mid": traj[len(traj) // 2], "n": len(traj),
+                     "timestep_map": torch.tensor(d.timestep_map)}
+    out["loops"] = res
+    # IntervalCFG: guidance on/off by interval, null label = num_classes
+    x = torch.randn(4, 3, 8, 8, generator=torch.Generator().manual_seed(5))
+    yy = torch.tensor([0, 3, 7, 9])
+    cfg = {}
+    for nm, scale, interval, tval in [("plain", 1.0, (-1.0, -1.0), 500.0), ("always", 2.5, (-1.0, -1.0), 500.0),
+                                      ("inside", 1.8, (100.0, 600.0), 300.0), ("outside", 1.8, (100.0, 600.0), 800.0)]:
+        m = IntervalCFG(sampling_model, 10, scale, interval, True)
+        cfg[nm] = m(x, torch.full((4,), tval), y=yy)
+    out["cfg"] = cfg
+    out["cfg_x"], out["cfg_y"] = x, yy
+    torch.save(out, os.path.join(HERE, "sampling.pt"))
+
+
 def gen_misc():
     from tools.utils import warmup_cosine_lr
     from tools import resample as R
@@ -430,7 +492,7 @@ def main():
     from tools import gaussian_diffusion as gd
     jobs = {"tables": lambda: gen_tables(gd), "weights": lambda: gen_loss_weights(gd),
             "objective": lambda: gen_objective(gd), "dit": gen_dit_tiny, "unet": gen_unet_tiny, "misc": gen_misc,
-            "trainer": gen_trainer, "vb": lambda: gen_vb(gd), "trainer_vb": gen_trainer_vb}
+            "trainer": gen_trainer, "vb": lambda: gen_vb(gd), "trainer_vb": gen_trainer_vb, "sampling": lambda: gen_sampling(gd)}
     for name in (sys.argv[1:] or list(jobs)):
         jobs[name]()
         print("wrote", name)

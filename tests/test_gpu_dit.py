@@ -188,3 +188,31 @@ def test_full_batch_256_properties():
     sub = diff.training_losses(m, x0[idx], None, t=t[idx], model_kwargs={"y": y[idx]}, noise=noise[idx])
     torch.testing.assert_close(sub["mse"], t1["mse"][idx], rtol=1e-3, atol=1e-5)
     assert torch.isfinite(g1).all() and float(g1.abs().max()) > 0
+
+
+def test_ddim_sampling_with_cfg_hip_dit_vs_oracle_dit():
+    """Sampling side end to end: tiny DiT (class-conditional, null label) in eval mode under IntervalCFG, DDIM over a 12-step
+    respaced process -- the HIP model + vaw_sample_step against the oracle model + the oracle's restated sampler, same
+    weights, same CPU RNG stream, f32.  12 chained model calls: 1e-4 relative."""
+    from oracle import diffusion as od, dit as odit, respace as orsp, sampler as osam
+    kw = dict(image_size=8, patch_size=2, in_channels=4, hidden_size=64, depth=2, num_heads=2, class_dropout_prob=0.1,
+              num_classes=10, learn_sigma=True)
+    torch.manual_seed(3)
+    om = odit.DiT(**kw)
+    perturb_(om, 17)
+    hm = vaw_amd.DiT(compute_dtype="fp32", **kw)
+    hm.load_state_dict(om.state_dict())
+    hm = hm.to(DEV).eval()
+    om.eval()
+    shape, y = (4, 4, 8, 8), torch.tensor([0, 3, 7, 9])
+    res = []
+    for pkg, sp, cfgc, model, dev, amod in ((od, orsp, osam.IntervalCFG, om, "cpu", od), (vaw_amd, vaw_amd, vaw_amd.IntervalCFG, hm, DEV, vaw_amd)):
+        d = sp.SpacedDiffusion(use_timesteps=sp.space_timesteps(1000, "12"), args=base_args(learn_sigma=True, cpu_rng=True),
+                               betas=pkg.get_named_beta_schedule("cosine", 1000), model_mean_type=amod.ModelMeanType.EPSILON,
+                               model_var_type=amod.ModelVarType.LEARNED_RANGE, loss_type=amod.LossType.MSE, rescale_timesteps=True)
+        cfg = cfgc(model, 10, 2.0, (-1.0, -1.0), True).eval()
+        torch.manual_seed(77)
+        out = d.ddim_sample_loop(cfg, shape, model_kwargs={"y": y.to(dev)}, device=dev, eta=0.3)
+        res.append(out.cpu())
+    torch.testing.assert_close(res[1], res[0], rtol=1e-4, atol=1e-4)
+    assert float(res[0].abs().max()) > 0.1

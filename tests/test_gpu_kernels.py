@@ -97,6 +97,52 @@ def test_variational_bound_objectives_vs_reference_golden():
         torch.testing.assert_close(P.grad.cpu(), ref, rtol=1e-4, atol=1e-5 * float(ref.abs().max()), msg=key + "/dP")
 
 
+def test_sampling_side_vs_reference_golden():
+    """SpacedDiffusion + p_sample / ddim_sample loops on the fused vaw_sample_step kernel vs trajectories the unmodified
+    reference produced on CPU (tests/golden/sampling.pt); the stand-in denoiser runs in torch on the GPU, the per-step
+    noise comes from the CPU RNG stream (args.cpu_rng) exactly as the reference drew it.  10..50 chained steps."""
+    from conftest import SAMPLING_CASES, sampling_model, sampling_model_2c
+    g = load_pt("sampling.pt")
+    for k, v in g["space"].items():
+        assert sorted(vaw_amd.space_timesteps(1000, k)) == v, k
+    assert sorted(vaw_amd.space_timesteps(300, [10, 15, 20])) == g["space_300_10_15_20"]
+    with pytest.raises(ValueError):
+        vaw_amd.space_timesteps(1000, "ddim999")
+    shape, y = (3, 3, 8, 8), torch.tensor([1, 5, 9], device=DEV)
+    for name, sched, mt, vt, respacing, kind, eta, clip in SAMPLING_CASES:
+        learned = vt.startswith("LEARNED")
+        d = vaw_amd.SpacedDiffusion(use_timesteps=vaw_amd.space_timesteps(1000, respacing),
+                                    args=base_args(learn_sigma=learned, cpu_rng=True),
+                                    betas=vaw_amd.get_named_beta_schedule(sched, 1000), model_mean_type=vaw_amd.ModelMeanType[mt],
+                                    model_var_type=vaw_amd.ModelVarType[vt], loss_type=vaw_amd.LossType.MSE, rescale_timesteps=True)
+        exp = g["loops"][name]
+        assert d.timestep_map == exp["timestep_map"].tolist()
+        torch.manual_seed(123)
+        model = sampling_model_2c if learned else sampling_model
+        kw = dict(clip_denoised=clip, model_kwargs={"y": y}, device=DEV)
+        loop = d.ddim_sample_loop_progressive(model, shape, eta=eta, **kw) if kind == "ddim" else d.p_sample_loop_progressive(model, shape, **kw)
+        traj = [o["sample"].cpu() for o in loop]
+        assert len(traj) == exp["n"]
+        for k, v in (("first", traj[0]), ("mid", traj[len(traj) // 2]), ("final", traj[-1])):
+            torch.testing.assert_close(v, exp[k], rtol=1e-4, atol=1e-4, msg=f"{name}/{k}")
+    # p_mean_variance keys and shapes; unsupported hooks fail loudly
+    d = vaw_amd.GaussianDiffusion(args=base_args(), betas=vaw_amd.get_named_beta_schedule("linear", 100),
+                                  model_mean_type=vaw_amd.ModelMeanType.EPSILON, model_var_type=vaw_amd.ModelVarType.FIXED_SMALL,
+                                  loss_type=vaw_amd.LossType.MSE)
+    x = torch.randn(2, 3, 4, 4, device=DEV)
+    out = d.p_mean_variance(sampling_model, x, torch.tensor([0, 99], device=DEV))
+    assert set(out) == {"mean", "variance", "log_variance", "pred_xstart"} and out["mean"].shape == x.shape
+    assert float(out["pred_xstart"].abs().max()) <= 1.0
+    with pytest.raises(NotImplementedError):
+        d.p_sample(sampling_model, x, torch.tensor([0, 99], device=DEV), cond_fn=lambda *a: None)
+    # IntervalCFG on the GPU
+    xg, yy = g["cfg_x"].to(DEV), g["cfg_y"].to(DEV)
+    for nm, scale, interval, tval in [("plain", 1.0, (-1.0, -1.0), 500.0), ("always", 2.5, (-1.0, -1.0), 500.0),
+                                      ("inside", 1.8, (100.0, 600.0), 300.0), ("outside", 1.8, (100.0, 600.0), 800.0)]:
+        m = vaw_amd.IntervalCFG(sampling_model, 10, scale, interval, True)
+        torch.testing.assert_close(m(xg, torch.full((4,), tval, device=DEV), y=yy).cpu(), g["cfg"][nm], rtol=1e-5, atol=1e-6)
+
+
 def test_wmse_backward_matches_autograd():
     o, p = _pair("cosine", "VELOCITY", "min_snr_5")
     x0, noise = _rand(6, 3, 9, 5, seed=4), _rand(6, 3, 9, 5, seed=5)

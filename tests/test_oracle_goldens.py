@@ -243,6 +243,40 @@ def test_trainer_trajectories_learned_variance(name, make, args, loader, steps):
     assert esum == pytest.approx(exp["ema_abs_sum"], rel=1e-9)
 
 
+def test_sampling_side_vs_reference():
+    """space_timesteps, SpacedDiffusion + p_sample / ddim_sample loops under the CPU RNG stream, IntervalCFG
+    (tests/golden/sampling.pt, written by the unmodified reference)."""
+    from conftest import SAMPLING_CASES, sampling_model, sampling_model_2c
+    from oracle import respace as orsp, sampler as osam
+    g = load_pt("sampling.pt")
+    for k, v in g["space"].items():
+        assert sorted(orsp.space_timesteps(1000, k)) == v, k
+    assert sorted(orsp.space_timesteps(300, [10, 15, 20])) == g["space_300_10_15_20"]
+    with pytest.raises(ValueError):
+        orsp.space_timesteps(1000, "ddim999")
+    shape, y = (3, 3, 8, 8), torch.tensor([1, 5, 9])
+    for name, sched, mt, vt, respacing, kind, eta, clip in SAMPLING_CASES:
+        learned = vt.startswith("LEARNED")
+        d = orsp.SpacedDiffusion(use_timesteps=orsp.space_timesteps(1000, respacing), args=base_args(learn_sigma=learned),
+                                 betas=od.get_named_beta_schedule(sched, 1000), model_mean_type=od.ModelMeanType[mt],
+                                 model_var_type=od.ModelVarType[vt], loss_type=od.LossType.MSE, rescale_timesteps=True)
+        exp = g["loops"][name]
+        assert d.timestep_map == exp["timestep_map"].tolist()
+        torch.manual_seed(123)
+        kw = dict(clip_denoised=clip, model_kwargs={"y": y})
+        loop = d.ddim_sample_loop_progressive(sampling_model_2c if learned else sampling_model, shape, eta=eta, **kw) \
+            if kind == "ddim" else d.p_sample_loop_progressive(sampling_model_2c if learned else sampling_model, shape, **kw)
+        traj = [o["sample"] for o in loop]
+        assert len(traj) == exp["n"]
+        for k, v in (("first", traj[0]), ("mid", traj[len(traj) // 2]), ("final", traj[-1])):
+            assert torch.equal(v, exp[k]), (name, k)
+    x, yy = g["cfg_x"], g["cfg_y"]
+    for nm, scale, interval, tval in [("plain", 1.0, (-1.0, -1.0), 500.0), ("always", 2.5, (-1.0, -1.0), 500.0),
+                                      ("inside", 1.8, (100.0, 600.0), 300.0), ("outside", 1.8, (100.0, 600.0), 800.0)]:
+        m = osam.IntervalCFG(sampling_model, 10, scale, interval, True)
+        assert torch.equal(m(x, torch.full((4,), tval), y=yy), g["cfg"][nm]), nm
+
+
 def test_misc_lr_resampler_latent():
     rec = load_json("misc.json")
     for s, a, b, c in rec["lr"]:

@@ -56,6 +56,7 @@ _PROTOS = {
     "vaw_conv3x3": [_i, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, C.POINTER(Epilogue), _p, _l, _p],
     "vaw_vb_fwd": [_p, _p, _p, _p, _p, _i, _i, _f, _p, _i, _l, _p],
     "vaw_vb_bwd": [_p, _p, _p, _p, _p, _i, _i, _f, _p, _p, _p, _i, _l, _p],
+    "vaw_sample_step": [_i, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _i, _l, _p],
     "vaw_conv3x3_narrow": [_i, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "vaw_conv3x3_wgrad_small": [_i, _p, _p, _p, _f, _i, _i, _i, _i, _i, _p, _l, _p],
     "vaw_resample2": [_i, _p, _p, _i, _i, _i, _i, _i, _f, _p],

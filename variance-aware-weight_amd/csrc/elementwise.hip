@@ -253,6 +253,64 @@ extern "C" int vaw_vb_bwd(const float* mean_out, const float* var_out, const flo
 }
 
 // ---------------------------------------------------------------------------------------------
+// One reverse-process step (sampling side): p_mean_variance + p_sample / ddim_sample fused.
+// coef[b][16] = {pa, pb, c1, c2, plv, lv_aux, ra, rm1, sqrt_abp, s1, abp, is_t0, s2, -, -, -}:
+//   pred_xstart = pa*x + pb*mean_out (clamped to [-1,1] if clip), model mean = c1*pred + c2*x (or mean_out itself),
+//   eps = (ra*x - pred)/rm1, sigma = (eta*s1)*s2, ddim mean = pred*sqrt_abp + sqrt(1 - abp - sigma^2)*eps.
+// kind 0: no sample (p_mean_variance only)   1: ancestral p_sample   2: ddim_sample.  Outputs may be NULL.
+// ---------------------------------------------------------------------------------------------
+#define SS_NCOEF 16
+__global__ void sample_step_kernel(const float* __restrict__ mean_out, const float* __restrict__ var_out, const float* __restrict__ x,
+                                   const float* __restrict__ noise, const float* __restrict__ coef, int kind, int mean_mode,
+                                   int var_mode, int clip, float eta, float* __restrict__ sample, float* __restrict__ pred_out,
+                                   float* __restrict__ mean_o, float* __restrict__ logvar_o, int64_t n) {
+    const int b = blockIdx.y;
+    float c[SS_NCOEF];
+#pragma unroll
+    for (int i = 0; i < SS_NCOEF; ++i) c[i] = coef[b * SS_NCOEF + i];
+    const float mask = c[11] != 0.f ? 0.f : 1.f;
+    const float sigma = (eta * c[9]) * c[12];
+    const float ddim_c = sqrtf(1.f - c[10] - sigma * sigma);
+    const int64_t base = (int64_t)b * n;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float xv = x[base + i], m = mean_out[base + i];
+        float pred = c[0] * xv + c[1] * m;
+        if (clip) pred = fminf(fmaxf(pred, -1.f), 1.f);
+        float lv;
+        if (var_mode == 1) lv = var_out[base + i];
+        else if (var_mode == 2) { const float frac = (var_out[base + i] + 1.f) / 2.f; lv = frac * c[5] + (1.f - frac) * c[4]; }
+        else lv = c[5];
+        const float mean = mean_mode == 1 ? m : c[2] * pred + c[3] * xv;
+        if (pred_out) pred_out[base + i] = pred;
+        if (mean_o) mean_o[base + i] = mean;
+        if (logvar_o) logvar_o[base + i] = lv;
+        if (kind == 1) {
+            sample[base + i] = mean + (mask * expf(0.5f * lv)) * noise[base + i];
+        } else if (kind == 2) {
+            const float eps = (c[6] * xv - pred) / c[7];
+            const float mp = pred * c[8] + ddim_c * eps;
+            sample[base + i] = mp + (mask * sigma) * noise[base + i];
+        }
+    }
+}
+
+extern "C" int vaw_sample_step(int kind, const float* mean_out, const float* var_out, const float* x, const float* noise,
+                               const float* coef, int mean_mode, int var_mode, int clip_denoised, float eta, float* sample,
+                               float* pred_xstart, float* mean, float* log_variance, int B, int64_t per_sample,
+                               vaw_stream stream) {
+    VAW_CHECK_ARG(B > 0 && per_sample > 0 && mean_out && x && coef && kind >= 0 && kind <= 2, "sample_step: bad arguments");
+    VAW_CHECK_ARG((mean_mode == 0 || mean_mode == 1) && var_mode >= 0 && var_mode <= 2 && (var_mode == 0 || var_out),
+                  "sample_step: bad modes (learned variance needs var_out)");
+    VAW_CHECK_ARG(kind == 0 || (sample && noise), "sample_step: kind 1/2 need noise and sample");
+    int gx = stream_grid(per_sample, 256);
+    dim3 grid(gx > 64 ? 64 : gx, B);
+    sample_step_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(mean_out, var_out, x, noise, coef, kind, mean_mode, var_mode,
+                                                             clip_denoised, eta, sample, pred_xstart, mean, log_variance, per_sample);
+    VAW_CHECK_LAUNCH("sample_step");
+    return VAW_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Small conditioning-path kernels ([B, D]-sized)
 // ---------------------------------------------------------------------------------------------
 template <typename T>

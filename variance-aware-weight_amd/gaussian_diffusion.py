@@ -219,6 +219,125 @@ class GaussianDiffusion:
         return torch.stack([f(self.posterior_mean_coef1), f(self.posterior_mean_coef2), f(self.posterior_log_variance_clipped),
                             lv_aux, pa, pb, t0, torch.zeros(T)], dim=1).contiguous()
 
+    # ---- sampling side (reference :278-384, :461-601, :603-790; no denoised_fn / cond_fn) ----------------------
+    def _sample_table(self):
+        """[T, 16] f32 rows for vaw_sample_step.  Every entry is the reference's float64 table cast to f32 as
+        _extract_into_tensor does; products of tables (ddim sigma) are formed in f32 in the kernel, as the reference's
+        tensor ops do."""
+        f = lambda arr: torch.from_numpy(np.asarray(arr, dtype=np.float64)).float()
+        T = self.num_timesteps
+        vt, mt = self.model_var_type, self.model_mean_type
+        if vt == ModelVarType.FIXED_LARGE:
+            lv_aux = f(np.log(np.append(self.posterior_variance[1], self.betas[1:])))
+        elif vt == ModelVarType.FIXED_SMALL:
+            lv_aux = f(self.posterior_log_variance_clipped)
+        else:
+            lv_aux = f(np.log(self.betas))
+        ra, rm1 = f(self.sqrt_recip_alphas_cumprod), f(self.sqrt_recipm1_alphas_cumprod)
+        if mt == ModelMeanType.EPSILON:
+            pa, pb = ra, -rm1
+        elif mt == ModelMeanType.PREVIOUS_X:                      # (xprev - coef2*x_t) / coef1  (:401-409)
+            pa, pb = -f(self.posterior_mean_coef2 / self.posterior_mean_coef1), f(1.0 / self.posterior_mean_coef1)
+        else:
+            pa, pb = torch.zeros(T), torch.ones(T)
+        ab, abp = f(self.alphas_cumprod), f(self.alphas_cumprod_prev)
+        s1, s2 = torch.sqrt((1 - abp) / (1 - ab)), torch.sqrt(1 - ab / abp)      # ddim sigma = eta * s1 * s2 (:636-640)
+        t0 = torch.zeros(T)
+        t0[0] = 1.0
+        z = torch.zeros(T)
+        return torch.stack([pa, pb, f(self.posterior_mean_coef1), f(self.posterior_mean_coef2),
+                            f(self.posterior_log_variance_clipped), lv_aux, ra, rm1, torch.sqrt(abp), s1, abp, t0, s2, z, z, z],
+                           dim=1).contiguous()
+
+    def _reverse_step(self, kind, model, x, t, clip_denoised, denoised_fn, cond_fn, model_kwargs, eta=0.0, want_all=False):
+        if denoised_fn is not None or cond_fn is not None:
+            raise NotImplementedError("denoised_fn / cond_fn (classifier guidance) are out of scope (SURVEY.md §2)")
+        mt, vt = self.model_mean_type, self.model_var_type
+        if mt == ModelMeanType.VELOCITY:
+            raise RuntimeError("VELOCITY: the reference's _predict_xstart_from_v fails to broadcast (:394-399)")
+        if mt not in (ModelMeanType.EPSILON, ModelMeanType.START_X, ModelMeanType.PREVIOUS_X):
+            raise NotImplementedError(mt)
+        B, C = x.shape[:2]
+        assert t.shape == (B,)
+        out = model(x, self._scale_timesteps(t), **(model_kwargs or {}))
+        out = out[0] if isinstance(out, tuple) else out
+        var_out = None
+        if vt in (ModelVarType.LEARNED, ModelVarType.LEARNED_RANGE):
+            assert out.shape == (B, C * 2, *x.shape[2:])
+            out, var_out = torch.split(out, C, dim=1)
+        assert out.shape == x.shape
+        key = "ss"
+        tb = self._tables(x.device)
+        if key not in tb:
+            tb[key] = self._sample_table().to(x.device)
+        noise = None
+        if kind:
+            if getattr(self.args, "cpu_rng", False):
+                noise = torch.randn(x.shape, dtype=torch.float32).to(x.device)     # the reference's CPU stream (parity runs)
+            else:
+                noise = torch.randn_like(x)
+        var_mode = {ModelVarType.LEARNED: 1, ModelVarType.LEARNED_RANGE: 2}.get(vt, 0)
+        return ops.sample_step(kind, out, var_out, x, noise, tb[key][t], 1 if mt == ModelMeanType.PREVIOUS_X else 0, var_mode,
+                               clip_denoised, eta, want_all)
+
+    def p_mean_variance(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None):
+        r = self._reverse_step(0, model, x, t, clip_denoised, denoised_fn, None, model_kwargs, want_all=True)
+        return {"mean": r["mean"], "variance": torch.exp(r["log_variance"]), "log_variance": r["log_variance"],
+                "pred_xstart": r["pred_xstart"]}
+
+    def p_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None):
+        return self._reverse_step(1, model, x, t, clip_denoised, denoised_fn, cond_fn, model_kwargs)
+
+    def ddim_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None, eta=0.0):
+        return self._reverse_step(2, model, x, t, clip_denoised, denoised_fn, cond_fn, model_kwargs, eta=eta)
+
+    def _loop(self, step, model, shape, noise, device, progress, **kw):
+        if device is None:
+            device = next(model.parameters()).device
+        assert isinstance(shape, (tuple, list))
+        if noise is not None:
+            img = noise
+        elif getattr(self.args, "cpu_rng", False):
+            img = torch.randn(*shape).to(device)
+        else:
+            img = torch.randn(*shape, device=device)
+        indices = list(range(self.num_timesteps))[::-1]
+        if progress:
+            from tqdm.auto import tqdm
+            indices = tqdm(indices)
+        for i in indices:
+            t = torch.full((shape[0],), i, device=device, dtype=torch.long)
+            with torch.no_grad():
+                out = step(model, img, t, **kw)
+                yield out
+                img = out["sample"]
+
+    def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                                  model_kwargs=None, device=None, progress=False):
+        return self._loop(self.p_sample, model, shape, noise, device, progress, clip_denoised=clip_denoised,
+                          denoised_fn=denoised_fn, cond_fn=cond_fn, model_kwargs=model_kwargs)
+
+    def p_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,
+                      device=None, progress=False):
+        final = None
+        for final in self.p_sample_loop_progressive(model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs,
+                                                    device, progress):
+            pass
+        return final["sample"]
+
+    def ddim_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                                     model_kwargs=None, device=None, progress=False, eta=0.0):
+        return self._loop(self.ddim_sample, model, shape, noise, device, progress, clip_denoised=clip_denoised,
+                          denoised_fn=denoised_fn, cond_fn=cond_fn, model_kwargs=model_kwargs, eta=eta)
+
+    def ddim_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,
+                         device=None, progress=False, eta=0.0):
+        final = None
+        for final in self.ddim_sample_loop_progressive(model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs,
+                                                       device, progress, eta):
+            pass
+        return final["sample"]
+
     def _vb_terms_bpd(self, mean_out, var_out, x_start, x_t, t, scale=1.0):
         """reference :775-808 on the fused kernel.  mean_out / var_out: the two halves of the model output."""
         mt, vt = self.model_mean_type, self.model_var_type

@@ -116,6 +116,28 @@ def vb_terms(mean_out, var_out, x0, x_t, coef, mean_mode, var_mode, scale=1.0):
                           int(mean_mode), int(var_mode), float(scale))
 
 
+def sample_step(kind, mean_out, var_out, x, noise, coef, mean_mode, var_mode, clip_denoised, eta=0.0, want_all=False):
+    """One reverse-process step (vaw_sample_step): kind 0 = p_mean_variance only, 1 = p_sample, 2 = ddim_sample.
+    Returns {"sample", "pred_xstart"} (+ "mean", "log_variance" with want_all)."""
+    need_cuda(mean_out, x, coef)
+    mean_out, x = mean_out.contiguous().float(), x.contiguous().float()
+    var_out = None if var_out is None else var_out.contiguous().float()
+    noise = None if noise is None else noise.contiguous().float()
+    coef = coef.contiguous()
+    B = x.shape[0]
+    assert mean_out.shape == x.shape and coef.shape == (B, 16) and coef.dtype == torch.float32
+    res = {"pred_xstart": torch.empty_like(x)}
+    if kind:
+        res["sample"] = torch.empty_like(x)
+    if want_all:
+        res["mean"], res["log_variance"] = torch.empty_like(x), torch.empty_like(x)
+    check(L.lib().vaw_sample_step(kind, ptr(mean_out), ptr(var_out), ptr(x), ptr(noise), ptr(coef), int(mean_mode), int(var_mode),
+                                  1 if clip_denoised else 0, float(eta), ptr(res.get("sample")), ptr(res["pred_xstart"]),
+                                  ptr(res.get("mean")), ptr(res.get("log_variance")), B, x.numel() // B, stream_ptr()),
+          "vaw_sample_step")
+    return res
+
+
 # ---- dense -------------------------------------------------------------------------------------
 def gemm(dt, a_kmajor, b_kmajor, M, N, K, A, lda, B, ldb, Cp, ldc, *, bias=None, act=0, aux_in=None, aux_out=None,
          gate=None, gate_ld=0, resid=None, rowadd=None, rows_per_batch=0, alpha=1.0, beta=0.0, out_f32=False,
