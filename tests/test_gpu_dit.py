@@ -216,3 +216,21 @@ def test_ddim_sampling_with_cfg_hip_dit_vs_oracle_dit():
         res.append(out.cpu())
     torch.testing.assert_close(res[1], res[0], rtol=1e-4, atol=1e-4)
     assert float(res[0].abs().max()) > 0.1
+
+
+def test_device_prefetcher_feeds_trainer():
+    """Pinned host -> device copies on a side stream: same batches, same order, and the Trainer trajectory is unchanged."""
+    cpu_batches = synth_loader(8, 8, 8, 3, 10, latent=True)
+    pf = vaw_amd.DevicePrefetcher(cpu_batches, DEV, depth=2)
+    for _ in range(2):
+        got = list(pf)
+        assert len(got) == len(cpu_batches)
+        for (gx, gy), (x, y) in zip(got, cpu_batches):
+            assert gx.is_cuda and torch.equal(gx.cpu(), x) and torch.equal(gy.cpu(), y)
+    exp = load_json("trainer.json")["dit_tiny_latent"]
+    args = base_args(in_chans=4, class_cond=True, dataset="Latent", image_size=8, lr=1e-3, cpu_rng=True)
+    random.seed(42); np.random.seed(42); torch.manual_seed(42)
+    model = vaw_amd.DiT(image_size=8, patch_size=2, in_channels=4, hidden_size=64, depth=2, num_heads=2,
+                        class_dropout_prob=0.0, num_classes=10, learn_sigma=False, compute_dtype="fp32").to(DEV)
+    losses, _, _ = _run_trainer(model, args, vaw_amd.DevicePrefetcher(synth_loader(8, 8, 8, 3, 10, latent=True), DEV), 6, True)
+    np.testing.assert_allclose(losses, exp["losses"], rtol=1e-4)

@@ -245,3 +245,15 @@ def test_checkpoint_roundtrip_and_module_prefix(tmp_path):
     a = torch.rand(3)
     vaw_amd.set_random_seed(args, 5)
     assert torch.equal(a, torch.rand(3))
+
+
+def test_device_prefetcher_cpu_passthrough():
+    """On CPU the prefetcher is a transparent, re-iterable wrapper that keeps batch order and the sampler handle."""
+    class _L(list):
+        sampler = "S"
+    batches = _L((torch.full((2, 3), float(i)), torch.tensor([i, i])) for i in range(5))
+    pf = vaw_amd.DevicePrefetcher(batches, "cpu", depth=2)
+    for _ in range(2):                                   # re-iterable
+        got = list(pf)
+        assert len(got) == 5 and all(torch.equal(g[0], b[0]) and torch.equal(g[1], b[1]) for g, b in zip(got, batches))
+    assert pf.sampler == "S" and len(pf) == 5
