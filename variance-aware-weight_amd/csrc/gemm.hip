@@ -37,6 +37,7 @@ struct EpiDev {
     void* C;
     float* slab;   // split-K partial sums [n_split][M][N] f32 (workspace), or NULL
     int debug;        // measurement only (VAW_GEMM_DEBUG): 1 = skip the epilogue, 2 = skip the K loop (ablations 3-5 of DESIGN.md §5 lived here)
+    int direct_epi;   // 1: register-direct epilogue (default), 0: LDS-staged (VAW_GEMM_EPI=0; always for fused column sums)
     float* rowpart;   // mn-major A only (CONV 3 / plain weight gradients): [n_split][M] f32 partial row sums of A = dy^T
                       // over this split's K range (the layer's bias gradient)
     float* colpart;   // [M/128][N] f32: per-row-tile column sums of the OUTPUT (bias gradient of the next layer), or NULL
@@ -134,6 +135,38 @@ __device__ __forceinline__ void epi_row8(const EpiDev& e, unsigned m, int64_t n,
         nt_store(c, r);
         v0 = f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};   // what a later reader of C sees
         v1 = f32x4{(float)r[4], (float)r[5], (float)r[6], (float)r[7]};
+    }
+}
+
+// Four consecutive columns n..n+3 of row m straight from a TRANSPOSED accumulator tile (the MFMA is issued with its
+// operands swapped, so a lane holds 4 consecutive columns of one row): the direct epilogue, no LDS round trip.
+__device__ __forceinline__ void epi_row4(const EpiDev& e, unsigned m, int64_t n, f32x4 v, f32x4 b) {
+    const int64_t off = (int64_t)m * e.ldc + n;
+    v = v * e.alpha + b;
+    if (e.aux_out) {
+        const bf16x4 r = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        __builtin_nontemporal_store(r, reinterpret_cast<bf16x4*>((bf16_t*)e.aux_out + off));
+        v = f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+    }
+    if (e.act == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = gelu_tanh_f(v[j]);
+    } else if (e.act == 2) {
+        const f32x4 h = load4((const bf16_t*)e.aux_in + off);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= gelu_tanh_grad_f(h[j]);
+    }
+    const unsigned rpb = (unsigned)e.rpb;
+    if (e.gate) v *= load4(e.gate + (int64_t)(m / rpb) * e.gate_ld + n);
+    if (e.resid) v += e.resid_act ? load4((const bf16_t*)e.resid + off) : load4((const float*)e.resid + off);
+    if (e.rowadd) v += load4(e.rowadd + (int64_t)(m % rpb) * e.N + n);
+    if (e.out_f32) {
+        float* c = (float*)e.C + off;
+        if (e.beta != 0.f) v += e.beta * load4(c);
+        nt_store(c, v);
+    } else {
+        const bf16x4 r = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        __builtin_nontemporal_store(r, reinterpret_cast<bf16x4*>((bf16_t*)e.C + off));
     }
 }
 
@@ -408,24 +441,24 @@ gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __rest
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-                if (RS) {     // A . ones: every column of the 16 x 16 result is the row sum
+                        // operands swapped: the tile is accumulated TRANSPOSED (lane l: row m = l&15, columns 4(l>>4)..+3),
+                        // so the epilogue finds 4 consecutive output columns in one register quad
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                if (RS) {     // ones . A^T: every row of the 16 x 16 result holds the row sums of A
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) accr[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones8, accr[i], 0, 0, 0);
+                    for (int i = 0; i < 4; ++i) accr[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones8, af[i], accr[i], 0, 0, 0);
                 }
             }
         }
     };
     if (CAN_ROWSUM && do_rowsum) k_loop(std::true_type{});
     else k_loop(std::false_type{});
-    if (CAN_ROWSUM && do_rowsum && (lane & 15) == 0) {
+    if (CAN_ROWSUM && do_rowsum && lane < 16) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = wm + 16 * i + 4 * (lane >> 4) + r;
-                if (row < mvalid) e.rowpart[(int64_t)split_idx * e.M + m0 + row] = accr[i][r];
-            }
+        for (int i = 0; i < 4; ++i) {
+            const int row = wm + 16 * i + lane;
+            if (row < mvalid) e.rowpart[(int64_t)split_idx * e.M + m0 + row] = accr[i][0];
+        }
     }
     if (e.debug == 1) {   // keep the accumulators alive with one store per wave-quadrant
         float t = 0.f;
@@ -434,6 +467,28 @@ gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __rest
 #pragma unroll
             for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
         if (t == 12345.678f) ((float*)e.C)[0] = t;
+        return;
+    }
+    // ---- direct epilogue: every lane owns rows (l&15) of its 4 m-tiles and 4 consecutive columns per n-tile ----
+    // (measured: a win only for the f32 split-K partials -- 16 B per lane, 64-B row segments; bf16 outputs written 8 B
+    //  per lane in 32-B segments ran 1.5-2x slower than the LDS-staged 16-B rows below, so those keep the staging)
+    if (e.direct_epi && !e.colpart && n_split > 1) {
+        if (!wave_live) return;
+        const int g4 = 4 * (lane >> 4), lr = lane & 15;
+        float* slab = n_split > 1 ? e.slab + (int64_t)split_idx * e.M * e.N : nullptr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = wn + 16 * j + g4;
+            if (col >= nvalid) continue;
+            const f32x4 bj = (e.bias && n_split == 1) ? load4(e.bias + n0 + col) : f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = wm + 16 * i + lr;
+                if (row >= mvalid) continue;
+                if (n_split > 1) store4(slab + (m0 + row) * e.N + n0 + col, acc[i][j]);
+                else epi_row4(e, (unsigned)(m0 + row), n0 + col, acc[i][j], bj);
+            }
+        }
         return;
     }
     // ---- epilogue in two 64-row halves: accumulators -> f32 staging image in LDS (the operand tiles are dead),
@@ -455,9 +510,7 @@ gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __rest
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        cs[(16 * i + 4 * (lane >> 4) + r) * CS_LD + wn + 16 * j + (lane & 15)] = acc[i][j][r];
+                    store4(cs + (16 * i + (lane & 15)) * CS_LD + wn + 16 * j + 4 * (lane >> 4), acc[i][j]);
         }
         __syncthreads();
         if (n_split > 1) {
@@ -851,6 +904,9 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
         static int dbg = -1;
         if (dbg < 0) { const char* v = getenv("VAW_GEMM_DEBUG"); dbg = v ? atoi(v) : 0; }
         e.debug = dbg;
+        static int depi = -1;
+        if (depi < 0) { const char* v = getenv("VAW_GEMM_EPI"); depi = v ? atoi(v) : 1; }
+        e.direct_epi = depi;
     }
     hipStream_t s = (hipStream_t)stream;
     const bool plain_f32 = e.out_f32 && !e.bias && !e.act && !e.aux_out && !e.gate && !e.resid && !e.rowadd && N % 4 == 0 &&
@@ -1021,6 +1077,11 @@ extern "C" int vaw_conv3x3(vaw_dtype dt, int mode, const void* act, const void* 
         e.alpha = ep->alpha; e.beta = ep->beta; e.out_f32 = ep->out_f32; e.resid_act = ep->resid_is_act;
     }
     if (e.rpb <= 0) e.rpb = 1;
+    {
+        static int depi = -1;
+        if (depi < 0) { const char* v = getenv("VAW_GEMM_EPI"); depi = v ? atoi(v) : 1; }
+        e.direct_epi = depi;
+    }
     if (mode == 2) e.out_f32 = 1;
     VAW_CHECK_ARG(e.beta == 0.f || e.out_f32, "conv3x3: beta needs f32 output");
     float* colsum_out = ep ? ep->colsum_out : nullptr;
