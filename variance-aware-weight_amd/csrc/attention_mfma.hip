@@ -322,6 +322,133 @@ attn_bwd_dkv_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __
 }
 
 // ------------------------------------------------------------------------------------------------
+// backward for T == 64 (DiT-B/4's 8x8 patch grid): one workgroup per (sample, head) holds all of Q, K, V, dO, so
+// delta, dQ, dK and dV come from ONE launch and one set of loads (the two kernels above each re-stage everything and
+// are latency-bound at this size).  Phase 1 = attn_bwd_dq_mfma's body, phase 2 = attn_bwd_dkv_mfma's, lse / delta
+// handed over through LDS.
+// ------------------------------------------------------------------------------------------------
+template <int HD>
+__global__ void __launch_bounds__(256)
+attn_bwd_t64_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                  const bf16_t* __restrict__ o, const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
+                  float* __restrict__ delta_out, bf16_t* __restrict__ dq, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 images of 64 x HD bf16 + lse / delta
+    constexpr int KS = HD / 32, DT = HD / 16;
+    char* qimg = smem;
+    char* gimg = qimg + 64 * 2 * HD;
+    char* kimg = gimg + 64 * 2 * HD;
+    char* vimg = kimg + 64 * 2 * HD;
+    float* lse_s = reinterpret_cast<float*>(vimg + 64 * 2 * HD);
+    float* del_s = lse_s + 64;
+    const int lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
+    const int64_t base = b * a.q_sb + h * a.q_sh, obase = b * a.o_sb + h * a.o_sh;
+    stage_block<HD>(q + base, a.q_st, qimg, wid, lane, a.hd);
+    stage_block<HD>(d_o + obase, a.o_st, gimg, wid, lane, a.hd);
+    stage_block<HD>(k + base, a.q_st, kimg, wid, lane, a.hd);
+    stage_block<HD>(v + base, a.q_st, vimg, wid, lane, a.hd);
+    const int qi = 16 * wid + li;
+    float dl = 0.f;
+    {
+        const bf16_t* gp = d_o + obase + (int64_t)qi * a.o_st + g * (HD / 4);
+        const bf16_t* op = o + obase + (int64_t)qi * a.o_st + g * (HD / 4);
+#pragma unroll
+        for (int d = 0; d < HD / 4; d += 4) {
+            if (g * (HD / 4) + d >= a.hd) continue;
+            const f32x4 x = load4(gp + d), y = load4(op + d);
+            dl += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+        }
+        dl = group_sum(dl);
+    }
+    const float li_lse = lse[(int64_t)bh * 64 + qi];
+    if (g == 0) {
+        delta_out[(int64_t)bh * 64 + qi] = dl;
+        lse_s[qi] = li_lse;
+        del_s[qi] = dl;
+    }
+    DMA_WAIT_SYNC();
+    // ---- phase 1: dQ of this wave's 16 queries ----
+    {
+        bf16x8 qf[KS], gf[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            qf[s] = frag_rows<HD>(qimg, 16 * wid, s, lane);
+            gf[s] = frag_rows<HD>(gimg, 16 * wid, s, lane);
+        }
+        f32x4 ds[4], acc[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) acc[dt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            f32x4 c = {0, 0, 0, 0}, d = {0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                c = MFMA(frag_rows<HD>(kimg, 16 * jt, s, lane), qf[s], c);
+                d = MFMA(frag_rows<HD>(vimg, 16 * jt, s, lane), gf[s], d);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ds[jt][r] = a.scale * __expf(c[r] * a.scale - li_lse) * (d[r] - dl);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 sf = pack_acc(ds[2 * s2], ds[2 * s2 + 1]);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) acc[dt] = MFMA(frag_cols_perm<HD>(kimg, 16 * dt, 32 * s2, lane), sf, acc[dt]);
+        }
+        bf16_t* row = dq + base + (int64_t)qi * a.q_st + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+            if (16 * dt + 4 * g < a.hd) store4(row + 16 * dt, acc[dt]);
+    }
+    // ---- phase 2: dK, dV of this wave's 16 keys (all four images stay as staged; lse_s / del_s were written before the sync) ----
+    {
+        bf16x8 kf[KS], vf[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            kf[s] = frag_rows<HD>(kimg, 16 * wid, s, lane);
+            vf[s] = frag_rows<HD>(vimg, 16 * wid, s, lane);
+        }
+        f32x4 p[4], ds[4], av[DT], ak[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) av[dt] = ak[dt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            f32x4 c = {0, 0, 0, 0}, d = {0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                c = MFMA(frag_rows<HD>(qimg, 16 * it, s, lane), kf[s], c);
+                d = MFMA(frag_rows<HD>(gimg, 16 * it, s, lane), vf[s], d);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * it + 4 * g + r;
+                const float pr = __expf(c[r] * a.scale - lse_s[i]);
+                p[it][r] = pr;
+                ds[it][r] = a.scale * pr * (d[r] - del_s[i]);
+            }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 pf = pack_acc(p[2 * s2], p[2 * s2 + 1]);
+            const bf16x8 sf = pack_acc(ds[2 * s2], ds[2 * s2 + 1]);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                av[dt] = MFMA(frag_cols_perm<HD>(gimg, 16 * dt, 32 * s2, lane), pf, av[dt]);
+                ak[dt] = MFMA(frag_cols_perm<HD>(qimg, 16 * dt, 32 * s2, lane), sf, ak[dt]);
+            }
+        }
+        const int64_t off = base + (int64_t)(16 * wid + li) * a.q_st + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            if (16 * dt + 4 * g >= a.hd) continue;
+            store4(dv + off + 16 * dt, av[dt]);
+            store4(dk + off + 16 * dt, ak[dt]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host dispatch (called from attention.hip)
 // ------------------------------------------------------------------------------------------------
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -363,6 +490,16 @@ int vaw_attn_bwd_mfma(const vaw_attn_desc* d, const void* q, const void* k, cons
                       const float* lse, float* delta, void* dq, void* dk, void* dv, hipStream_t s) {
     AttnMfmaArgs a = mk_args(d);
     dim3 grid(d->T / 64, d->B * d->H);
+    if (d->T == 64) {      // single block of queries and keys: one fused launch
+        DISPATCH_HD(d->hd,
+            const int lds = 4 * 64 * 2 * HD + 2 * 64 * 4;
+            (void)hipFuncSetAttribute((const void*)attn_bwd_t64_mfma<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            attn_bwd_t64_mfma<HD><<<d->B * d->H, 256, lds, s>>>(a, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o,
+                                                              (const bf16_t*)d_o, lse, delta, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv);
+        )
+        VAW_CHECK_LAUNCH("attn_bwd_t64_mfma");
+        return VAW_OK;
+    }
     DISPATCH_HD(d->hd,
         const int lds = 4 * 64 * 2 * HD + 2 * 64 * 4;
         (void)hipFuncSetAttribute((const void*)attn_bwd_dq_mfma<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
