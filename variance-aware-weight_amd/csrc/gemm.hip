@@ -723,9 +723,19 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __
 }
 
 // out = beta*C + alpha * sum_s slab[s], fixed order (deterministic split-K).  N % 4 == 0.
+// The LAST workgroup also folds the [S][M] partial row sums of A (bias gradient), when given: one launch fewer.
 template <typename TO>
 __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int S, int64_t M, int64_t N, int64_t ldc,
-                                     void* __restrict__ C, float alpha, float beta, int out_f32) {
+                                     void* __restrict__ C, float alpha, float beta, int out_f32,
+                                     const float* __restrict__ rowpart = nullptr, float* __restrict__ rowsum_out = nullptr,
+                                     float rowsum_beta = 0.f) {
+    if (rowpart && blockIdx.x == gridDim.x - 1) {
+        for (int64_t m = threadIdx.x; m < M; m += blockDim.x) {
+            float t = 0.f;
+            for (int sidx = 0; sidx < S; ++sidx) t += rowpart[(int64_t)sidx * M + m];
+            rowsum_out[m] = (rowsum_beta != 0.f ? rowsum_beta * rowsum_out[m] : 0.f) + t;
+        }
+    }
     const int64_t total4 = M * N / 4;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t m = (4 * i) / N, n = (4 * i) % N;
@@ -1003,12 +1013,12 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
         else LAUNCH_FAST_BK(64);
         if (split > 1)
             splitk_reduce_kernel<float><<<ceil_div(M * N / 4, 256) > 2048 ? 2048 : ceil_div(M * N / 4, 256), 256, 0, s>>>(
-                workspace, split, M, N, ldc, C, e.alpha, e.beta, 1);
+                workspace, split, M, N, ldc, C, e.alpha, e.beta, 1, rowpart, rowsum_out, rowsum_beta);
         VAW_CHECK_LAUNCH("gemm_bf16");
-        if (fused_rowsum) {
+        if (fused_rowsum && split == 1) {
             const int rc = vaw_reduce_rows(rowpart, split, M, rowsum_out, rowsum_beta, stream);
             if (rc != VAW_OK) return rc;
-        } else if (rowsum_out) {
+        } else if (rowsum_out && !fused_rowsum) {
             const int rc = rowsum_a_separate(dt, a_kmajor, M, K, A, lda, rowsum_out, rowsum_beta, workspace, workspace_floats, stream);
             if (rc != VAW_OK) return rc;
         }
@@ -1134,9 +1144,9 @@ extern "C" int vaw_conv3x3(vaw_dtype dt, int mode, const void* act, const void* 
     else LAUNCH_CONV(false, false, 3, act, (int64_t)Co, act2, (int64_t)Ci);
     if (split > 1)
         splitk_reduce_kernel<float><<<ceil_div(M * N / 4, 256) > 2048 ? 2048 : ceil_div(M * N / 4, 256), 256, 0, s>>>(
-            workspace, split, M, N, ldc, out, e.alpha, e.beta, 1);
+            workspace, split, M, N, ldc, out, e.alpha, e.beta, 1, rowpart, rowsum_out, rowsum_beta);
     VAW_CHECK_LAUNCH("conv3x3");
-    if (bias_grad) return vaw_reduce_rows(rowpart, split, M, rowsum_out, rowsum_beta, stream);
+    if (bias_grad && split == 1) return vaw_reduce_rows(rowpart, split, M, rowsum_out, rowsum_beta, stream);
     if (colsum_out) return vaw_reduce_rows(workspace, (M + BM - 1) / BM, N, colsum_out, colsum_beta, stream);
     return VAW_OK;
 }
