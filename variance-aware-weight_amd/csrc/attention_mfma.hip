@@ -93,26 +93,34 @@ __device__ __forceinline__ float group_max(float v) {
 // ------------------------------------------------------------------------------------------------
 // forward: grid (T/64, B*H), 4 waves x 16 queries; keys stream in blocks of 64 with an online softmax
 // ------------------------------------------------------------------------------------------------
-template <int HD>
+// QG = 16-query groups per wave: 1 -> 64 queries per workgroup, 2 -> 128 (T % 128 == 0): every K / V fragment read from
+// LDS then feeds two MFMAs, and the per-key-block barrier + DMA wait is paid once per 128 queries.
+template <int HD, int QG>
 __global__ void __launch_bounds__(256)
 attn_fwd_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
               bf16_t* __restrict__ o, float* __restrict__ lse) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 3 images of 64 x HD bf16
-    constexpr int KS = HD / 32, DT = HD / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // QG + 2 images of 64 x HD bf16
+    constexpr int KS = HD / 32, DT = HD / 16, IMG = 64 * 2 * HD;
     char* qimg = smem;
-    char* kimg = smem + 64 * 2 * HD;
-    char* vimg = kimg + 64 * 2 * HD;
+    char* kimg = smem + QG * IMG;
+    char* vimg = kimg + IMG;
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
-    const int qb = blockIdx.x * 64;
+    const int qb = blockIdx.x * 64 * QG;
     const int64_t base = b * a.q_sb + h * a.q_sh;
-    stage_block<HD>(q + base + (int64_t)qb * a.q_st, a.q_st, qimg, wid, lane, a.hd);
-    bf16x8 qf[KS];
-    f32x4 ot[DT];
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) ot[dt] = f32x4{0, 0, 0, 0};
-    float m = -INFINITY, l = 0.f;
+    for (int u = 0; u < QG; ++u) stage_block<HD>(q + base + (int64_t)(qb + 64 * u) * a.q_st, a.q_st, qimg + u * IMG, wid, lane, a.hd);
+    bf16x8 qf[QG][KS];
+    f32x4 ot[QG][DT];
+    float m[QG], l[QG];
+#pragma unroll
+    for (int u = 0; u < QG; ++u) {
+        m[u] = -INFINITY;
+        l[u] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) ot[u][dt] = f32x4{0, 0, 0, 0};
+    }
     for (int kb = 0; kb < a.T; kb += 64) {
         __syncthreads();                                     // previous block's reads of kimg / vimg are done
         stage_block<HD>(k + base + (int64_t)kb * a.q_st, a.q_st, kimg, wid, lane, a.hd);
@@ -120,47 +128,72 @@ attn_fwd_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __rest
         DMA_WAIT_SYNC();
         if (kb == 0) {
 #pragma unroll
-            for (int s = 0; s < KS; ++s) qf[s] = frag_rows<HD>(qimg, 16 * wid, s, lane);
+            for (int u = 0; u < QG; ++u)
+#pragma unroll
+                for (int s = 0; s < KS; ++s) qf[u][s] = frag_rows<HD>(qimg, 16 * (QG * wid + u), s, lane);
         }
-        f32x4 st[4];
-        float bm = -INFINITY;
+        f32x4 st[QG][4];
+        float bm[QG];
+#pragma unroll
+        for (int u = 0; u < QG; ++u) bm[u] = -INFINITY;
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) {
-            f32x4 c = {0, 0, 0, 0};
+            f32x4 c[QG];
 #pragma unroll
-            for (int s = 0; s < KS; ++s) c = MFMA(frag_rows<HD>(kimg, 16 * jt, s, lane), qf[s], c);
-            st[jt] = c;
+            for (int u = 0; u < QG; ++u) c[u] = f32x4{0, 0, 0, 0};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) bm = fmaxf(bm, c[r]);
-        }
-        const float m_new = fmaxf(m, group_max(bm) * a.scale);
-        const float alpha = __expf(m - m_new);               // first block: exp(-inf) = 0 on l = 0, ot = 0
-        float ps = 0.f;
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8 kf = frag_rows<HD>(kimg, 16 * jt, s, lane);
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                st[jt][r] = __expf(st[jt][r] * a.scale - m_new);
-                ps += st[jt][r];
+                for (int u = 0; u < QG; ++u) c[u] = MFMA(kf, qf[u][s], c[u]);
             }
-        l = l * alpha + group_sum(ps);
-        m = m_new;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) ot[dt] *= alpha;
+            for (int u = 0; u < QG; ++u) {
+                st[u][jt] = c[u];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bm[u] = fmaxf(bm[u], c[u][r]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < QG; ++u) {
+            const float m_new = fmaxf(m[u], group_max(bm[u]) * a.scale);
+            const float alpha = __expf(m[u] - m_new);            // first block: exp(-inf) = 0 on l = 0, ot = 0
+            float ps = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    st[u][jt][r] = __expf(st[u][jt][r] * a.scale - m_new);
+                    ps += st[u][jt][r];
+                }
+            l[u] = l[u] * alpha + group_sum(ps);
+            m[u] = m_new;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) ot[u][dt] *= alpha;
+        }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-            const bf16x8 pf = pack_acc(st[2 * s2], st[2 * s2 + 1]);
+            bf16x8 pf[QG];
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) ot[dt] = MFMA(frag_cols_perm<HD>(vimg, 16 * dt, 32 * s2, lane), pf, ot[dt]);
+            for (int u = 0; u < QG; ++u) pf[u] = pack_acc(st[u][2 * s2], st[u][2 * s2 + 1]);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const bf16x8 vf = frag_cols_perm<HD>(vimg, 16 * dt, 32 * s2, lane);
+#pragma unroll
+                for (int u = 0; u < QG; ++u) ot[u][dt] = MFMA(vf, pf[u], ot[u][dt]);
+            }
         }
     }
-    const float inv = 1.f / l;
-    const int qi = qb + 16 * wid + (lane & 15);
-    bf16_t* orow = o + b * a.o_sb + h * a.o_sh + (int64_t)qi * a.o_st + 4 * (lane >> 4);
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-        if (16 * dt + 4 * (lane >> 4) < a.hd) store4(orow + 16 * dt, ot[dt] * inv);
-    if ((lane >> 4) == 0) lse[(int64_t)bh * a.T + qi] = m + __logf(l);
+    for (int u = 0; u < QG; ++u) {
+        const float inv = 1.f / l[u];
+        const int qi = qb + 16 * (QG * wid + u) + (lane & 15);
+        bf16_t* orow = o + b * a.o_sb + h * a.o_sh + (int64_t)qi * a.o_st + 4 * (lane >> 4);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+            if (16 * dt + 4 * (lane >> 4) < a.hd) store4(orow + 16 * dt, ot[u][dt] * inv);
+        if ((lane >> 4) == 0) lse[(int64_t)bh * a.T + qi] = m[u] + __logf(l[u]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -465,6 +498,12 @@ static AttnMfmaArgs mk_args(const vaw_attn_desc* d) {
     return a;
 }
 
+static bool attn_qg2() {
+    static int on = -1;
+    if (on < 0) { const char* v = getenv("VAW_ATTN_QG2"); on = v ? atoi(v) : 1; }
+    return on != 0;
+}
+
 #define DISPATCH_HD(hd, ...)                                \
     switch (((hd) + 31) / 32) {                             \
         case 1: { constexpr int HD = 32; __VA_ARGS__ } break;    \
@@ -476,11 +515,23 @@ static AttnMfmaArgs mk_args(const vaw_attn_desc* d) {
 int vaw_attn_fwd_mfma(const vaw_attn_desc* d, const void* q, const void* k, const void* v, void* o, float* lse,
                       hipStream_t s) {
     AttnMfmaArgs a = mk_args(d);
+    // two 16-query groups per wave: +10..17 % for head dims <= 64 (tools/attn_bench.py); slower for the padded 96-wide
+    // images (DiT-XL's 72, UNet_64's 96: unswizzled LDS rows and twice the accumulators), which keep one group
+    if (d->T % 128 == 0 && d->hd <= 64 && attn_qg2()) {
+        dim3 grid(d->T / 128, d->B * d->H);
+        DISPATCH_HD(d->hd,
+            const int lds = 4 * 64 * 2 * HD;
+            (void)hipFuncSetAttribute((const void*)attn_fwd_mfma<HD, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            attn_fwd_mfma<HD, 2><<<grid, 256, lds, s>>>(a, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse);
+        )
+        VAW_CHECK_LAUNCH("attn_fwd_mfma");
+        return VAW_OK;
+    }
     dim3 grid(d->T / 64, d->B * d->H);
     DISPATCH_HD(d->hd,
         const int lds = 3 * 64 * 2 * HD;
-        (void)hipFuncSetAttribute((const void*)attn_fwd_mfma<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attn_fwd_mfma<HD><<<grid, 256, lds, s>>>(a, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse);
+        (void)hipFuncSetAttribute((const void*)attn_fwd_mfma<HD, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attn_fwd_mfma<HD, 1><<<grid, 256, lds, s>>>(a, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse);
     )
     VAW_CHECK_LAUNCH("attn_fwd_mfma");
     return VAW_OK;
