@@ -46,6 +46,19 @@ WORKLOADS = {
 BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def pmc_traffic(workload, batch):
+    """HBM bytes per GEMM launch from the PMC counters (FETCH_SIZE x 2 + WRITE_SIZE, KiB -> bytes; the gfx950 corrections of
+    MI355X_MICROARCH.md).  Counters cannot be read from inside this process: they come from two separate rocprofv3 --pmc
+    passes of this same command, folded by tools/pmc_traffic.py into profiles/ (named per round); null when no such file
+    exists for the workload / batch being run."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r01_final_{workload}_bs{batch}_bf16_hbm_traffic.json")
+    try:
+        with open(path) as f:
+            return round(json.load(f)["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def make_args(**kw):
     a = dict(weight_type="lambda", gamma=0.0, learn_sigma=False, p2_gamma=1, p2_k=1, time_dist=["uniform", -0.8, 0.8],
              learn_align=False, align_type="mse", amp=True, dataset="Latent", class_cond=True, parallel=False,
@@ -239,7 +252,8 @@ def main():
                 rec["roofline"] = {
                     "kernel": "gemm_bf16_kernel (v_mfma_f32_16x16x32_bf16, 128x128x64 tiles; fwd/dgrad/wgrad variants)",
                     "bound": "mfma", "achieved": round(ach, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "traffic_unit": "HBM bytes per launch (PMC, separate passes)",
+                    "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None if a.fp32 else pmc_traffic(a.workload, B),
                     "launches_per_step": n_l / traced_steps, "avg_launch_us": round(1e3 * t_ms / n_l, 2),
                     "traced_steps": traced_steps,
                     "gemm_share_of_step": round(t_ms / traced_steps / (1e3 * elapsed / a.steps), 4),
