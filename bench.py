@@ -162,6 +162,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-trace", action="store_true", help="do not bracket GEMM launches with HIP events")
     ap.add_argument("--fp32", action="store_true", help="parity-mode kernels (not the headline number)")
+    ap.add_argument("--graph", action="store_true", help="capture the step into one hipGraph (Trainer args.hip_graph); implies --no-trace")
     a = ap.parse_args()
 
     import vaw_amd
@@ -184,7 +185,9 @@ def main():
     if parallel:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         vaw_amd.dist_util.setup_dist(backend="gloo" if rehearse else None, device_index=local)
-    args = workload_args(wl, parallel=parallel, amp=not a.fp32)
+    if a.graph:
+        a.no_trace = True
+    args = workload_args(wl, parallel=parallel, amp=not a.fp32, hip_graph=a.graph)
     model, ema_model = build(vaw_amd, wl, args, device, rank)
     if a.fp32:
         model.set_compute_dtype("fp32")

@@ -281,6 +281,12 @@ int vaw_sumsq(const float* g, int64_t n, float* sumsq_out, int accumulate, float
 int vaw_adamw_ema_step(float* p, float* g, float* m, float* v, float* ema, void* shadow_bf16, int64_t n, float lr,
                        float beta1, float beta2, float eps, float weight_decay, float bc1, float bc2,
                        float ema_decay, const float* sumsq, float clip_max_norm, int zero_grad, vaw_stream stream);
+/* Same update with the step-dependent scalars read from DEVICE memory -- hyper = f32[3] {lr, bc1, bc2} -- so the launch
+ * carries no per-step host value and a captured hipGraph of the whole training step can be replayed while the LR
+ * schedule (LambdaLR, utils.py:75-90) and the bias corrections advance (the host refreshes hyper before each replay). */
+int vaw_adamw_ema_step_dev(float* p, float* g, float* m, float* v, float* ema, void* shadow_bf16, int64_t n,
+                           const float* hyper, float beta1, float beta2, float eps, float weight_decay, float ema_decay,
+                           const float* sumsq, float clip_max_norm, int zero_grad, vaw_stream stream);
 /* ema = ema*decay + src*(1-decay) over n f32 (buffers that are not optimizer-owned, e.g. frozen pos_embed) */
 int vaw_ema_update(float* ema, const float* src, int64_t n, float decay, vaw_stream stream);
 /* dst(bf16) = src(f32) */

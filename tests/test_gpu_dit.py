@@ -234,3 +234,40 @@ def test_device_prefetcher_feeds_trainer():
                         class_dropout_prob=0.0, num_classes=10, learn_sigma=False, compute_dtype="fp32").to(DEV)
     losses, _, _ = _run_trainer(model, args, vaw_amd.DevicePrefetcher(synth_loader(8, 8, 8, 3, 10, latent=True), DEV), 6, True)
     np.testing.assert_allclose(losses, exp["losses"], rtol=1e-4)
+
+
+def test_hip_graph_step_matches_eager_step():
+    """args.hip_graph: the whole step (forward, loss, backward, clip, AdamW+EMA with a moving LR) captured once and replayed
+    must reproduce the eager trajectory bit for bit when the random draws are pinned (fixed t / noise; the warm-up cosine
+    schedule and Adam's bias corrections advance through the device-side hyper-parameters)."""
+    class FixedDraws(vaw_amd.GaussianDiffusion):
+        def training_losses(self, model, x_start, features=None, t=None, model_kwargs=None, noise=None):
+            return super().training_losses(model, x_start, features, t=self._t, model_kwargs=model_kwargs, noise=self._noise)
+
+    def run(graph):
+        args = base_args(in_chans=4, class_cond=True, dataset="Pixels4", image_size=8, lr=1e-3, warmup_steps=3, cosine_decay=True,
+                         total_steps=20, final_lr=1e-5, grad_clip=0.5, defer_loss_sync=True, hip_graph=graph)
+        args.in_chans = 3            # no latent sampling: Trainer draws nothing itself
+        random.seed(42); np.random.seed(42); torch.manual_seed(42)
+        model = vaw_amd.DiT(image_size=8, patch_size=2, in_channels=4, hidden_size=64, depth=2, num_heads=2,
+                            class_dropout_prob=0.0, num_classes=10, learn_sigma=False, compute_dtype="bf16").to(DEV)
+        perturb_(model, 5)
+        ema_model = copy.deepcopy(model)
+        opt = vaw_amd.FusedAdamW(model, lr=args.lr, betas=(0.9, 0.95), weight_decay=0.01, eps=1e-8)
+        sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=vaw_amd.get_lr_lambda(args))
+        diff = FixedDraws(args=args, betas=vaw_amd.get_named_beta_schedule("cosine", 1000), model_mean_type=vaw_amd.ModelMeanType.EPSILON,
+                          model_var_type=vaw_amd.ModelVarType.FIXED_LARGE, loss_type=vaw_amd.LossType.MSE, rescale_timesteps=True)
+        g = torch.Generator().manual_seed(9)
+        diff._t = torch.randint(0, 1000, (8,), generator=g).to(DEV)
+        diff._noise = torch.randn(8, 4, 8, 8, generator=g).to(DEV)
+        batches = [(torch.randn(8, 4, 8, 8, generator=g), torch.randint(0, 10, (8,), generator=g)) for _ in range(3)]
+        tr = vaw_amd.Trainer(args, torch.device(DEV), model, ema_model, opt, sched, diff, batches, Pbar())
+        losses = [float(tr.train_step(s)) for s in range(1, 9)]
+        return losses, model._flat.clone(), ema_model._flat.clone(), sched.get_last_lr()[0], opt.step_count
+
+    le, pe, ee, lre, ne = run(False)
+    lg, pg, eg, lrg, ng = run(True)
+    assert le == lg, (le, lg)
+    assert torch.equal(pe, pg) and torch.equal(ee, eg)
+    assert lre == lrg and ne == ng == 8
+    assert le[-1] < le[0]

@@ -65,6 +65,7 @@ _PROTOS = {
     "vaw_nchw_to_nhwc": [_i, _p, _p, _i, _i, _i, _p],
     "vaw_nhwc_to_nchw": [_i, _p, _p, _i, _i, _i, _p],
     "vaw_sumsq": [_p, _l, _p, _i, _p, _p],
+    "vaw_adamw_ema_step_dev": [_p, _p, _p, _p, _p, _p, _l, _p, _f, _f, _f, _f, _f, _p, _f, _i, _p],
     "vaw_adamw_ema_step": [_p, _p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _f, _f, _p, _f, _i, _p],
     "vaw_ema_update": [_p, _p, _l, _f, _p],
     "vaw_cast_bf16": [_p, _p, _l, _p],

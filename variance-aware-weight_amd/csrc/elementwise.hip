@@ -526,7 +526,12 @@ __device__ __forceinline__ void adam_one(float& p, float& g, float& m, float& v,
 
 __global__ void adamw_ema_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                  float* __restrict__ v, float* __restrict__ ema, bf16_t* __restrict__ shadow, int64_t n,
-                                 const float* __restrict__ sumsq, AdamArgs a) {
+                                 const float* __restrict__ sumsq, AdamArgs a, const float* __restrict__ hyper) {
+    if (hyper) {          // step-dependent scalars from device memory: the launch can then sit in a replayed hipGraph
+        a.lr = hyper[0];
+        a.bc1 = hyper[1];
+        a.bc2_sqrt = sqrtf(hyper[2]);
+    }
     float gs = 1.f;
     if (a.clip > 0.f) {
         const float coef = a.clip / (sqrtf(*sumsq) + 1e-6f);
@@ -569,8 +574,22 @@ extern "C" int vaw_adamw_ema_step(float* p, float* g, float* m, float* v, float*
                       ((uintptr_t)shadow_bf16 & 7) == 0, "adamw: buffers must be 16-byte aligned");
     VAW_CHECK_ARG(clip_max_norm <= 0.f || sumsq != nullptr, "adamw: clip needs sumsq");
     AdamArgs a{lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), ema_decay, clip_max_norm, zero_grad};
-    adamw_ema_kernel<<<stream_grid(n / 4 + 1, 256), 256, 0, (hipStream_t)stream>>>(p, g, m, v, ema, (bf16_t*)shadow_bf16, n, sumsq, a);
+    adamw_ema_kernel<<<stream_grid(n / 4 + 1, 256), 256, 0, (hipStream_t)stream>>>(p, g, m, v, ema, (bf16_t*)shadow_bf16, n, sumsq, a, nullptr);
     VAW_CHECK_LAUNCH("adamw_ema");
+    return VAW_OK;
+}
+
+extern "C" int vaw_adamw_ema_step_dev(float* p, float* g, float* m, float* v, float* ema, void* shadow_bf16, int64_t n,
+                                      const float* hyper, float beta1, float beta2, float eps, float weight_decay,
+                                      float ema_decay, const float* sumsq, float clip_max_norm, int zero_grad,
+                                      vaw_stream stream) {
+    VAW_CHECK_ARG(n > 0 && hyper, "adamw_dev: n<=0 or no hyper buffer");
+    VAW_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)ema) & 15) == 0 &&
+                      ((uintptr_t)shadow_bf16 & 7) == 0, "adamw_dev: buffers must be 16-byte aligned");
+    VAW_CHECK_ARG(clip_max_norm <= 0.f || sumsq != nullptr, "adamw_dev: clip needs sumsq");
+    AdamArgs a{0.f, beta1, beta2, eps, weight_decay, 1.f, 1.f, ema_decay, clip_max_norm, zero_grad};
+    adamw_ema_kernel<<<stream_grid(n / 4 + 1, 256), 256, 0, (hipStream_t)stream>>>(p, g, m, v, ema, (bf16_t*)shadow_bf16, n, sumsq, a, hyper);
+    VAW_CHECK_LAUNCH("adamw_ema_dev");
     return VAW_OK;
 }
 

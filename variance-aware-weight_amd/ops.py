@@ -310,7 +310,13 @@ def sumsq(g, out, accumulate=False):
     check(L.lib().vaw_sumsq(ptr(g), g.numel(), ptr(out), 1 if accumulate else 0, ptr(ws), stream_ptr()), "vaw_sumsq")
 
 
-def adamw_ema_step(p, g, m, v, ema, shadow, lr, beta1, beta2, eps, wd, step, ema_decay, sumsq_t, clip, zero_grad):
+def adamw_ema_step(p, g, m, v, ema, shadow, lr, beta1, beta2, eps, wd, step, ema_decay, sumsq_t, clip, zero_grad, hyper=None):
+    """hyper: device f32[3] {lr, bc1, bc2} -- when given, the kernel reads the step-dependent scalars from it (graph replay)."""
+    if hyper is not None:
+        check(L.lib().vaw_adamw_ema_step_dev(ptr(p), ptr(g), ptr(m), ptr(v), ptr(ema), ptr(shadow), p.numel(), ptr(hyper), beta1,
+                                             beta2, eps, wd, ema_decay, ptr(sumsq_t), clip or 0.0, 1 if zero_grad else 0,
+                                             stream_ptr()), "vaw_adamw_ema_step_dev")
+        return
     bc1 = 1.0 - beta1 ** step
     bc2 = 1.0 - beta2 ** step
     check(L.lib().vaw_adamw_ema_step(ptr(p), ptr(g), ptr(m), ptr(v), ptr(ema), ptr(shadow), p.numel(), lr, beta1, beta2,

@@ -31,6 +31,25 @@ class FusedAdamW(torch.optim.Optimizer):
         self.ema_model, self.ema_decay = None, 0.0
         self.max_grad_norm = None          # set per step by the trainer (args.grad_clip)
         self._flat_ptr = inner._flat.data_ptr()
+        # hipGraph mode (Trainer, args.hip_graph): lr and the bias corrections live in device memory, refreshed by
+        # prepare_step() before every (captured or replayed) step; step() then neither counts nor reads host scalars
+        self.device_hyper = None
+        self._hyper_host = None
+
+    def enable_device_hyper(self):
+        dev = self.model._flat.device
+        self.device_hyper = torch.zeros(4, device=dev, dtype=torch.float32)
+        self._hyper_host = torch.zeros(4, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(4)
+
+    def prepare_step(self):
+        """Host side of one step in device-hyper mode: count it and upload {lr, bc1, bc2}."""
+        grp = self.param_groups[0]
+        self.step_count += 1
+        b1, b2 = grp["betas"]
+        self._hyper_host[0] = grp["lr"]
+        self._hyper_host[1] = 1.0 - b1 ** self.step_count
+        self._hyper_host[2] = 1.0 - b2 ** self.step_count
+        self.device_hyper.copy_(self._hyper_host, non_blocking=True)
 
     def attach_ema(self, ema_model, decay):
         """Fold `ema(model, ema_model, decay)` into the update kernel.  Layouts must match (deepcopy does)."""
@@ -51,7 +70,8 @@ class FusedAdamW(torch.optim.Optimizer):
             raise RuntimeError("the model's flat buffer was rebuilt (moved device / deep-copied) after the optimizer was created")
         g = m.flat_grads()
         grp = self.param_groups[0]
-        self.step_count += 1
+        if self.device_hyper is None:
+            self.step_count += 1
         n = m._flat_n_train
         clip = self.max_grad_norm
         if clip:
@@ -63,7 +83,8 @@ class FusedAdamW(torch.optim.Optimizer):
         shadow = m._flat_shadow
         ops.adamw_ema_step(m._flat[:n], g, self.exp_avg, self.exp_avg_sq, None if ema_flat is None else ema_flat[:n],
                            None if shadow is None else shadow[:n], grp["lr"], grp["betas"][0], grp["betas"][1], grp["eps"],
-                           grp["weight_decay"], self.step_count, self.ema_decay, self._sumsq if clip else None, clip, False)
+                           grp["weight_decay"], self.step_count, self.ema_decay, self._sumsq if clip else None, clip, False,
+                           hyper=self.device_hyper)
         if ema_flat is not None and ema_flat.numel() > n:
             ops.ema_update(ema_flat[n:], m._flat[n:], self.ema_decay)   # frozen entries (pos_embed) are EMA'd too
         m.mark_shadow_fresh()

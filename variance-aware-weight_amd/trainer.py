@@ -8,6 +8,10 @@ Differences that do not change results:
     torch optimizer is driven exactly as the reference drives it.
   * the two `.item()` host syncs per micro-step become one per step (or none: `args.defer_loss_sync=True`
     makes train_step return a 0-dim device tensor).
+  * `args.hip_graph=True` (single GPU, FusedAdamW, grad_accumulation 1): after two eager steps the whole step -- latent
+    sampling, q_sample, forward, loss, backward, clip, AdamW+EMA, zero_grad: several hundred launches -- is captured
+    into ONE hipGraph and replayed; per step the host only copies the next batch into the static input buffers and
+    refreshes three optimizer scalars in device memory.  For launch-bound configurations (small models / batches).
 """
 from contextlib import nullcontext
 
@@ -62,6 +66,16 @@ class Trainer:
             optimizer.attach_ema(ema_model, args.ema_decay)
         self.last_mse = None
         self._cpu_rng = bool(getattr(args, "cpu_rng", False))
+        # hipGraph mode
+        self._graph, self._graph_calls, self._gin, self._gout = None, 0, None, None
+        self._use_graph = bool(getattr(args, "hip_graph", False))
+        if self._use_graph:
+            why = ("needs vaw_amd.FusedAdamW" if not self._fused else "not with DDP (args.parallel)" if args.parallel else
+                   "not with grad_accumulation > 1" if max(1, args.grad_accumulation) > 1 else
+                   "not with args.cpu_rng" if self._cpu_rng else "needs a CUDA device" if torch.device(device).type != "cuda" else None)
+            if why:
+                raise ValueError(f"args.hip_graph: {why}")
+            optimizer.enable_device_hyper()
 
     def _get_next_batch(self):
         try:
@@ -95,7 +109,57 @@ class Trainer:
                 return
             ema(self.model, self.ema_model, self.args.ema_decay)
 
+    def _graph_body(self, images, labels):
+        """Everything of one step that runs on the GPU, on static inputs; returns (loss, mse) device scalars."""
+        a = self.args
+        if a.in_chans == 4:
+            images = sample_from_latent(images, a.latent_scale, False)
+        loss_dict = self._compute_loss(images, labels, None)
+        loss = loss_dict["loss"].mean()
+        loss.backward()
+        self._apply_gradient_clipping()
+        self.optimizer.step()
+        self.optimizer.zero_grad()
+        return loss.detach(), loss_dict["mse"].detach().mean()
+
+    def _train_step_graph(self, step):
+        a = self.args
+        self.model.train()
+        images, labels = self._get_next_batch()
+        self.optimizer.prepare_step()                     # host: step count, {lr, bc1, bc2} -> device
+        self._graph_calls += 1
+        if self._graph is None and self._graph_calls <= 2:
+            total, mse = self._graph_body(images, labels)   # eager warm-up: lazy initialisation, workspaces, scratch
+        else:
+            if self._graph is None:
+                self._gin = (images.clone(), None if labels is None else labels.clone())
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._gout = self._graph_body(*self._gin)
+                self._graph = g
+            else:
+                self._gin[0].copy_(images, non_blocking=True)
+                if labels is not None:
+                    self._gin[1].copy_(labels, non_blocking=True)
+            self._graph.replay()
+            total, mse = self._gout
+        self.scheduler.step()
+        if dist_util.is_main_process():
+            self._update_ema()
+        self.last_mse = mse
+        if dist_util.is_main_process() and self.pbar is not None:
+            self.pbar.update(1)
+        if getattr(a, "defer_loss_sync", False):
+            return total
+        total_f = float(total.item())
+        if dist_util.is_main_process() and self.pbar is not None:
+            self.pbar.set_postfix(mse=f"{float(mse.item()):.4f}")
+        return total_f
+
     def train_step(self, step):
+        if self._use_graph:
+            return self._train_step_graph(step)
         a = self.args
         self.model.train()
         if a.parallel:
