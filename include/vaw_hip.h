@@ -150,13 +150,18 @@ int vaw_ln_modulate_fwd(vaw_dtype dt, const float* x, const float* shift, const 
  * dx may alias dres_in. */
 int vaw_ln_modulate_bwd(vaw_dtype dt, const void* dout, const float* x, const float* mean, const float* rstd,
                         const float* scale, int64_t mod_ld, const float* dres_in, float* dx, float* dshift,
-                        float* dscale, int64_t dmod_ld, int B, int T, int D, vaw_stream stream);
+                        float* dscale, int64_t dmod_ld, int B, int T, int D, float* workspace, int64_t workspace_floats,
+                        vaw_stream stream);
+/* Workspace (f32) of vaw_ln_modulate_bwd / vaw_gate_bwd: with it, a sample's T rows are cut into chunks handled by
+ * separate workgroups (small per-GPU batches would otherwise leave most CUs idle: one workgroup per sample) and the
+ * per-sample column sums are folded over the chunks in a fixed order by a second kernel.  NULL = one workgroup per sample. */
+int64_t vaw_row_bwd_workspace_floats(int B, int T, int D);
 /* Backward of `x + gate.unsqueeze(1) * y` :135-136 w.r.t. the branch:
  *   dy[b,t,:] = dres[b,t,:] * gate[b,:] (act dtype) ; dgate[b,:] = sum_t dres * y ;
  *   dy_colsum_partial (f32 [B, D] or NULL): per-sample sum_t dy -- reduce over B with vaw_reduce_rows to get the
  *   bias gradient of the branch's last Linear without re-reading dy. */
 int vaw_gate_bwd(vaw_dtype dt, const float* dres, const void* y, const float* gate, int64_t mod_ld, void* dy,
-                 float* dgate, int64_t dmod_ld, float* dy_colsum_partial, int B, int T, int D, vaw_stream stream);
+                 float* dgate, int64_t dmod_ld, float* dy_colsum_partial, int B, int T, int D, float* workspace, int64_t workspace_floats, vaw_stream stream);
 
 /* timm PatchEmbed (dit.py:192) input side: x f32 [B,C,H,W] -> tokens act dtype [B*(H/p)*(W/p), C*p*p],
  * column order (c, i, j) = Conv2d weight flattening. */

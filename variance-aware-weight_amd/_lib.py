@@ -35,8 +35,8 @@ _PROTOS = {
     "vaw_gemm_uses_bf16_mfma": [_i, _l, _l, _l, _p, _l, _p, _l],
     "vaw_colsum": [_i, _p, _l, _l, _l, _p, _f, _p, _l, _p],
     "vaw_ln_modulate_fwd": [_i, _p, _p, _p, _l, _p, _p, _p, _i, _i, _i, _f, _p],
-    "vaw_ln_modulate_bwd": [_i, _p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _l, _i, _i, _i, _p],
-    "vaw_gate_bwd": [_i, _p, _p, _p, _l, _p, _p, _l, _p, _i, _i, _i, _p],
+    "vaw_ln_modulate_bwd": [_i, _p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _l, _i, _i, _i, _p, _l, _p],
+    "vaw_gate_bwd": [_i, _p, _p, _p, _l, _p, _p, _l, _p, _i, _i, _i, _p, _l, _p],
     "vaw_reduce_rows": [_p, _l, _l, _p, _f, _p],
     "vaw_patchify": [_i, _p, _p, _i, _i, _i, _i, _i, _p],
     "vaw_patchify_bwd": [_p, _p, _i, _i, _i, _i, _i, _p],
@@ -94,6 +94,8 @@ def lib():
         L.vaw_last_error_string.restype = C.c_char_p
         L.vaw_colsum_workspace_floats.argtypes = [_l, _l]
         L.vaw_colsum_workspace_floats.restype = _l
+        L.vaw_row_bwd_workspace_floats.argtypes = [_i, _i, _i]
+        L.vaw_row_bwd_workspace_floats.restype = _l
         L.vaw_conv3x3_wgrad_small_workspace_floats.argtypes = [_i, _i, _i, _i, _i]
         L.vaw_conv3x3_wgrad_small_workspace_floats.restype = _l
         L.vaw_groupnorm_workspace_floats.argtypes = [_i, _i, _i]
@@ -113,7 +115,7 @@ def lib():
 def exported_symbols():
     return sorted(list(_PROTOS) + ["vaw_version", "vaw_last_error_string", "vaw_colsum_workspace_floats",
                                    "vaw_sumsq_workspace_floats", "vaw_groupnorm_workspace_floats",
-                                   "vaw_conv3x3_wgrad_small_workspace_floats"])
+                                   "vaw_conv3x3_wgrad_small_workspace_floats", "vaw_row_bwd_workspace_floats"])
 
 
 def check(rc, what):

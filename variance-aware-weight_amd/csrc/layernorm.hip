@@ -61,10 +61,15 @@ row_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ x, const fl
                float* __restrict__ dscale, int64_t dmod_ld, int Tt, int D,
                // GATE_ONLY operands
                const float* __restrict__ dres, const T* __restrict__ y, const float* __restrict__ gate,
-               T* __restrict__ dy, float* __restrict__ dgate, float* __restrict__ dy_colpart) {
+               T* __restrict__ dy, float* __restrict__ dgate, float* __restrict__ dy_colpart,
+               // gridDim.y > 1: the sample's rows are cut into chunks of rows_per_chunk, one workgroup each; the per-sample
+               // column sums then go to part[chunk][b][2][D] and row_bwd_finish_kernel folds the chunks in order
+               int rows_per_chunk, float* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][D]
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int b = blockIdx.x;
+    const int t_begin = blockIdx.y * rows_per_chunk;
+    const int t_end = t_begin + rows_per_chunk < Tt ? t_begin + rows_per_chunk : Tt;
     f32x4 acc0[NV], acc1[NV], sc[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -74,7 +79,7 @@ row_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ x, const fl
         const float* src = GATE_ONLY ? gate : scale;
         sc[i] = c < D ? load4(src + (int64_t)b * mod_ld + c) : f32x4{0, 0, 0, 0};
     }
-    for (int t = wid; t < Tt; t += nw) {
+    for (int t = t_begin + wid; t < t_end; t += nw) {
         const int64_t row = (int64_t)b * Tt + t;
         if (GATE_ONLY) {
 #pragma unroll
@@ -140,6 +145,11 @@ row_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ x, const fl
         }
         __syncthreads();
     }
+    if (part) {
+        float* dst = part + ((int64_t)blockIdx.y * gridDim.x + b) * 2 * D;
+        for (int c = threadIdx.x; c < 2 * D; c += blockDim.x) dst[c] = lds[c];
+        return;
+    }
     for (int c = threadIdx.x; c < D; c += blockDim.x) {
         if (GATE_ONLY) {
             dgate[(int64_t)b * dmod_ld + c] = s0[c];
@@ -151,7 +161,34 @@ row_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ x, const fl
     }
 }
 
+// out0[b][c] (row stride ld0) = sum_chunk part[chunk][b][0][c], out1 likewise from [1] (row stride ld1; may be NULL)
+__global__ void row_bwd_finish_kernel(const float* __restrict__ part, int NC, int B, int D, float* __restrict__ out0, int64_t ld0,
+                                      float* __restrict__ out1, int64_t ld1) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * D) return;
+    const int b = (int)(i / D), c = (int)(i % D);
+    float a0 = 0.f, a1 = 0.f;
+    for (int ch = 0; ch < NC; ++ch) {
+        const float* src = part + ((int64_t)ch * B + b) * 2 * D;
+        a0 += src[c];
+        a1 += src[D + c];
+    }
+    out0[(int64_t)b * ld0 + c] = a0;
+    if (out1) out1[(int64_t)b * ld1 + c] = a1;
+}
+
 static int pick_nv(int D) { return (D + 255) / 256; }
+// chunks per sample so that small batches still fill the chip: aim at >= 256 workgroups (one per CU; at B >= 256 the
+// single 1024-thread workgroup per sample already runs at 4.5 TB/s and the extra fold launch only costs), >= 8 rows per chunk
+static int pick_chunks(int B, int Tt, bool have_ws) {
+    if (!have_ws) return 1;
+    int nc = (256 + B - 1) / B;
+    const int max_nc = Tt / 8 > 0 ? Tt / 8 : 1;
+    if (nc > max_nc) nc = max_nc;
+    return nc < 1 ? 1 : nc;
+}
+extern "C" int64_t vaw_row_bwd_workspace_floats(int B, int T, int D) { return (int64_t)pick_chunks(B, T, true) * B * 2 * D; }
+
 static int pick_block(int Tt) {
     int nw = Tt < 16 ? Tt : 16;
     if (nw < 1) nw = 1;
@@ -188,34 +225,47 @@ extern "C" int vaw_ln_modulate_fwd(vaw_dtype dt, const float* x, const float* sh
 
 extern "C" int vaw_ln_modulate_bwd(vaw_dtype dt, const void* dout, const float* x, const float* mean, const float* rstd,
                                    const float* scale, int64_t mod_ld, const float* dres_in, float* dx, float* dshift,
-                                   float* dscale, int64_t dmod_ld, int B, int T, int D, vaw_stream stream) {
+                                   float* dscale, int64_t dmod_ld, int B, int T, int D, float* workspace,
+                                   int64_t workspace_floats, vaw_stream stream) {
     VAW_CHECK_ARG(B > 0 && T > 0 && D > 0 && D % 4 == 0 && D <= 2048 && mod_ld % 4 == 0,
                   "ln_modulate_bwd: need D%%4==0, D<=2048, mod_ld%%4==0 (D=%d)", D);
     hipStream_t s = (hipStream_t)stream;
-    const int block = pick_block(T);
+    int nc = pick_chunks(B, T, workspace != nullptr);
+    if (nc > 1 && workspace_floats < (int64_t)nc * B * 2 * D) nc = 1;
+    const int rpc = (T + nc - 1) / nc;
+    float* part = nc > 1 ? workspace : nullptr;
+    const int block = pick_block(rpc);
     const size_t lds = 2 * (size_t)D * sizeof(float);
+    dim3 grid(B, nc);
     if (dt == VAW_F32) {
-        DISPATCH_NV(pick_nv(D), (row_bwd_kernel<float, NV, false><<<B, block, lds, s>>>((const float*)dout, x, mean, rstd, scale, mod_ld, dres_in, dx, dshift, dscale, dmod_ld, T, D, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr)));
+        DISPATCH_NV(pick_nv(D), (row_bwd_kernel<float, NV, false><<<grid, block, lds, s>>>((const float*)dout, x, mean, rstd, scale, mod_ld, dres_in, dx, dshift, dscale, dmod_ld, T, D, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, rpc, part)));
     } else {
-        DISPATCH_NV(pick_nv(D), (row_bwd_kernel<bf16_t, NV, false><<<B, block, lds, s>>>((const bf16_t*)dout, x, mean, rstd, scale, mod_ld, dres_in, dx, dshift, dscale, dmod_ld, T, D, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr)));
+        DISPATCH_NV(pick_nv(D), (row_bwd_kernel<bf16_t, NV, false><<<grid, block, lds, s>>>((const bf16_t*)dout, x, mean, rstd, scale, mod_ld, dres_in, dx, dshift, dscale, dmod_ld, T, D, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, rpc, part)));
     }
+    if (nc > 1) row_bwd_finish_kernel<<<ceil_div((int64_t)B * D, 256), 256, 0, s>>>(part, nc, B, D, dshift, dmod_ld, dscale, dmod_ld);
     VAW_CHECK_LAUNCH("ln_modulate_bwd");
     return VAW_OK;
 }
 
 extern "C" int vaw_gate_bwd(vaw_dtype dt, const float* dres, const void* y, const float* gate, int64_t mod_ld, void* dy,
-                            float* dgate, int64_t dmod_ld, float* dy_colsum_partial, int B, int T, int D,
-                            vaw_stream stream) {
+                            float* dgate, int64_t dmod_ld, float* dy_colsum_partial, int B, int T, int D, float* workspace,
+                            int64_t workspace_floats, vaw_stream stream) {
     VAW_CHECK_ARG(B > 0 && T > 0 && D > 0 && D % 4 == 0 && D <= 2048 && mod_ld % 4 == 0,
                   "gate_bwd: need D%%4==0, D<=2048, mod_ld%%4==0 (D=%d)", D);
     hipStream_t s = (hipStream_t)stream;
-    const int block = pick_block(T);
+    int nc = pick_chunks(B, T, workspace != nullptr);
+    if (nc > 1 && workspace_floats < (int64_t)nc * B * 2 * D) nc = 1;
+    const int rpc = (T + nc - 1) / nc;
+    float* part = nc > 1 ? workspace : nullptr;
+    const int block = pick_block(rpc);
     const size_t lds = 2 * (size_t)D * sizeof(float);
+    dim3 grid(B, nc);
     if (dt == VAW_F32) {
-        DISPATCH_NV(pick_nv(D), (row_bwd_kernel<float, NV, true><<<B, block, lds, s>>>(nullptr, nullptr, nullptr, nullptr, nullptr, mod_ld, nullptr, nullptr, nullptr, nullptr, dmod_ld, T, D, dres, (const float*)y, gate, (float*)dy, dgate, dy_colsum_partial)));
+        DISPATCH_NV(pick_nv(D), (row_bwd_kernel<float, NV, true><<<grid, block, lds, s>>>(nullptr, nullptr, nullptr, nullptr, nullptr, mod_ld, nullptr, nullptr, nullptr, nullptr, dmod_ld, T, D, dres, (const float*)y, gate, (float*)dy, dgate, dy_colsum_partial, rpc, part)));
     } else {
-        DISPATCH_NV(pick_nv(D), (row_bwd_kernel<bf16_t, NV, true><<<B, block, lds, s>>>(nullptr, nullptr, nullptr, nullptr, nullptr, mod_ld, nullptr, nullptr, nullptr, nullptr, dmod_ld, T, D, dres, (const bf16_t*)y, gate, (bf16_t*)dy, dgate, dy_colsum_partial)));
+        DISPATCH_NV(pick_nv(D), (row_bwd_kernel<bf16_t, NV, true><<<grid, block, lds, s>>>(nullptr, nullptr, nullptr, nullptr, nullptr, mod_ld, nullptr, nullptr, nullptr, nullptr, dmod_ld, T, D, dres, (const bf16_t*)y, gate, (bf16_t*)dy, dgate, dy_colsum_partial, rpc, part)));
     }
+    if (nc > 1) row_bwd_finish_kernel<<<ceil_div((int64_t)B * D, 256), 256, 0, s>>>(part, nc, B, D, dgate, dmod_ld, dy_colsum_partial, D);
     VAW_CHECK_LAUNCH("gate_bwd");
     return VAW_OK;
 }

@@ -262,14 +262,20 @@ def ln_modulate_fwd(dt, x, shift, scale, mod_ld, out, mean, rstd, B, T, D, eps=1
           "vaw_ln_modulate_fwd")
 
 
+def _row_ws(B, T, D):
+    return scratch_f32(torch.device("cuda", torch.cuda.current_device()), L.lib().vaw_row_bwd_workspace_floats(B, T, D))
+
+
 def ln_modulate_bwd(dt, dout, x, mean, rstd, scale, mod_ld, dres_in, dx, dshift, dscale, dmod_ld, B, T, D):
+    ws = _row_ws(B, T, D)
     check(L.lib().vaw_ln_modulate_bwd(dt, dout, x, mean, rstd, scale, mod_ld, dres_in or None, dx, dshift, dscale,
-                                      dmod_ld, B, T, D, stream_ptr()), "vaw_ln_modulate_bwd")
+                                      dmod_ld, B, T, D, ws.data_ptr(), ws.numel(), stream_ptr()), "vaw_ln_modulate_bwd")
 
 
 def gate_bwd(dt, dres, y, gate, mod_ld, dy, dgate, dmod_ld, B, T, D, dy_colpart=0):
-    check(L.lib().vaw_gate_bwd(dt, dres, y, gate, mod_ld, dy, dgate, dmod_ld, dy_colpart or None, B, T, D, stream_ptr()),
-          "vaw_gate_bwd")
+    ws = _row_ws(B, T, D)
+    check(L.lib().vaw_gate_bwd(dt, dres, y, gate, mod_ld, dy, dgate, dmod_ld, dy_colpart or None, B, T, D, ws.data_ptr(),
+                               ws.numel(), stream_ptr()), "vaw_gate_bwd")
 
 
 def reduce_rows(partial, R, N, out, beta):
