@@ -26,7 +26,7 @@ def _free_port():
 
 def _build(vaw_amd, dev):
     torch.manual_seed(21)
-    m = vaw_amd.DiT(image_size=8, patch_size=2, in_channels=4, hidden_size=64, depth=2, num_heads=2, class_dropout_prob=0.0,
+    m = vaw_amd.DiT(image_size=8, patch_size=2, in_channels=4, hidden_size=64, depth=4, num_heads=2, class_dropout_prob=0.0,
                     num_classes=10, learn_sigma=False, compute_dtype="fp32")
     perturb_(m, 31)
     return m.to(dev)

@@ -271,3 +271,38 @@ def test_hip_graph_step_matches_eager_step():
     assert torch.equal(pe, pg) and torch.equal(ee, eg)
     assert lre == lrg and ne == ng == 8
     assert le[-1] < le[0]
+
+
+def test_backward_stage_hooks_and_early_adaln_bucket():
+    """With a gradient-ready listener (DDP) the backward reports head, blocks L-1..0, an early bucket with the adaLN rows of
+    the upper half of the blocks, then the rest; the stage ranges tile the flat gradient buffer exactly once and the
+    gradients are the same as without a listener (the packed adaLN weight gradient is then one GEMM instead of two)."""
+    kw = dict(image_size=8, patch_size=2, in_channels=4, hidden_size=64, depth=4, num_heads=2, class_dropout_prob=0.0,
+              num_classes=10, learn_sigma=False, compute_dtype="fp32")
+    torch.manual_seed(5)
+    m = vaw_amd.DiT(**kw)
+    perturb_(m, 6)
+    m = m.to(DEV)
+    m.ensure_flat()
+    g = torch.Generator().manual_seed(1)
+    x, t, y = torch.randn(4, 4, 8, 8, generator=g).to(DEV), torch.rand(4, generator=g).to(DEV) * 999, torch.randint(0, 10, (4,), generator=g).to(DEV)
+    gout = torch.randn(4, 4, 8, 8, generator=g).to(DEV)
+
+    def grads(hook):
+        m.grad_ready_hook = hook
+        m.zero_grad_flat()
+        out, _ = m(x, t, y)
+        (out * gout).sum().backward()
+        return m.flat_grads().clone()
+
+    ref = grads(None)
+    seen = []
+    got = grads(seen.append)
+    m.grad_ready_hook = None
+    assert seen == [5, 4, 3, "ada_hi", 2, 1, 0], seen          # block l reports stage l+1; blocks 3 and 2 are the upper half
+    torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-7)
+    cover = torch.zeros(m._flat_n_train, dtype=torch.int32)
+    for stage, rng in m.grad_stage_bounds().items():
+        for lo, hi in (rng if isinstance(rng, list) else [rng]):
+            cover[lo:hi] += 1
+    assert int(cover.min()) == 1 and int(cover.max()) == 1

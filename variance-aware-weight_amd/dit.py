@@ -238,7 +238,25 @@ class DiT(FlatModule):
         b = {self.depth + 1: (first[-1], self._flat_n_train), 0: (0, first[0])}
         for l in range(self.depth):
             b[l + 1] = (first[l], first[l + 1])
+        # the packed adaLN matrix is the largest tensor of the embedder stage (DiT-B: 42 M of its 44 M parameters) and
+        # would be reduced after everything else, un-overlapped.  Its rows for blocks >= depth/2 (and the final layer's)
+        # are final half-way through backward: stage "ada_hi" ships them then; stage 0 keeps only the lower rows.
+        half = self._ada_split_block()
+        if half is not None:
+            D = self.D
+            wo, bo = off("blocks.0.adaLN_modulation.1.weight"), off("blocks.0.adaLN_modulation.1.bias")
+            we = sum(self._flat_offsets["final_layer.adaLN_modulation.1.weight"])       # end of the packed [(6L+2)D, D] matrix
+            be = sum(self._flat_offsets["final_layer.adaLN_modulation.1.bias"])
+            assert we - wo == (6 * self.depth + 2) * D * D and be - bo == (6 * self.depth + 2) * D
+            cut_w, cut_b = wo + 6 * half * D * D, bo + 6 * half * D
+            b["ada_hi"] = [(cut_w, we), (cut_b, be)]
+            lo = [(0, cut_w), (we, cut_b), (be, first[0])] if wo < bo else [(0, cut_b), (be, cut_w), (we, first[0])]
+            b[0] = [r for r in lo if r[1] > r[0]]
         return b
+
+    def _ada_split_block(self):
+        """First block whose adaLN rows go out with the early bucket (None: no split -- shallow models)."""
+        return self.depth // 2 if self.depth >= 4 else None
 
     def unpatchify(self, x):
         c, p = self.out_channels, self.patch_size
@@ -354,6 +372,20 @@ class DiT(FlatModule):
         ops.gemm(dt, 0, 0, Nw, Kw, M, dy, Nw, x, Kw, self._g(name + "weight"), Kw, beta=beta, out_f32=True,
                  rowsum_a_out=self._g(name + "bias") if bias else None, rowsum_a_beta=beta)
 
+    def _adaln_wgrad(self, dt, ws, r0, nrows, B, beta):
+        """Weight and bias gradient of rows [r0, r0 + nrows) of the packed adaLN matrix: dW = dmod[:, rows]^T cs, db = colsum.
+        Returns the address of dmod in the GEMM operand dtype (whole buffer)."""
+        D, ld = self.D, self.mod_cols
+        if dt == BF16:
+            ops.cast_bf16(ws.dmod, ws.dmod_a)
+            dmod_a, es = ptr(ws.dmod_a), 2
+        else:
+            dmod_a, es = ptr(ws.dmod), 4
+        ops.gemm(dt, 0, 0, nrows, D, B, dmod_a + es * r0, ld, ptr(ws.cs), D, self._g("blocks.0.adaLN_modulation.1.weight") + 4 * r0 * D,
+                 D, beta=beta, out_f32=True)
+        ops.colsum(dt, dmod_a + es * r0, B, nrows, ld, self._g("blocks.0.adaLN_modulation.1.bias") + 4 * r0, beta)
+        return dmod_a
+
     def _backward_impl(self, dout, need_dx):
         ws = self._ws_cur
         B = ws.B
@@ -363,6 +395,7 @@ class DiT(FlatModule):
         beta = 1.0 if self.grads_live() else 0.0
         self._gbase = self.flat_grads().data_ptr()
         hook = self.grad_ready_hook
+        ada_half = self._ada_split_block() if hook else None      # early adaLN bucket only when somebody listens (DDP)
         dres, dD, dDm, dmod = ptr(ws.dres), ptr(ws.dD), ptr(ws.dDm), ptr(ws.dmod)
         colpart = ptr(ws.colpart)
         mod = ptr(ws.mod)
@@ -404,6 +437,12 @@ class DiT(FlatModule):
                                 ld, B, T, D)
             if hook:
                 hook(l + 1)
+                if l == ada_half:
+                    # data-parallel runs: the adaLN rows of blocks >= l (and the final layer's) are final now -- weight and
+                    # bias gradients of that part of the packed matrix leave with their own bucket while blocks l-1..0 run
+                    r0 = 6 * l * D
+                    self._adaln_wgrad(dt, ws, r0, ld - r0, B, beta)
+                    hook("ada_hi")
         # patch embedding: d(x0) = dres
         if dt == BF16:
             ops.cast_bf16(ws.dres, ws.dD)
@@ -416,14 +455,9 @@ class DiT(FlatModule):
             ops.gemm(dt, 1, 0, M, self.Kp, D, dx0, D, self._w("x_embedder.proj.weight"), self.Kp, ptr(ws.dxp), self.Kp, out_f32=True)
             dx = torch.empty(B, self.in_channels, H, W, device=dout.device, dtype=torch.float32)
             L.check(lib.vaw_patchify_bwd(ptr(ws.dxp), ptr(dx), B, self.in_channels, H, W, self.patch_size, st), "patchify_bwd")
-        # conditioning path: adaLN (all blocks at once), label table, timestep MLP
-        if dt == BF16:
-            ops.cast_bf16(ws.dmod, ws.dmod_a)
-            dmod_a = ptr(ws.dmod_a)
-        else:
-            dmod_a = dmod
-        ops.gemm(dt, 0, 0, ld, D, B, dmod_a, ld, ptr(ws.cs), D, self._g("blocks.0.adaLN_modulation.1.weight"), D, beta=beta, out_f32=True)
-        ops.colsum(dt, dmod_a, B, ld, ld, self._g("blocks.0.adaLN_modulation.1.bias"), beta)
+        # conditioning path: adaLN (all blocks at once, or the rows the early bucket has not covered), label table, timestep MLP
+        rows = ld if ada_half is None else 6 * ada_half * D
+        dmod_a = self._adaln_wgrad(dt, ws, 0, rows, B, beta)
         ops.gemm(dt, 1, 0, B, D, ld, dmod_a, ld, self._w("blocks.0.adaLN_modulation.1.weight"), D, ptr(ws.dcs), D, out_f32=True)
         L.check(lib.vaw_silu_bwd(ptr(ws.c), ptr(ws.dcs), ptr(ws.dc), B * D, st), "silu_bwd")
         ye = self.y_embedder.embedding_table

@@ -64,8 +64,12 @@ class DistributedDataParallel(nn.Module):
     def _on_stage(self, stage):
         if not self._sync or self.world == 1:
             return
-        rng = self._ranges.get(stage)
-        if rng is not None and rng[1] > rng[0]:
+        rngs = self._ranges.get(stage)
+        if rngs is not None and not isinstance(rngs, list):
+            rngs = [rngs]
+        for rng in rngs or ():
+            if rng[1] <= rng[0]:
+                continue
             g = self.module.flat_grads()[rng[0]:rng[1]]
             op = dist.ReduceOp.AVG if self._backend_avg else dist.ReduceOp.SUM
             if self._cuda:
