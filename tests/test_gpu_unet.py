@@ -309,3 +309,33 @@ def test_trainer_trajectory_tiny_unet_learned_variance_vs_reference():
     np.testing.assert_allclose(losses, exp["losses"], rtol=1e-4)
     assert psum == pytest.approx(exp["param_abs_sum"], rel=1e-5)
     assert esum == pytest.approx(exp["ema_abs_sum"], rel=1e-6)
+
+
+def test_unet_backward_stage_hooks_tile_the_gradient_buffer():
+    """DDP buckets of the UNet: decoder (output_blocks + out) first, then middle_block, then the rest; the ranges tile the
+    flat gradient buffer exactly once, and each stage's gradients are final (equal to the end-of-backward values) when
+    its hook fires."""
+    m = vaw_amd.UNetModel(16, 3, 32, 3, 1, attention_resolutions=(2,), channel_mult=(1, 2), num_heads=2, use_scale_shift_norm=True,
+                          resblock_updown=True, use_new_attention_order=True, compute_dtype="fp32")
+    perturb_(m, 3)
+    m = m.to(DEV)
+    m.ensure_flat()
+    bounds = m.grad_stage_bounds()
+    assert set(bounds) == {3, 2, 0}
+    cover = torch.zeros(m._flat_n_train, dtype=torch.int32)
+    for rng in bounds.values():
+        for lo, hi in (rng if isinstance(rng, list) else [rng]):
+            cover[lo:hi] += 1
+    assert int(cover.min()) == 1 and int(cover.max()) == 1
+    g = torch.Generator().manual_seed(2)
+    x, t = torch.randn(2, 3, 16, 16, generator=g).to(DEV), (torch.rand(2, generator=g) * 999).to(DEV)
+    gout = torch.randn(2, 3, 16, 16, generator=g).to(DEV)
+    snaps = []
+    m.grad_ready_hook = lambda st: snaps.append((st, m.flat_grads()[bounds[st][0]:bounds[st][1]].clone()))
+    (m(x, t) * gout).sum().backward()
+    m.grad_ready_hook = None
+    assert [s for s, _ in snaps] == [3, 2, 0]
+    final = m.flat_grads()
+    for st, snap in snaps:
+        assert torch.equal(snap, final[bounds[st][0]:bounds[st][1]]), st
+        assert float(snap.abs().max()) > 0

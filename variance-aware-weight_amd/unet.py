@@ -210,8 +210,19 @@ class UNetModel(FlatModule):
         return r
 
     def grad_stage_bounds(self):
+        """stage -> range(s) of the flat gradient buffer final when backward reports `stage`.  Backward runs the tape in
+        reverse, so the decoder's gradients are complete first: 3 = output_blocks + out, 2 = middle_block, 0 = the rest
+        (input_blocks, embeddings, the packed FiLM matrix).  The first two leave while the encoder is still back-propagating."""
         self.ensure_flat()
-        return {0: (0, self._flat_n_train)}
+        names = [n for n, p in self.named_parameters() if p.requires_grad and ".emb_layers." not in n]
+        first = lambda prefix: min(self._flat_offsets[n][0] for n in names if n.startswith(prefix))
+        mid, dec, n = first("middle_block."), first("output_blocks."), self._flat_n_train
+        if not (0 < mid < dec < n):
+            return {0: (0, n)}
+        # everything from `dec` on is output_blocks.* / out.* and [mid, dec) is middle_block.* (named_parameters order, FiLM packed in front)
+        assert all(self._flat_offsets[k][0] >= dec for k in names if k.startswith(("output_blocks.", "out.")))
+        assert all(mid <= self._flat_offsets[k][0] < dec for k in names if k.startswith("middle_block."))
+        return {3: (dec, n), 2: (mid, dec), 0: (0, mid)}
 
     # ---- reference surface ------------------------------------------------------------------
     def forward(self, x, timesteps, y=None, force_drop_ids=None, **kwargs):
@@ -437,6 +448,10 @@ class UNetModel(FlatModule):
                 raise TypeError(type(layer))
         return h
 
+    def _stage_done(self, stage):
+        if self.grad_ready_hook:
+            self.grad_ready_hook(stage)
+
     def _needs_grad(self, a):
         return a is not self._x_act or self._need_dx
 
@@ -492,7 +507,9 @@ class UNetModel(FlatModule):
         for blk in self.input_blocks:
             h = self._run(blk, h)
             hs.append(h)
+        self._tape.append(lambda: self._stage_done(2))      # popped once middle_block has been back-propagated
         h = self._run(self.middle_block, h)
+        self._tape.append(lambda: self._stage_done(3))      # ... once output_blocks + out have been
         for blk in self.output_blocks:
             h = self._run(blk, self._cat(h, hs.pop()))
         h = self._conv3(self._gn(h, self.out[0], silu=True), self.out[2])
