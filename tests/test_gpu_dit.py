@@ -306,3 +306,25 @@ def test_backward_stage_hooks_and_early_adaln_bucket():
         for lo, hi in (rng if isinstance(rng, list) else [rng]):
             cover[lo:hi] += 1
     assert int(cover.min()) == 1 and int(cover.max()) == 1
+
+
+def test_trainer_with_loss_second_moment_sampler():
+    """args.schedule_sampler="loss-second-moment" (the wiring the reference's Trainer lacks): t comes from the sampler, the
+    per-sample losses feed its history, the importance weights multiply the loss; after enough steps on a 20-step
+    process the sampler is warmed up and its weights are no longer uniform."""
+    args = base_args(in_chans=4, class_cond=True, dataset="Latent", image_size=8, lr=1e-3, schedule_sampler="loss-second-moment")
+    random.seed(1); np.random.seed(1); torch.manual_seed(1)
+    model = vaw_amd.DiT(image_size=8, patch_size=2, in_channels=4, hidden_size=64, depth=2, num_heads=2,
+                        class_dropout_prob=0.0, num_classes=10, learn_sigma=False, compute_dtype="fp32").to(DEV)
+    perturb_(model, 2)
+    opt = vaw_amd.FusedAdamW(model, lr=args.lr, betas=(0.9, 0.95), weight_decay=0.0, eps=1e-8)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=vaw_amd.get_lr_lambda(args))
+    diff = vaw_amd.GaussianDiffusion(args=args, betas=vaw_amd.get_named_beta_schedule("linear", 20), model_mean_type=vaw_amd.ModelMeanType.EPSILON,
+                                     model_var_type=vaw_amd.ModelVarType.FIXED_LARGE, loss_type=vaw_amd.LossType.MSE, rescale_timesteps=True)
+    tr = vaw_amd.Trainer(args, torch.device(DEV), model, None, opt, sched, diff, synth_loader(8, 8, 8, 3, 10, latent=True), Pbar())
+    assert isinstance(tr.schedule_sampler, vaw_amd.LossSecondMomentResampler)
+    assert np.allclose(tr.schedule_sampler.weights(), 1.0)              # not warmed up: uniform
+    losses = [tr.train_step(s) for s in range(1, 61)]
+    assert all(np.isfinite(losses))
+    w = tr.schedule_sampler.weights()
+    assert tr.schedule_sampler._warmed_up() and abs(w.sum() - 1.0) < 1e-9 and w.std() > 0

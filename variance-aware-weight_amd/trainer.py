@@ -66,6 +66,16 @@ class Trainer:
             optimizer.attach_ema(ema_model, args.ema_decay)
         self.last_mse = None
         self._cpu_rng = bool(getattr(args, "cpu_rng", False))
+        # optional importance sampling of t (resample.py exists in the reference but its Trainer never
+        # calls it).  args.schedule_sampler = "loss-second-moment": t ~ sampler, loss = mean(w_t * loss_t) with the
+        # sampler's 1/(T p_t) weights (guided-diffusion's TrainLoop), history updated from the per-sample losses
+        self.schedule_sampler = None
+        name = getattr(args, "schedule_sampler", None)
+        if name and name != "uniform":
+            from .resample import create_named_schedule_sampler
+            self.schedule_sampler = create_named_schedule_sampler(name, diffusion)
+            if getattr(args, "hip_graph", False):
+                raise ValueError("args.schedule_sampler updates its history on the host every step: not with args.hip_graph")
         # hipGraph mode
         self._graph, self._graph_calls, self._gin, self._gout = None, 0, None, None
         self._use_graph = bool(getattr(args, "hip_graph", False))
@@ -94,6 +104,13 @@ class Trainer:
             noise = torch.randn(images.shape).to(images.device)
             t = torch.randint(0, self.diffusion.num_timesteps, (images.shape[0],)).to(images.device)
             return self.diffusion.training_losses(self.model, images, features, t=t, model_kwargs=model_kwargs, noise=noise)
+        if self.schedule_sampler is not None:
+            t, w = self.schedule_sampler.sample(images.shape[0], images.device)
+            terms = self.diffusion.training_losses(self.model, images, features, t=t, model_kwargs=model_kwargs)
+            self.schedule_sampler.update_with_local_losses(t, terms["loss"].detach())
+            terms = dict(terms)
+            terms["loss"] = terms["loss"] * w
+            return terms
         return self.diffusion.training_losses(self.model, images, features, model_kwargs=model_kwargs)
 
     def _apply_gradient_clipping(self):
