@@ -95,15 +95,16 @@ __device__ __forceinline__ float group_max(float v) {
 // ------------------------------------------------------------------------------------------------
 // QG = 16-query groups per wave: 1 -> 64 queries per workgroup, 2 -> 128 (T % 128 == 0): every K / V fragment read from
 // LDS then feeds two MFMAs, and the per-key-block barrier + DMA wait is paid once per 128 queries.
-template <int HD, int QG>
+// DB: K / V blocks double-buffered (the next block streams in while this one is consumed; one barrier per block):
+// +10..19 % for head dims <= 64; the wider images lose a resident workgroup to the extra LDS and keep one buffer.
+template <int HD, int QG, bool DB = (HD <= 64)>
 __global__ void __launch_bounds__(256)
 attn_fwd_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
               bf16_t* __restrict__ o, float* __restrict__ lse) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // QG + 2 images of 64 x HD bf16
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // QG + 2 (+ 2 if DB) images of 64 x HD bf16
     constexpr int KS = HD / 32, DT = HD / 16, IMG = 64 * 2 * HD;
     char* qimg = smem;
-    char* kimg = smem + QG * IMG;
-    char* vimg = kimg + IMG;
+    char* kv = smem + QG * IMG;                                   // [1 or 2 buffers][K image | V image]
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
@@ -121,11 +122,25 @@ attn_fwd_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __rest
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) ot[u][dt] = f32x4{0, 0, 0, 0};
     }
-    for (int kb = 0; kb < a.T; kb += 64) {
-        __syncthreads();                                     // previous block's reads of kimg / vimg are done
-        stage_block<HD>(k + base + (int64_t)kb * a.q_st, a.q_st, kimg, wid, lane, a.hd);
-        stage_block<HD>(v + base + (int64_t)kb * a.q_st, a.q_st, vimg, wid, lane, a.hd);
-        DMA_WAIT_SYNC();
+    if (DB) {
+        stage_block<HD>(k + base, a.q_st, kv, wid, lane, a.hd);
+        stage_block<HD>(v + base, a.q_st, kv + IMG, wid, lane, a.hd);
+    }
+    for (int kb = 0, buf = 0; kb < a.T; kb += 64, buf ^= (DB ? 1 : 0)) {
+        const char* kimg = kv + buf * 2 * IMG;
+        const char* vimg = kimg + IMG;
+        if (DB) {
+            DMA_WAIT_SYNC();                                 // this key block has landed; nobody still reads the other buffer
+            if (kb + 64 < a.T) {
+                stage_block<HD>(k + base + (int64_t)(kb + 64) * a.q_st, a.q_st, kv + (buf ^ 1) * 2 * IMG, wid, lane, a.hd);
+                stage_block<HD>(v + base + (int64_t)(kb + 64) * a.q_st, a.q_st, kv + (buf ^ 1) * 2 * IMG + IMG, wid, lane, a.hd);
+            }
+        } else {
+            __syncthreads();                                 // previous block's reads of the K / V images are done
+            stage_block<HD>(k + base + (int64_t)kb * a.q_st, a.q_st, kv, wid, lane, a.hd);
+            stage_block<HD>(v + base + (int64_t)kb * a.q_st, a.q_st, kv + IMG, wid, lane, a.hd);
+            DMA_WAIT_SYNC();
+        }
         if (kb == 0) {
 #pragma unroll
             for (int u = 0; u < QG; ++u)
@@ -520,7 +535,7 @@ int vaw_attn_fwd_mfma(const vaw_attn_desc* d, const void* q, const void* k, cons
     if (d->T % 128 == 0 && d->hd <= 64 && attn_qg2()) {
         dim3 grid(d->T / 128, d->B * d->H);
         DISPATCH_HD(d->hd,
-            const int lds = 4 * 64 * 2 * HD;
+            const int lds = (HD <= 64 ? 6 : 4) * 64 * 2 * HD;
             (void)hipFuncSetAttribute((const void*)attn_fwd_mfma<HD, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             attn_fwd_mfma<HD, 2><<<grid, 256, lds, s>>>(a, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse);
         )
@@ -529,7 +544,7 @@ int vaw_attn_fwd_mfma(const vaw_attn_desc* d, const void* q, const void* k, cons
     }
     dim3 grid(d->T / 64, d->B * d->H);
     DISPATCH_HD(d->hd,
-        const int lds = 3 * 64 * 2 * HD;
+        const int lds = (HD <= 64 ? 5 : 3) * 64 * 2 * HD;
         (void)hipFuncSetAttribute((const void*)attn_fwd_mfma<HD, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attn_fwd_mfma<HD, 1><<<grid, 256, lds, s>>>(a, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse);
     )
