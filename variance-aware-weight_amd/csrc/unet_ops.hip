@@ -440,44 +440,55 @@ template <typename T, int S>
 __global__ void __launch_bounds__(256)
 conv3x3_narrow_in_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias, T* __restrict__ out,
                          int B, int H, int W, int Cw, int flip) {
+    constexpr int PS = (9 * S + 3) / 4 * 4;          // patch row padded to whole 16-byte quads
     __shared__ float wl[9 * S][256 + 8];             // [tap*S + j][wide channel of this 256-chunk]
+    __shared__ __attribute__((aligned(16))) float pat[NW_BLOCK_PIX][PS];   // the 3x3 x S patch of every pixel of the workgroup
     const int c0 = blockIdx.y * 256, cn = Cw - c0 < 256 ? Cw - c0 : 256;
     for (int i = threadIdx.x; i < 9 * S * cn; i += 256) {
         const int c = i % cn, kj = i / cn, tap = kj / S, j = kj % S;
         wl[kj][c] = flip ? to_f32(w[((int64_t)j * 9 + (8 - tap)) * Cw + c0 + c]) : to_f32(w[((int64_t)(c0 + c) * 9 + tap) * S + j]);
     }
+    const int64_t M = (int64_t)B * H * W;
+    {   // thread t gathers the patch of pixel t once (zero padding resolved here); everyone then reads it from LDS
+        const int64_t p = (int64_t)blockIdx.x * NW_BLOCK_PIX + threadIdx.x;
+        const int wq = (int)(p % W), hq = (int)((p / W) % H);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int hh = hq + t / 3 - 1, ww = wq + t % 3 - 1;
+            const bool ok = p < M && hh >= 0 && hh < H && ww >= 0 && ww < W;
+            const T* src = in + (p + (int64_t)(t / 3 - 1) * W + (t % 3 - 1)) * S;
+#pragma unroll
+            for (int j = 0; j < S; ++j) pat[threadIdx.x][t * S + j] = ok ? to_f32(src[j]) : 0.f;
+        }
+#pragma unroll
+        for (int k = 9 * S; k < PS; ++k) pat[threadIdx.x][k] = 0.f;
+    }
     __syncthreads();
     const int cg = (threadIdx.x & 31) * 8, pl = threadIdx.x >> 5;     // 32 groups of 8 channels x 8 pixel lanes
     if (cg >= cn) return;                                               // Cw % 8 == 0: a group is in or out as a whole
-    const int64_t M = (int64_t)B * H * W;
     f32x4 b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
     if (bias) { b0 = load4(bias + c0 + cg); b1 = load4(bias + c0 + cg + 4); }
     for (int it = 0; it < NW_BLOCK_PIX / (8 * NW_PIX); ++it) {
-        const int64_t p0 = (int64_t)blockIdx.x * NW_BLOCK_PIX + (it * 8 + pl) * NW_PIX;
-        float patch[NW_PIX][9 * S];
-#pragma unroll
-        for (int q = 0; q < NW_PIX; ++q) {
-            const int64_t p = p0 + q;
-            const int wq = (int)(p % W), hq = (int)((p / W) % H);
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int hh = hq + t / 3 - 1, ww = wq + t % 3 - 1;
-                const bool ok = p < M && hh >= 0 && hh < H && ww >= 0 && ww < W;
-                const T* src = in + (p + (int64_t)(t / 3 - 1) * W + (t % 3 - 1)) * S;
-#pragma unroll
-                for (int j = 0; j < S; ++j) patch[q][t * S + j] = ok ? to_f32(src[j]) : 0.f;
-            }
-        }
+        const int lp = (it * 8 + pl) * NW_PIX;                          // first of this thread's pixels inside the workgroup
+        const int64_t p0 = (int64_t)blockIdx.x * NW_BLOCK_PIX + lp;
         f32x4 a0[NW_PIX], a1[NW_PIX];
 #pragma unroll
         for (int q = 0; q < NW_PIX; ++q) { a0[q] = b0; a1[q] = b1; }
 #pragma unroll
-        for (int kj = 0; kj < 9 * S; ++kj) {
-            const f32x4 w0 = load4(&wl[kj][cg]), w1 = load4(&wl[kj][cg + 4]);
+        for (int k4 = 0; k4 < PS / 4; ++k4) {
+            f32x4 pv[NW_PIX];
 #pragma unroll
-            for (int q = 0; q < NW_PIX; ++q) {
-                a0[q] += patch[q][kj] * w0;
-                a1[q] += patch[q][kj] * w1;
+            for (int q = 0; q < NW_PIX; ++q) pv[q] = load4(&pat[lp + q][4 * k4]);       // same address for the 32 channel groups: broadcast
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int kj = 4 * k4 + u;
+                if (kj >= 9 * S) break;
+                const f32x4 w0 = load4(&wl[kj][cg]), w1 = load4(&wl[kj][cg + 4]);
+#pragma unroll
+                for (int q = 0; q < NW_PIX; ++q) {
+                    a0[q] += pv[q][u] * w0;
+                    a1[q] += pv[q][u] * w1;
+                }
             }
         }
 #pragma unroll
