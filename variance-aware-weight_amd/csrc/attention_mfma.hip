@@ -543,6 +543,15 @@ int vaw_attn_fwd_mfma(const vaw_attn_desc* d, const void* q, const void* k, cons
         return VAW_OK;
     }
     dim3 grid(d->T / 64, d->B * d->H);
+    if (d->T == 64) {        // a single key block: nothing to double-buffer, keep the LDS footprint (and residency) small
+        DISPATCH_HD(d->hd,
+            const int lds = 3 * 64 * 2 * HD;
+            (void)hipFuncSetAttribute((const void*)attn_fwd_mfma<HD, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            attn_fwd_mfma<HD, 1, false><<<grid, 256, lds, s>>>(a, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse);
+        )
+        VAW_CHECK_LAUNCH("attn_fwd_mfma");
+        return VAW_OK;
+    }
     DISPATCH_HD(d->hd,
         const int lds = (HD <= 64 ? 5 : 3) * 64 * 2 * HD;
         (void)hipFuncSetAttribute((const void*)attn_fwd_mfma<HD, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
