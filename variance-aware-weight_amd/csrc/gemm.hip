@@ -266,6 +266,7 @@ struct ConvGeom {
 };
 __device__ __attribute__((aligned(64))) const unsigned char vaw_zero_page[64] = {0};
 
+#define KMAJ_READS(KM) ((KM) ? 1 : 2)      /* LDS read instructions per fragment: one b128, or two transposing b64 */
 template <bool AK, bool BKM, int BKT, int CONV>
 __global__ void __launch_bounds__(256, BKT == 64 ? 2 : 3)
 gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb, int nk_total,
@@ -418,8 +419,8 @@ gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __rest
     stage_b(kt0, smem + Cfg::tile_bytes);
     // The K loop exists twice (compile-time flag): the few waves that also take row sums of A (CONV 3 bias gradient) run
     // their own copy, so the common copy's schedule and register use are untouched by it.
-    auto k_loop = [&](auto with_rowsum) {
-        constexpr bool RS = decltype(with_rowsum)::value;
+    auto k_loop = [&](auto with_rowsum, auto with_preload) {
+        constexpr bool RS = decltype(with_rowsum)::value, PRE = decltype(with_preload)::value;
         for (int kt = 0; kt < nk; ++kt) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA for tile kt has landed
             __syncthreads();                                    // everyone's has; and tile kt-1 is no longer read
@@ -430,6 +431,29 @@ gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __rest
                 stage_b(kt0 + kt + 1, nxt + Cfg::tile_bytes);
             }
             if (!wave_live) continue;      // this wave's 64 x 64 quadrant lies wholly outside the matrix (edge tile)
+            if (PRE) {
+                // every fragment of the K tile is requested before the first MFMA: the LDS latency of the second 32-deep
+                // half hides behind the MFMAs of the first instead of being waited for in the open
+                bf16x8 afp[BKT / 32][4], bfp[BKT / 32][4];
+#pragma unroll
+                for (int s = 0; s < BKT / 32; ++s) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bfp[s][j] = load_frag<BKM, BKT>(cur + Cfg::tile_bytes, wn + 16 * j, s, lane);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) afp[s][i] = load_frag<AK, BKT>(cur, wm + 16 * i, s, lane);
+                }
+#pragma unroll
+                for (int s = 0; s < BKT / 32; ++s)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfp[s][j], afp[s][i], acc[i][j], 0, 0, 0);
+                // pin the order: all LDS reads of the tile first, then the MFMAs (mask 0x100 = DS read, 0x008 = MFMA)
+                __builtin_amdgcn_sched_group_barrier(0x100, (KMAJ_READS(AK) + KMAJ_READS(BKM)) * 4 * (BKT / 32), 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 16 * (BKT / 32), 0);
+                continue;
+            }
 #pragma unroll
             for (int s = 0; s < BKT / 32; ++s) {
                 bf16x8 af[4], bfr[4];
@@ -451,8 +475,10 @@ gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __rest
             }
         }
     };
-    if (CAN_ROWSUM && do_rowsum) k_loop(std::true_type{});
-    else k_loop(std::false_type{});
+    if (CAN_ROWSUM && do_rowsum) k_loop(std::true_type{}, std::false_type{});
+    else if (BKT == 32 && CONV == 0 && AK) k_loop(std::false_type{}, std::true_type{});   // measured: +3..8 % on the 32-deep
+                                                                                            // input-gradient launches, neutral elsewhere
+    else k_loop(std::false_type{}, std::false_type{});
     if (CAN_ROWSUM && do_rowsum && lane < 16) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
