@@ -38,6 +38,8 @@ class DistributedDataParallel(nn.Module):
         self._backend_avg = dist.get_backend(process_group) == "nccl"     # RCCL has ReduceOp.AVG; gloo does not
         if broadcast:
             dist.broadcast(module._flat, src=0, group=process_group)     # one collective for all parameters
+            if getattr(module, "_flat_shadow", None) is not None:
+                module._shadow_version = None                            # the bf16 copy must follow the new weights
         self._ranges = self._stage_ranges()
         module.grad_ready_hook = self._on_stage
 
