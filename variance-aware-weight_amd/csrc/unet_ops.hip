@@ -331,9 +331,40 @@ template <typename T, int S, bool SMALL_IN>
 __global__ void __launch_bounds__(256)
 conv3x3_wgrad_small_kernel(const T* __restrict__ dy, const T* __restrict__ x, float* __restrict__ part, int B, int H, int W,
                            int Cw /* wide channel count */) {
+    // Per workgroup: WG_CHUNK pixels x 256 wide channels.  What every thread needs of a pixel -- the 3x3 x S patch of the
+    // narrow input (SMALL_IN) or the S narrow output gradients plus the tap validity (SMALL_OUT) -- is gathered ONCE into
+    // LDS by thread = pixel and then read back as broadcasts, instead of 256 threads re-loading the same scalars.
+    constexpr int PS = SMALL_IN ? (9 * S + 3) / 4 * 4 : 4;
+    __shared__ __attribute__((aligned(16))) float pix[WG_CHUNK][PS];
+    __shared__ unsigned short tapmask[WG_CHUNK];             // bit t: tap t of this pixel lies inside the image
     const int c = blockIdx.y * 256 + threadIdx.x;
     const int64_t M = (int64_t)B * H * W;
     const int64_t m0 = (int64_t)blockIdx.x * WG_CHUNK, m1 = m0 + WG_CHUNK < M ? m0 + WG_CHUNK : M;
+    {
+        const int64_t m = m0 + threadIdx.x;
+        const int w = (int)(m % W), h = (int)((m / W) % H);
+        unsigned mask = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
+            const bool ok = m < M && hh >= 0 && hh < H && ww >= 0 && ww < W;
+            mask |= ok ? (1u << t) : 0u;
+            if (SMALL_IN) {
+                const T* xp = x + (m + (int64_t)(t / 3 - 1) * W + (t % 3 - 1)) * S;
+#pragma unroll
+                for (int j = 0; j < S; ++j) pix[threadIdx.x][t * S + j] = ok ? to_f32(xp[j]) : 0.f;
+            }
+        }
+        if (SMALL_IN) {
+#pragma unroll
+            for (int k = 9 * S; k < PS; ++k) pix[threadIdx.x][k] = 0.f;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pix[threadIdx.x][j] = (j < S && m < M) ? to_f32(dy[m * S + j]) : 0.f;
+        }
+        tapmask[threadIdx.x] = (unsigned short)mask;
+    }
+    __syncthreads();
     float acc[9][S];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -341,26 +372,24 @@ conv3x3_wgrad_small_kernel(const T* __restrict__ dy, const T* __restrict__ x, fl
         for (int j = 0; j < S; ++j) acc[t][j] = 0.f;
     if (c < Cw) {
         for (int64_t m = m0; m < m1; ++m) {
-            const int w = (int)(m % W), h = (int)((m / W) % H);
+            const int lm = (int)(m - m0);
             if (SMALL_IN) {
                 const float g = to_f32(dy[m * Cw + c]);
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
-                    if (hh >= 0 && hh < H && ww >= 0 && ww < W) {
-                        const T* xp = x + (m + (int64_t)(t / 3 - 1) * W + (t % 3 - 1)) * S;
+                for (int k4 = 0; k4 < PS / 4; ++k4) {
+                    const f32x4 pv = load4(&pix[lm][4 * k4]);
 #pragma unroll
-                        for (int j = 0; j < S; ++j) acc[t][j] += g * to_f32(xp[j]);
+                    for (int u = 0; u < 4; ++u) {
+                        const int k = 4 * k4 + u;
+                        if (k < 9 * S) acc[k / S][k % S] += g * pv[u];       // padded taps hold zeros
                     }
                 }
             } else {
-                float g[S];
-#pragma unroll
-                for (int j = 0; j < S; ++j) g[j] = to_f32(dy[m * S + j]);
+                const f32x4 g = load4(&pix[lm][0]);
+                const unsigned mask = tapmask[lm];
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
-                    const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
-                    if (hh >= 0 && hh < H && ww >= 0 && ww < W) {
+                    if (mask & (1u << t)) {                  // uniform across the workgroup: same pixel for every thread
                         const float xv = to_f32(x[(m + (int64_t)(t / 3 - 1) * W + (t % 3 - 1)) * Cw + c]);
 #pragma unroll
                         for (int j = 0; j < S; ++j) acc[t][j] += g[j] * xv;
