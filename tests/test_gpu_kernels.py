@@ -189,7 +189,7 @@ def _mk(M, N, K, a_k, b_k, dtype, seed, ints=False):
 
 
 @pytest.mark.parametrize("a_k,b_k", [(True, True), (True, False), (False, False), (False, True)])
-@pytest.mark.parametrize("mode", ["f32", "bf16_generic", "bf16_fast", "bf16_big"])
+@pytest.mark.parametrize("mode", ["f32", "bf16_generic", "bf16_fast", "bf16_big", "bf16_p8_256", "bf16_p8_192"])
 def test_gemm_layouts_exact_integers(a_k, b_k, mode):
     """Small-integer operands are exact in bf16 and f32: any fragment-layout or swizzle error shows as a
     wrong integer, with asymmetric data on both sides (a symmetric operand would hide a transpose)."""
@@ -197,16 +197,20 @@ def test_gemm_layouts_exact_integers(a_k, b_k, mode):
     # the MFMA path predicates edge tiles: any M (multiple of 8 when A is mn-major), N % 8 == 0, K % 64 == 0
     shapes = ([(256, 384, 192), (200, 72, 128), (136, 200, 64), (192, 1728, 256), (64, 64, 64)] if mode == "bf16_fast"
               else [(256, 384, 192), (200, 72, 128), (136, 200, 64), (520, 264, 256), (304, 776, 320), (1024, 512, 2048)]
-              if mode == "bf16_big" else [(256, 384, 192), (70, 45, 23), (129, 1, 17), (5, 200, 64)])
+              if mode == "bf16_big" else
+              # persistent kernel: edge tiles in M and N, one K tile only, more items than CUs (two items per workgroup)
+              [(256, 384, 192), (200, 72, 128), (136, 200, 64), (520, 264, 256), (304, 776, 320), (1024, 512, 2048),
+               (8192, 3072, 128), (4104, 2504, 192)]
+              if mode.startswith("bf16_p8") else [(256, 384, 192), (70, 45, 23), (129, 1, 17), (5, 200, 64)])
     if mode.startswith("bf16_"):
         dtype = torch.bfloat16
     lib().vaw_debug_force_generic_gemm(1 if mode == "bf16_generic" else 0)
-    lib().vaw_debug_gemm_tile({"bf16_fast": 0, "bf16_big": 1}.get(mode, -1))
+    lib().vaw_debug_gemm_tile({"bf16_fast": 0, "bf16_big": 1, "bf16_p8_256": 2, "bf16_p8_192": 3}.get(mode, -1))
     try:
         for (M, N, K) in shapes:
             A, B = _mk(M, N, K, a_k, b_k, dtype, seed=M + N + K, ints=True)
             Ad, Bd = A.to(DEV), B.to(DEV)
-            if mode in ("bf16_fast", "bf16_big"):
+            if mode in ("bf16_fast", "bf16_big", "bf16_p8_256", "bf16_p8_192"):
                 assert lib().vaw_gemm_uses_bf16_mfma(BF16, M, N, K, ptr(Ad), Ad.shape[1], ptr(Bd), Bd.shape[1]) == 1
             got = ops.gemm_t(Ad, Bd, a_kmajor=a_k, b_kmajor=b_k, out_dtype=torch.float32).cpu()
             ref = _gemm_ref(A, B, a_k, b_k)
@@ -221,7 +225,7 @@ def test_gemm_layouts_exact_integers(a_k, b_k, mode):
         lib().vaw_debug_gemm_tile(-1)
 
 
-@pytest.mark.parametrize("tile", [0, 1])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
 @pytest.mark.parametrize("a_k,b_k", [(True, True), (True, False), (False, False)])
 def test_gemm_bf16_fast_random_and_large_k(a_k, b_k, tile):
     lib().vaw_debug_gemm_tile(tile)
@@ -235,7 +239,8 @@ def test_gemm_bf16_fast_random_and_large_k(a_k, b_k, tile):
         lib().vaw_debug_gemm_tile(-1)
 
 
-@pytest.mark.parametrize("dtype,tile", [(torch.float32, -1), (torch.bfloat16, 0), (torch.bfloat16, 1)])
+@pytest.mark.parametrize("dtype,tile", [(torch.float32, -1), (torch.bfloat16, 0), (torch.bfloat16, 1), (torch.bfloat16, 2),
+                                        (torch.bfloat16, 3)])
 def test_gemm_epilogues(dtype, tile):
     lib().vaw_debug_gemm_tile(tile)
     try:

@@ -6,50 +6,54 @@ import torch
 from .gaussian_diffusion import GaussianDiffusion
 
 
+def _ddim_stride(num_timesteps, count):
+    """Smallest integer stride whose strided range over [0, T) has exactly `count` entries (the DDIM paper's spacing)."""
+    stride = -(-num_timesteps // count) if count > 0 else 0          # ceil(T / count): the only candidate that can be smallest
+    if not (1 <= stride < num_timesteps) or -(-num_timesteps // stride) != count:
+        raise ValueError(f"cannot create exactly {num_timesteps} steps with an integer stride")
+    return stride
+
+
 def space_timesteps(num_timesteps, section_counts):
-    """Timesteps to keep: "ddimN" = the DDIM paper's fixed stride; "a,b,c" / [a, b, c] = counts per equal section."""
+    """Timesteps of the base process to keep (reference tools/respace.py:8-62).
+
+    "ddimN" keeps every s-th step for the smallest s that yields N steps.  Otherwise [0, T) is cut into len(counts)
+    sections as equal as possible (the first T % len get one more) and section i keeps counts[i] steps spread from its
+    first to its last index: offsets are the running float64 sums of (size - 1) / (count - 1), rounded half-to-even."""
     if isinstance(section_counts, str):
         if section_counts.startswith("ddim"):
-            desired_count = int(section_counts[len("ddim"):])
-            for i in range(1, num_timesteps):
-                if len(range(0, num_timesteps, i)) == desired_count:
-                    return set(range(0, num_timesteps, i))
-            raise ValueError(f"cannot create exactly {num_timesteps} steps with an integer stride")
-        section_counts = [int(x) for x in section_counts.split(",")]
-    size_per = num_timesteps // len(section_counts)
-    extra = num_timesteps % len(section_counts)
-    start_idx = 0
-    all_steps = []
-    for i, section_count in enumerate(section_counts):
-        size = size_per + (1 if i < extra else 0)
-        if size < section_count:
-            raise ValueError(f"cannot divide section of {size} steps into {section_count}")
-        frac_stride = 1 if section_count <= 1 else (size - 1) / (section_count - 1)
-        cur_idx = 0.0
-        for _ in range(section_count):
-            all_steps.append(start_idx + round(cur_idx))
-            cur_idx += frac_stride
-        start_idx += size
-    return set(all_steps)
+            return set(range(0, num_timesteps, _ddim_stride(num_timesteps, int(section_counts[4:]))))
+        section_counts = [int(tok) for tok in section_counts.split(",")]
+    counts = np.asarray(section_counts, dtype=np.int64)
+    sizes = np.full(len(counts), num_timesteps // len(counts), dtype=np.int64)
+    sizes[: num_timesteps % len(counts)] += 1
+    short = np.nonzero(sizes < counts)[0]
+    if short.size:
+        raise ValueError(f"cannot divide section of {int(sizes[short[0]])} steps into {int(counts[short[0]])}")
+    firsts = np.cumsum(sizes) - sizes
+    kept = set()
+    for first, size, count in zip(firsts.tolist(), sizes.tolist(), counts.tolist()):
+        if count <= 0:
+            continue
+        step = 1.0 if count == 1 else (size - 1) / (count - 1)
+        offsets = np.concatenate(([0.0], np.cumsum(np.full(count - 1, step, dtype=np.float64))))   # sequential sums
+        kept.update((first + np.rint(offsets).astype(np.int64)).tolist())
+    return kept
 
 
 class SpacedDiffusion(GaussianDiffusion):
-    """A diffusion process that keeps only `use_timesteps` of the base process (new betas from the kept alpha-bars);
-    the model is wrapped so that it still sees the ORIGINAL timestep values."""
+    """The base process restricted to `use_timesteps` (reference tools/respace.py:65-112): the kept cumulative alphas
+    define new betas  beta'_j = 1 - abar[k_j] / abar[k_{j-1}]  (abar[k_{-1}] = 1), and models are wrapped so that they
+    still receive the ORIGINAL timestep values k_j."""
 
     def __init__(self, use_timesteps, **kwargs):
+        base_betas = np.asarray(kwargs["betas"], dtype=np.float64)
+        self.original_num_steps = int(base_betas.shape[0])
         self.use_timesteps = set(use_timesteps)
-        self.timestep_map = []
-        self.original_num_steps = len(kwargs["betas"])
-        base_diffusion = GaussianDiffusion(**kwargs)
-        last_alpha_cumprod = 1.0
-        new_betas = []
-        for i, alpha_cumprod in enumerate(base_diffusion.alphas_cumprod):
-            if i in self.use_timesteps:
-                new_betas.append(1 - alpha_cumprod / last_alpha_cumprod)
-                last_alpha_cumprod = alpha_cumprod
-                self.timestep_map.append(i)
-        kwargs["betas"] = np.array(new_betas)
+        keep = np.array(sorted(k for k in self.use_timesteps if 0 <= k < self.original_num_steps), dtype=np.int64)
+        self.timestep_map = keep.tolist()
+        abar = np.cumprod(1.0 - base_betas, axis=0)[keep]
+        kwargs["betas"] = 1 - abar / np.concatenate(([1.0], abar[:-1]))
         super().__init__(**kwargs)
 
     def _reverse_step(self, kind, model, *args, **kwargs):       # p_mean_variance / p_sample / ddim_sample all come here
