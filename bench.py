@@ -1,15 +1,18 @@
 #!/usr/bin/env python3
 """Headline benchmark: training images/sec of the variance-aware-weighted diffusion step on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dit_b4]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dit_b4] [--scaling strong|weak]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
+(a plain `python bench.py --gpus N` starts its N ranks itself, before anything touches the GPU, and relays rank 0's line)
 
 One "step" = one full `Trainer.train_step` on one synthetic batch already resident in HBM:
 latent sampling, noise + timestep draw, q_sample, DiT forward, weighted-MSE loss, hand-written backward,
 (N>1: bucketed RCCL all-reduce overlapped with backward), fused AdamW + EMA.  Nothing is skipped or cached.
-Default workload = BASELINE.json config 4, the one its MFMA target is quoted on: DiT-B/4 on 4x32x32 latents,
-batch 256 PER GPU (weak scaling: global batch = 256*N), bf16 MFMA with f32 accumulation, weight_type 'lambda'.
+Default workload = BASELINE.json config 4, the one its MFMA target is quoted on: DiT-B/4 on 4x32x32 latents, GLOBAL batch
+256 sharded over the N GPUs as the reference shards it (main.py:166-180: per-GPU batch = batch_size // world_size; strong
+scaling), bf16 MFMA with f32 accumulation, weight_type 'lambda'.  For N > 1 the same process then also times the weak
+configuration (256 per GPU) and reports it in the extra field "weak".
 
 Prints ONE JSON line on rank 0 (contract in the project brief) with two extra objects:
   roofline      the dominant kernel (bf16 MFMA GEMM): algorithmic FLOP / HIP-event launch time, vs 2.5 PFLOP/s
@@ -49,14 +52,23 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md
 def pmc_traffic(workload, batch):
     """HBM bytes per GEMM launch from the PMC counters (FETCH_SIZE x 2 + WRITE_SIZE, KiB -> bytes; the gfx950 corrections of
     MI355X_MICROARCH.md).  Counters cannot be read from inside this process: they come from two separate rocprofv3 --pmc
-    passes of this same command, folded by tools/pmc_traffic.py into profiles/ (named per round); null when no such file
-    exists for the workload / batch being run."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r01_final_{workload}_bs{batch}_bf16_hbm_traffic.json")
+    passes of this same command, folded by tools/pmc_traffic.py into profiles/r<NN>_*_hbm_traffic.json; the newest round's
+    file for the workload / batch being run is used and named in the line ("traffic_source"); (None, None) without one."""
+    import glob
+    import re
+    pat = os.path.join(REPO, "profiles", f"r*_{workload}_bs{batch}_bf16_hbm_traffic.json")
+    best = None
+    for path in glob.glob(pat):
+        m = re.match(r"r(\d+)_", os.path.basename(path))
+        if m and (best is None or int(m.group(1)) >= best[0]):
+            best = (int(m.group(1)), path)
+    if best is None:
+        return None, None
     try:
-        with open(path) as f:
-            return round(json.load(f)["hbm_bytes_per_launch"])
+        with open(best[1]) as f:
+            return round(json.load(f)["hbm_bytes_per_launch"]), os.path.relpath(best[1], REPO)
     except (OSError, KeyError, ValueError):
-        return None
+        return None, None
 
 
 def make_args(**kw):
@@ -125,13 +137,14 @@ def build(pkg, wl, args, device, rank):
     return model, ema_model
 
 
-def cpu_baseline(wl, budget_s=25.0):
-    """The CPU oracle (torch restatement of the reference path, pinned by tests/golden) on this host."""
+def cpu_baseline(wl, batch, budget_s=25.0):
+    """The CPU oracle (torch restatement of the reference path, pinned by tests/golden) on this host: the workload's batch
+    when one step fits the budget, else the largest batch that does (flagged in "reduced_batch")."""
     from oracle import diffusion as od, dit as odit, trainer as otr, unet as ounet
     torch.manual_seed(42)
-    # a one-GPU box gives this job a 16-core CPU share; more threads than that only thrash
-    torch.set_num_threads(int(os.environ.get("VAW_CPU_THREADS", "16")))
-    B = {"dit": 32, "unet": 16 if wl.get("size") == 32 else 4}[wl["kind"]]
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = int(os.environ.get("VAW_CPU_THREADS", usable))
+    torch.set_num_threads(threads)
     args = workload_args(wl, amp=False, defer_loss_sync=False)
     opkg = SimpleNamespace(DiT_models=odit.DiT_models, UNetModel=ounet.UNetModel, ADM_64=ounet.ADM_64, UNet_64=ounet.UNet_64)
     model = make_model(opkg, wl)
@@ -141,29 +154,94 @@ def cpu_baseline(wl, budget_s=25.0):
     diff = od.GaussianDiffusion(args=args, betas=od.get_named_beta_schedule("cosine", 1000),
                                 model_mean_type=od.ModelMeanType.EPSILON, model_var_type=od.ModelVarType.FIXED_LARGE,
                                 loss_type=od.LossType.MSE, rescale_timesteps=True)
-    tr = otr.Trainer(args, torch.device("cpu"), model, ema_model, opt, sched, diff, synth_batches(B, 2, "cpu", 123, wl))
+    # probe one small step to size the sample: the timed steps run the config batch if ~3 of them fit the budget
+    probe_b = min(batch, 8)
+    tr = otr.Trainer(args, torch.device("cpu"), model, ema_model, opt, sched, diff, synth_batches(probe_b, 1, "cpu", 5, wl))
     tr.train_step(0)               # warm-up (allocator, oneDNN primitive cache)
+    t0 = time.perf_counter()
+    tr.train_step(1)
+    per_img = (time.perf_counter() - t0) / probe_b
+    B = batch
+    while B > 1 and 3 * B * per_img > budget_s:
+        B //= 2
+    tr = otr.Trainer(args, torch.device("cpu"), model, ema_model, opt, sched, diff, synth_batches(B, 2, "cpu", 123, wl))
     t0, n = time.perf_counter(), 0
     while n < 2 or (time.perf_counter() - t0 < budget_s and n < 20):
-        tr.train_step(n + 1)
+        tr.train_step(n + 2)
         n += 1
     dt = time.perf_counter() - t0
-    return {"value": round(B * n / dt, 2), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} steps of {wl['desc']} at batch {B}, f32, oracle/ Trainer (fwd+bwd+AdamW+EMA), after 1 warm-up step"}
+    return {"value": round(B * n / dt, 2), "unit": "images/sec", "cores": threads, "host_cpu_count": os.cpu_count(),
+            "usable_cores": usable, "kind": "port", "reduced_batch": None if B == batch else B,
+            "sample": f"{n} steps of {wl['desc']} at batch {B}, f32, oracle/ Trainer (fwd+bwd+AdamW+EMA), {threads} threads, "
+                      f"after 2 warm-up steps at batch {probe_b}"}
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes (this parent never touches the
+    GPU: device_count() does not initialise it), relay rank 0's JSON line, exit with the worst return code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if torch.cuda.device_count() < n and "VAW_REHEARSE_ONE_GPU" not in base:
+        raise SystemExit(f"--gpus {n} but only {torch.cuda.device_count()} visible (VAW_REHEARSE_ONE_GPU=1 rehearses the "
+                         f"{n}-rank control flow on one GPU over gloo; its numbers are not a multi-GPU measurement)")
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = rc or p.wait()
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    raise SystemExit(rc)
+
+
+def timed_steps(tr, first_step, n_steps, barrier, parallel, device):
+    """EXACTLY n_steps steps between barrier + synchronize on both sides; -> (seconds, MAX over ranks; per-step ms list of this
+    rank from stream markers, which fence nothing)."""
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(n_steps + 1)]
+    losses = []
+    barrier()
+    t0 = time.perf_counter()
+    marks[0].record()
+    for s in range(n_steps):
+        losses.append(tr.train_step(first_step + s))
+        marks[s + 1].record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if parallel:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    per = [marks[i].elapsed_time(marks[i + 1]) for i in range(n_steps)]
+    return elapsed, per, losses
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="dit_b4", choices=list(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the workload's)")
+    ap.add_argument("--batch", type=int, default=None, help="GLOBAL batch of the strong configuration = per-GPU batch of the weak one (default: the workload's)")
+    ap.add_argument("--scaling", default=None, choices=["strong", "weak"],
+                    help="strong (default): global batch fixed, batch // N per GPU (reference main.py:166-180), plus a weak pass "
+                         "reported as the field 'weak' when N > 1; weak: only the batch-per-GPU-fixed measurement")
+    ap.add_argument("--bucket-dtype", default="bf16", choices=["bf16", "f32"], help="gradient all-reduce buckets on the wire")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-trace", action="store_true", help="do not bracket GEMM launches with HIP events")
+    ap.add_argument("--no-trace", action="store_true", help="skip the extra (untimed) steps that bracket GEMM launches with HIP events")
     ap.add_argument("--fp32", action="store_true", help="parity-mode kernels (not the headline number)")
     ap.add_argument("--graph", action="store_true", help="capture the step into one hipGraph (Trainer args.hip_graph); implies --no-trace")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(a.gpus)
 
     import vaw_amd
     vaw_amd.lib()                   # fail loudly if the HIP library is missing
@@ -173,7 +251,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    scaling = a.scaling or "strong"
+    if scaling == "strong" and B % world:
+        raise SystemExit(f"global batch {B} does not divide over {world} GPUs")
     # VAW_REHEARSE_ONE_GPU=1: every rank on cuda:0 over gloo -- exercises the N-rank control flow (buckets, side stream,
     # barriers, max-over-ranks timing) on a one-GPU box; the numbers it prints are NOT a multi-GPU measurement
     rehearse = os.environ.get("VAW_REHEARSE_ONE_GPU") == "1"
@@ -191,7 +272,7 @@ def main():
     model, ema_model = build(vaw_amd, wl, args, device, rank)
     if a.fp32:
         model.set_compute_dtype("fp32")
-    net = vaw_amd.DistributedDataParallel(model) if parallel else model
+    net = vaw_amd.DistributedDataParallel(model, bucket_dtype=a.bucket_dtype) if parallel else model
     opt = vaw_amd.FusedAdamW(model, lr=args.lr, betas=(0.9, 0.95), weight_decay=0.0, eps=1e-8)
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=vaw_amd.get_lr_lambda(args))
     diff = vaw_amd.GaussianDiffusion(args=args, betas=vaw_amd.get_named_beta_schedule("cosine", 1000),
@@ -199,52 +280,70 @@ def main():
                                      model_var_type=vaw_amd.ModelVarType.FIXED_LARGE, loss_type=vaw_amd.LossType.MSE,
                                      rescale_timesteps=True)
     torch.manual_seed(1000 + rank)          # seed + rank: every rank draws its own t / noise (reference utils.py:62-69)
-    loader = _Loader(synth_batches(B, 4, device, 123 + rank, wl))
-    tr = vaw_amd.Trainer(args, device, net, ema_model if rank == 0 else None, opt, sched, diff, loader)
 
     def barrier():
         if parallel:
             dist.barrier()
         torch.cuda.synchronize()
 
-    losses = []
-    for s in range(a.warmup):
-        losses.append(tr.train_step(s))
+    def run(per_gpu, first_step):
+        """W untimed + K timed steps at `per_gpu` images per rank -> result fields."""
+        loader = _Loader(synth_batches(per_gpu, 4, device, 123 + rank, wl))
+        tr = run.tr
+        if tr is None:
+            tr = run.tr = vaw_amd.Trainer(args, device, net, ema_model if rank == 0 else None, opt, sched, diff, loader)
+        else:
+            tr.train_loader, tr.datalooper = loader, iter(loader)
+        for s in range(a.warmup):
+            tr.train_step(first_step + s)
+        elapsed, per, losses = timed_steps(tr, first_step + a.warmup, a.steps, barrier, parallel, device)
+        last = float(losses[-1])
+        if not (last == last) or abs(last) > 1e4:
+            raise SystemExit(f"non-finite / diverged loss {last}: the measurement is void")
+        per.sort()
+        return {"value": round(per_gpu * world * a.steps / elapsed, 2), "ms_per_step": round(1e3 * elapsed / a.steps, 3),
+                "median_ms_per_step": round(per[len(per) // 2], 3), "per_gpu_batch": per_gpu, "global_batch": per_gpu * world,
+                "last_loss": round(last, 5)}
+    run.tr = None
+
+    main_res = run(B // world if scaling == "strong" else B, 0)
+    weak_res = run(B, a.warmup + a.steps) if (parallel and scaling == "strong") else None
+
+    # roofline of the dominant kernel: extra steps AFTER the timed region (the HIP-event brackets fence the launch stream and
+    # cost ~3 % of a step, so the timed steps carry none), at the batch of the headline measurement
     trace = None
     if not a.no_trace and rank == 0:
         trace = vaw_amd.ops.GemmTrace()
-    # the HIP-event brackets around every GEMM call cost ~3 % of a step (they fence the launch stream), so inside the timed
-    # region only every 4th step carries them (all steps when fewer than 8 are timed); roofline = those steps' launches
-    stride = 4 if a.steps >= 8 else 1
-    barrier()
-    t0 = time.perf_counter()
-    for s in range(a.steps):
-        vaw_amd.ops.gemm_trace = trace if s % stride == 0 else None
-        losses.append(tr.train_step(a.warmup + s))
-    barrier()
-    elapsed = time.perf_counter() - t0
-    vaw_amd.ops.gemm_trace = None
-    if parallel:
-        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    last_loss = float(losses[-1])
-    if not (last_loss == last_loss) or abs(last_loss) > 1e4:
-        raise SystemExit(f"non-finite / diverged loss {last_loss}: the measurement is void")
+    traced_steps = 3
+    if parallel or trace is not None:       # every rank runs them: the steps contain collectives
+        if weak_res is not None:
+            loader = _Loader(synth_batches(main_res["per_gpu_batch"], 4, device, 123 + rank, wl))
+            run.tr.train_loader, run.tr.datalooper = loader, iter(loader)
+        if not a.no_trace:
+            run.tr.train_step(10 ** 6)
+            barrier()
+            vaw_amd.ops.gemm_trace = trace
+            for s in range(traced_steps):
+                run.tr.train_step(10 ** 6 + 1 + s)
+            barrier()
+            vaw_amd.ops.gemm_trace = None
 
     if rank == 0:
-        ms = 1e3 * elapsed / a.steps
-        ips = B * world * a.steps / elapsed
-        rec = {"metric": "training images/sec", "value": round(ips, 2), "unit": "images/sec", "n_gpus": world,
-               "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "f32" if a.fp32 else "bf16", "data": "synthetic",
+        ips, ms = main_res["value"], main_res["ms_per_step"]
+        rec = {"metric": "training images/sec", "value": ips, "unit": "images/sec", "n_gpus": world,
+               "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "median_ms_per_step": main_res["median_ms_per_step"],
+               "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32" if a.fp32 else "bf16",
+               "data": "synthetic",
                "config": {"workload": f"{wl['desc']}; Trainer.train_step: q_sample + fwd + lambda-weighted MSE + bwd + "
-                                      f"AdamW + EMA; per-GPU batch {B}", "global_batch": B * world,
-                          "parallelism": f"dp{world}", "weight_type": args.weight_type, "last_loss": round(last_loss, 5)}}
+                                      f"AdamW + EMA; global batch {main_res['global_batch']} = {main_res['per_gpu_batch']} per GPU",
+                          "global_batch": main_res["global_batch"], "per_gpu_batch": main_res["per_gpu_batch"],
+                          "parallelism": f"dp{world}", "weight_type": args.weight_type, "last_loss": main_res["last_loss"],
+                          "grad_bucket_dtype": a.bucket_dtype if parallel else None}}
+        if weak_res is not None:
+            rec["weak"] = dict(weak_res, scaling="weak", note=f"same process, {B} images per GPU")
         if wl["gflop_per_img"]:
             rec["config"]["step_mfma_util_vs_2.5PF"] = round(ips / world * wl["gflop_per_img"] / 1e3 / BF16_MFMA_PEAK_TFLOPS, 4)
         if trace is not None:
-            traced_steps = len(range(0, a.steps, stride))
             summ = trace.summarize()
             fast = {k: v for k, v in summ.items() if k.startswith("bf16_mfma")}
             if fast:
@@ -252,21 +351,25 @@ def main():
                 t_ms = sum(v["ms"] for v in fast.values())
                 n_l = sum(v["launches"] for v in fast.values())
                 ach = flop / (t_ms * 1e-3) / 1e12
+                traffic, src = (None, None) if a.fp32 else pmc_traffic(a.workload, main_res["per_gpu_batch"])
                 rec["roofline"] = {
-                    "kernel": "gemm_bf16_kernel (v_mfma_f32_16x16x32_bf16, 128x128x64 tiles; fwd/dgrad/wgrad variants)",
+                    "kernel": "bf16 MFMA GEMM family (v_mfma_f32_16x16x32_bf16): gemm_p8_kernel (persistent 256 x 256|192 tiles, "
+                              "LDS-DMA ring, counted vmcnt) for the large Linear launches, gemm_bf16_kernel (128 x 128) for the rest; "
+                              "fwd/dgrad/wgrad variants",
                     "bound": "mfma", "achieved": round(ach, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "traffic_unit": "HBM bytes per launch (PMC, separate passes)",
-                    "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None if a.fp32 else pmc_traffic(a.workload, B),
+                    "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
                     "launches_per_step": n_l / traced_steps, "avg_launch_us": round(1e3 * t_ms / n_l, 2),
-                    "traced_steps": traced_steps,
-                    "gemm_share_of_step": round(t_ms / traced_steps / (1e3 * elapsed / a.steps), 4),
+                    "traced_steps": traced_steps, "traced_where": "extra steps after the timed region",
+                    "gemm_share_of_step": round(t_ms / traced_steps / ms, 4),
                     "by_variant": {k: {"launches_per_step": v["launches"] / traced_steps,
                                        "tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 1),
                                        "avg_us": round(1e3 * v["ms"] / v["launches"], 2)} for k, v in summ.items()}}
         if world == 1 and not a.no_cpu_baseline:
-            del tr, opt, model, ema_model, net
+            run.tr = None
+            del opt, model, ema_model, net
             torch.cuda.empty_cache()
-            rec["cpu_baseline"] = cpu_baseline(wl)
+            rec["cpu_baseline"] = cpu_baseline(wl, B)
         print(json.dumps(rec), flush=True)
     if parallel:
         dist.barrier()

@@ -296,6 +296,10 @@ int vaw_adamw_ema_step_dev(float* p, float* g, float* m, float* v, float* ema, v
 int vaw_ema_update(float* ema, const float* src, int64_t n, float decay, vaw_stream stream);
 /* dst(bf16) = src(f32) */
 int vaw_cast_bf16(const float* src, void* dst, int64_t n, vaw_stream stream);
+/* dst[i] = scale * float(src[i]), src bf16: the way back of a gradient bucket that was all-reduced in bf16 over xGMI
+ * (the reference's DDP reduces f32 buckets, main.py:347-348; bf16 halves the bytes on the wire); scale = 1/world when the
+ * collective summed.  src and dst 16-byte aligned. */
+int vaw_uncast_bf16(const void* src, float* dst, int64_t n, float scale, vaw_stream stream);
 
 #ifdef __cplusplus
 }

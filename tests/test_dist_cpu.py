@@ -82,6 +82,16 @@ def _worker(rank, world, port, q):
         assert torch.allclose(m.a.weight.grad, torch.full_like(m.a.weight, float(rank + 1)))
         m.fake_backward(10.0)
         assert torch.allclose(m.a.weight.grad, torch.full_like(m.a.weight, mean + 10.0))
+        # bf16 wire buckets: cast -> all-reduce at half the bytes -> widen back (values exact in bf16 here)
+        ddp16 = vaw_amd.DistributedDataParallel(m, broadcast=False, bucket_dtype="bf16")
+        m.zero_grad_flat()
+        m.fake_backward(float(rank + 1))
+        assert m.flat_grads().dtype == torch.float32
+        assert torch.allclose(m.a.weight.grad, torch.full_like(m.a.weight, mean))
+        assert torch.allclose(m.b.bias.grad, torch.full_like(m.b.bias, mean))
+        with pytest.raises(ValueError):
+            vaw_amd.DistributedDataParallel(m, broadcast=False, bucket_dtype="fp8")
+        del ddp16
         # loss-aware sampler: ranks hold different numbers of (t, loss) pairs; histories must end identical
         s = vaw_amd.create_named_schedule_sampler("loss-second-moment", SimpleNamespace(num_timesteps=6))
         ts = torch.tensor([rank, 5]) if rank == 0 else torch.tensor([2, 3, 4])

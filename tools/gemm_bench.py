@@ -27,6 +27,10 @@ UNET64 = [  # a few conv-as-GEMM shapes of UNet_64 at batch 128 (M = B*H*W pixel
     ("c192@64 fwd", "fwd", 128 * 64 * 64, 192, 9 * 192, "bias"), ("c384@32 fwd", "fwd", 128 * 32 * 32, 384, 9 * 384, "bias"),
     ("c576@16 fwd", "fwd", 128 * 16 * 16, 576, 9 * 576, "bias"), ("c768@8 fwd", "fwd", 128 * 8 * 8, 768, 9 * 768, "bias"),
 ]
+# per-round cost of the persistent kernel: 256 x 256 tiles, 8 column tiles, 32 / 64 / 96 / 128 row tiles = 1..4 rounds of 256
+ROUNDS = [(f"r{r} K768", "fwd", 8192 * r, 2048, 768, "none") for r in (1, 2, 3, 4)] + \
+         [(f"r{r} K768 gelu", "fwd", 8192 * r, 2048, 768, "gelu") for r in (1, 2, 3)] + \
+         [(f"r{r} K3072", "fwd", 8192 * r, 2048, 3072, "none") for r in (1, 2)]
 SQUARE = [("4096^3 fwd", "fwd", 4096, 4096, 4096, "none"), ("4096^3 dgrad", "dgrad", 4096, 4096, 4096, "none"),
           ("4096^3 wgrad", "wgrad", 4096, 4096, 4096, "f32"), ("8192^3 fwd", "fwd", 8192, 8192, 8192, "none")]
 
@@ -74,7 +78,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     from vaw_amd._lib import lib
     tiles = {"auto": [-1], "128": [0], "256": [1], "both": [0, 1], "p8": [4], "cmp": [0, 2, 3], "p8_256": [2], "p8_192": [3]}[a.tile]
-    for row in {"dit_b4": DIT_B4, "square": SQUARE, "unet64": UNET64, "all": DIT_B4 + SQUARE}[a.shapes]:
+    for row in {"dit_b4": DIT_B4, "square": SQUARE, "unet64": UNET64, "all": DIT_B4 + SQUARE, "rounds": ROUNDS}[a.shapes]:
         if a.only is None or a.only in row[0]:
             for t in tiles:
                 lib().vaw_debug_gemm_tile(t)

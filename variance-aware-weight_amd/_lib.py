@@ -69,6 +69,7 @@ _PROTOS = {
     "vaw_adamw_ema_step": [_p, _p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _f, _f, _p, _f, _i, _p],
     "vaw_ema_update": [_p, _p, _l, _f, _p],
     "vaw_cast_bf16": [_p, _p, _l, _p],
+    "vaw_uncast_bf16": [_p, _p, _l, _f, _p],
 }
 
 _lib = None

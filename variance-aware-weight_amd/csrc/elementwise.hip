@@ -617,3 +617,23 @@ extern "C" int vaw_cast_bf16(const float* src, void* dst, int64_t n, vaw_stream 
     VAW_CHECK_LAUNCH("cast_bf16");
     return VAW_OK;
 }
+
+// dst[i] = scale * float(src[i]): gradient buckets that travelled over xGMI in bf16 come back into the f32 gradient
+// buffer (scale = 1/world when the collective summed instead of averaging).
+__global__ void uncast_bf16_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, int64_t n, float scale) {
+    const int64_t n8 = n / 8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const bf16x8 v = reinterpret_cast<const bf16x8*>(src)[i];
+        f32x4 a = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]}, b = {(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
+        reinterpret_cast<f32x4*>(dst)[2 * i] = a * scale;
+        reinterpret_cast<f32x4*>(dst)[2 * i + 1] = b * scale;
+    }
+    for (int64_t i = n8 * 8 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = scale * (float)src[i];
+}
+extern "C" int vaw_uncast_bf16(const void* src, float* dst, int64_t n, float scale, vaw_stream stream) {
+    VAW_CHECK_ARG(n > 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "uncast_bf16: n<=0 or unaligned");
+    uncast_bf16_kernel<<<stream_grid(n / 8 + 1, 256), 256, 0, (hipStream_t)stream>>>((const bf16_t*)src, dst, n, scale);
+    VAW_CHECK_LAUNCH("uncast_bf16");
+    return VAW_OK;
+}

@@ -865,11 +865,18 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
         if (g_gemm_tile == -2) { const char* v = getenv("VAW_GEMM_BIG"); g_gemm_tile = v ? atoi(v) : -1; }
         {
             const int force = g_gemm_tile == -1 ? -1 : g_gemm_tile == 4 ? 1 : (g_gemm_tile == 2 || g_gemm_tile == 3) ? g_gemm_tile : 0;
-            const P8Plan pl = (bk_env == 0 && !fused_rowsum)
+            const bool p8_epi_ok = !(e.act == 2 && e.gate) && !(e.resid && e.rowadd);     // gemm_epi.h: EpiOps has two slots
+            const P8Plan pl = (bk_env == 0 && !fused_rowsum && p8_epi_ok)
                                   ? vaw_p8_plan(M, N, K, plain_f32, colsum_out != nullptr, workspace_floats, force)
                                   : P8Plan{false, 4, 1, 0};
             if (pl.use) {
                 EpiDev ep8 = e;
+                static int nt_off = -1;
+                // default: epilogue stores with the default cache policy (measured: nt costs 5-15 % on the f32 gated-residual and
+                // the 192-column launches, whose row segments are not whole 128-byte lines, and the next kernel re-reads the
+                // output from L2 / MALL anyway); VAW_P8_NT=1 switches the non-temporal hint on
+                if (nt_off < 0) { const char* v = getenv("VAW_P8_NT"); nt_off = (v && atoi(v) == 1) ? 0 : 1; }
+                ep8.nt_off = nt_off;
                 ep8.colpart = colsum_out ? workspace : nullptr;
                 ep8.rowpart = nullptr;
                 vaw_p8_launch(pl, a_kmajor, b_kmajor, M, N, K, a, lda, b, ldb, ep8, s);

@@ -18,6 +18,7 @@ struct EpiDev {
     int64_t M, N, ldc;
     void* C;
     float* slab;   // split-K partial sums [n_split][M][N] f32 (workspace), or NULL
+    int nt_off;       // 1 (default): gemm_p8 epilogue stores use the default cache policy; 0 (VAW_P8_NT=1): non-temporal
     int debug;        // measurement only (VAW_GEMM_DEBUG): 1 = skip the epilogue, 2 = skip the K loop (ablations 3-5 of DESIGN.md §5 lived here)
     int direct_epi;   // 1: register-direct epilogue (default), 0: LDS-staged (VAW_GEMM_EPI=0; always for fused column sums)
     float* rowpart;   // mn-major A only (CONV 3 / plain weight gradients): [n_split][M] f32 partial row sums of A = dy^T
@@ -152,3 +153,136 @@ __device__ __forceinline__ void epi_row4(const EpiDev& e, unsigned m, int64_t n,
     }
 }
 
+
+// ---- the same row epilogue in two halves, specialised at compile time, for the persistent kernel (gemm_p8.hip), which
+// software-pipelines it: epi_load8 issues the global loads of one 8-column group one step ahead of the stores of the
+// previous group (the compiler may not hoist loads over possibly-aliasing stores itself), epi_apply8 does the arithmetic and
+// the stores.  EPI names the launch kinds of the training step; P8_ANY keeps every switch at run time.  GELU here goes through
+// v_rcp_f32 instead of the IEEE division sequence (bf16 MFMA path only; the f32 parity kernels keep gelu_tanh_f).
+enum { P8_STORE = 0,   // value = acc*alpha (+ bias) -> C (act dtype or f32)                      qkv forward, plain input gradients
+       P8_GELU = 1,    // (+ bias) -> aux_out (bf16) -> GELU -> C (bf16)                          fc1 forward
+       P8_DGELU = 2,   // * GELU'(aux_in) -> C (bf16), column sums optional                       fc2 input gradient
+       P8_GATE = 3,    // (+ bias) -> aux_out (bf16) -> * gate + resid (f32) -> C (f32)           proj / fc2 forward
+       P8_SLAB = 4,    // raw f32 partial sums of one K split                                     weight gradients
+       P8_ANY = 5 };
+template <int EPI> struct EpiKind {
+    static __device__ __forceinline__ bool act1(const EpiDev& e) { return EPI == P8_GELU || (EPI == P8_ANY && e.act == 1); }
+    static __device__ __forceinline__ bool act2(const EpiDev& e) { return EPI == P8_DGELU || (EPI == P8_ANY && e.act == 2); }
+    static __device__ __forceinline__ bool gate(const EpiDev& e) { return EPI == P8_GATE || (EPI == P8_ANY && e.gate != nullptr); }
+    static __device__ __forceinline__ bool resid(const EpiDev& e) { return EPI == P8_GATE || (EPI == P8_ANY && e.resid != nullptr); }
+    static __device__ __forceinline__ bool resid_act(const EpiDev& e) { return EPI == P8_ANY && e.resid_act; }
+    static __device__ __forceinline__ bool rowadd(const EpiDev& e) { return EPI == P8_ANY && e.rowadd != nullptr; }
+    static __device__ __forceinline__ bool aux_out(const EpiDev& e) { return EPI == P8_GELU || EPI == P8_GATE || (EPI == P8_ANY && e.aux_out != nullptr); }
+    static __device__ __forceinline__ bool out_f32(const EpiDev& e) { return EPI == P8_GATE || ((EPI == P8_ANY || EPI == P8_STORE) && e.out_f32); }
+    static __device__ __forceinline__ bool beta(const EpiDev& e) { return EPI == P8_ANY && e.beta != 0.f; }
+    static __device__ __forceinline__ bool colsum(const EpiDev& e) { return (EPI == P8_DGELU || EPI == P8_STORE || EPI == P8_ANY) && e.colpart != nullptr; }
+    static constexpr bool may_colsum = EPI == P8_DGELU || EPI == P8_STORE || EPI == P8_ANY;   // the sums are then always carried
+    static constexpr bool loads = EPI == P8_DGELU || EPI == P8_GATE || EPI == P8_ANY;     // epi_load8 has something to fetch
+};
+// Two operand slots: x = GELU'-argument (act == 2) or gate; y = residual or row-add (each pair is mutually exclusive in every
+// launch of the training step; the dispatcher keeps launches that set both members of a pair on the other kernel).
+struct EpiOps {
+    f32x4 x0, x1, y0, y1;
+};
+__device__ __forceinline__ float gelu_tanh_fast(float x) {
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    const float u2 = 2.f * k0 * (x + k1 * x * x * x);
+    return x * __builtin_amdgcn_rcpf(1.f + __expf(-u2));
+}
+__device__ __forceinline__ float gelu_tanh_grad_fast(float x) {
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    const float x2 = x * x;
+    const float u2 = 2.f * k0 * (x + k1 * x * x2);
+    const float s = __builtin_amdgcn_rcpf(1.f + __expf(-u2));
+    return s + x * s * (1.f - s) * (2.f * k0 * (1.f + 3.f * k1 * x2));
+}
+// (sample, row-in-sample) of row m are passed in: callers that walk rows in steps carry them instead of dividing
+template <int EPI>
+__device__ __forceinline__ void epi_load8(const EpiDev& e, unsigned m, int64_t n, unsigned sample, unsigned row_in_sample, EpiOps& o) {
+    using K = EpiKind<EPI>;
+    const int64_t off = (int64_t)m * e.ldc + n;
+    if (K::act2(e)) {
+        const bf16x8 h = *reinterpret_cast<const bf16x8*>((const bf16_t*)e.aux_in + off);
+        o.x0 = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+        o.x1 = f32x4{(float)h[4], (float)h[5], (float)h[6], (float)h[7]};
+    } else if (K::gate(e)) {
+        const float* g = e.gate + (int64_t)sample * e.gate_ld + n;
+        o.x0 = load4(g);
+        o.x1 = load4(g + 4);
+    }
+    if (K::resid(e)) {
+        if (K::resid_act(e)) {
+            const bf16x8 r = *reinterpret_cast<const bf16x8*>((const bf16_t*)e.resid + off);
+            o.y0 = f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+            o.y1 = f32x4{(float)r[4], (float)r[5], (float)r[6], (float)r[7]};
+        } else {
+            o.y0 = load4((const float*)e.resid + off);
+            o.y1 = load4((const float*)e.resid + off + 4);
+        }
+    } else if (K::rowadd(e)) {
+        const float* ra = e.rowadd + (int64_t)row_in_sample * e.N + n;
+        o.y0 = load4(ra);
+        o.y1 = load4(ra + 4);
+    }
+}
+// Stores of the pipelined epilogue go through buffer resources based at the tile's first element: a lane beyond the matrix
+// edge gets an out-of-range offset and the hardware drops its store.  No branch around the stores, so the compiler can
+// count its s_waitcnt for the operand loads that are in flight across them (a store inside a conditional block forces
+// vmcnt(0) at the join: the whole memory pipe drains once per step).
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+#define EPI_OOB 0xFFFFFFF0u
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t epi_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)0x80000000u, 0x00020000);
+}
+__device__ __forceinline__ void buf_store16(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, f32x4 v, bool nt) {
+    if (nt) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs, byte_off, 0, 2);
+    else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs, byte_off, 0, 0);
+}
+__device__ __forceinline__ void buf_store16(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, bf16x8 v, bool nt) {
+    if (nt) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs, byte_off, 0, 2);
+    else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs, byte_off, 0, 0);
+}
+// loc = element offset of (row, first column) from the tile's first element, or a negative value for "store nothing".
+// The beta read (P8_ANY) uses the plain pointer c_row = address of that row group when valid.
+template <int EPI>
+__device__ __forceinline__ void epi_apply8(const EpiDev& e, __amdgpu_buffer_rsrc_t rs_c, __amdgpu_buffer_rsrc_t rs_aux, int loc,
+                                           const float* c_f32, f32x4& v0, f32x4& v1, f32x4 b0, f32x4 b1, const EpiOps& o) {
+    using K = EpiKind<EPI>;
+    const bool ok = loc >= 0;
+    v0 = v0 * e.alpha + b0;
+    v1 = v1 * e.alpha + b1;
+    if (K::aux_out(e)) {
+        const bf16x8 r = {(bf16_t)v0[0], (bf16_t)v0[1], (bf16_t)v0[2], (bf16_t)v0[3],
+                          (bf16_t)v1[0], (bf16_t)v1[1], (bf16_t)v1[2], (bf16_t)v1[3]};
+        buf_store16(rs_aux, ok ? 2u * (unsigned)loc : EPI_OOB, r, !e.nt_off);
+        v0 = f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+        v1 = f32x4{(float)r[4], (float)r[5], (float)r[6], (float)r[7]};
+    }
+    if (K::act1(e)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v0[j] = gelu_tanh_fast(v0[j]); v1[j] = gelu_tanh_fast(v1[j]); }
+    } else if (K::act2(e)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v0[j] *= gelu_tanh_grad_fast(o.x0[j]); v1[j] *= gelu_tanh_grad_fast(o.x1[j]); }
+    } else if (K::gate(e)) {
+        v0 *= o.x0;
+        v1 *= o.x1;
+    }
+    if (K::resid(e) || K::rowadd(e)) { v0 += o.y0; v1 += o.y1; }
+    if (K::out_f32(e)) {
+        if (K::beta(e)) {      // c_f32 points at a valid row group (mirrored beyond the edge)
+            v0 += e.beta * load4(c_f32);
+            v1 += e.beta * load4(c_f32 + 4);
+        }
+        const unsigned bo = ok ? 4u * (unsigned)loc : EPI_OOB;
+        buf_store16(rs_c, bo, v0, !e.nt_off);
+        buf_store16(rs_c, ok ? bo + 16u : EPI_OOB, v1, !e.nt_off);
+    } else {
+        bf16x8 r = {(bf16_t)v0[0], (bf16_t)v0[1], (bf16_t)v0[2], (bf16_t)v0[3], (bf16_t)v1[0], (bf16_t)v1[1], (bf16_t)v1[2], (bf16_t)v1[3]};
+        buf_store16(rs_c, ok ? 2u * (unsigned)loc : EPI_OOB, r, !e.nt_off);
+        if (K::may_colsum) {
+            v0 = f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};   // what a later reader of C sees
+            v1 = f32x4{(float)r[4], (float)r[5], (float)r[6], (float)r[7]};
+        }
+    }
+}

@@ -1,0 +1,13 @@
+// Instantiations of the persistent GEMM kernel (gemm_p8_kernel.h) for the input-gradient layout: A [M][K] (dy), B [K][N] (weights as stored).
+#include "gemm_p8_kernel.h"
+
+void p8_launch_dgrad(const P8Launch& L, const EpiDev& e, hipStream_t s) {
+    switch (L.epi) {
+        P8_CASE(true, false, P8_STORE);
+        P8_CASE(true, false, P8_DGELU);
+        P8_CASE(true, false, P8_SLAB);
+        default:
+            if (L.ntw == 4) p8_launch_one<true, false, 4, P8_ANY>(L.a, L.lda, L.b, L.ldb, L.nk, L.tiles_m, L.tiles_n, L.split, L.grid, e, s, L.team_delay);
+            else p8_launch_one<true, false, 3, P8_ANY>(L.a, L.lda, L.b, L.ldb, L.nk, L.tiles_m, L.tiles_n, L.split, L.grid, e, s, L.team_delay);
+    }
+}

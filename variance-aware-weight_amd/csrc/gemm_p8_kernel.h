@@ -1,0 +1,411 @@
+// Persistent 256-row-tile bf16 MFMA GEMM for the large Linear launches of the training step
+// (models/dit.py:118-155: qkv / proj / fc1 / fc2 forward, input gradient and weight gradient; 12 D^2 MAC per token and block).
+//
+// Why a second kernel next to gemm_bf16_kernel (gemm.hip): the 128 x 128 tile moves 32 KiB from L2 into LDS per 2.1 MFLOP;
+// at two to three workgroups per CU that is 55-75 GB/s per CU, the ceiling of the vector-memory -> LDS path
+// (MI355X_MICROARCH.md "Indexed rows: gather into LDS"), so its main loop stalls on LDS-DMA whatever the schedule.
+// This kernel halves the staged bytes per MFMA and hides their latency completely:
+//   * one 512-thread workgroup per CU, tile 256 x BN (BN = 256 or 192: 192 divides the 768 / 2304 / 3072 / 1152-wide
+//     layers of DiT-B and DiT-XL into whole rounds of 256 workgroups), waves 2 (M) x 4 (N), wave tile 128 x BN/4;
+//   * K in 64-deep tiles through TWO LDS stages; a stage is cut into 8 KiB parts (64 rows of A or B), each filled by one
+//     LDS-DMA instruction per wave.  A K tile is computed in four phases (one 32-row quarter of each wave's A rows per
+//     phase, the B fragments of the tile held in registers); every phase issues the DMA of two parts that lie 4-6 phases
+//     ahead and waits with a COUNTED s_waitcnt vmcnt(N) only for the part the next phase reads, so 60-70 KiB stay in
+//     flight per CU across raw s_barriers (cdna_hip_programming.md "Pipelining across barriers", 8-phase template);
+//   * the two wave rows run half a phase apart (one extra barrier for waves 4-7 when a tile starts, one for waves 0-3 when
+//     it ends): while one wave of a SIMD issues its MFMA cluster the other reads fragments and issues DMA;
+//   * persistent: a workgroup walks a static list of (tile, K split) items; the DMA stream runs ahead across item
+//     boundaries, so the first K tiles of the next item land during the epilogue of the current one;
+//   * epilogue through a wave-private 4 KiB LDS image (no workgroup barrier): accumulators (held transposed: a lane owns 4
+//     consecutive columns of one row) -> XOR-swizzled f32 rows -> 8 consecutive columns per lane, 16-byte global accesses,
+//     the same epilogue arithmetic as gemm.hip (gemm_epi.h); column sums of the output (next bias gradient) stay in
+//     registers and leave as one partial row per wave row (128 rows), folded by vaw_reduce_rows in a fixed order;
+//   * split-K items write f32 slabs that splitk_reduce_kernel folds in a fixed order (deterministic, as in gemm.hip).
+// Operand layouts: k-major ([rows][K], ds_read_b128) or mn-major ([K][rows], ds_read_b64_tr_b16), any combination.
+//
+// LDS images of one 8 KiB part:
+//   k-major  [64 rows][128 B]   chunk' = chunk ^ ((row >> 1) & 7)                      (16-byte chunks, 8 per row)
+//   mn-major [64 k][64 cols]    chunk' = chunk ^ ((((k >> 1) & 1) | (((k >> 3) & 1) << 1)) << 1)
+// both conflict-free for the 16x16x32 fragment reads (bank = (addr/4) % 64; the swizzle is applied to the per-lane
+// SOURCE address of the DMA and to the read address: cdna_hip_programming.md rule 21).
+// A part i of a stage holds rows (or columns) {32 i .. 32 i + 31} and {128 + 32 i .. 128 + 32 i + 31} of the 256-row
+// A tile: exactly what the two wave rows read in phase i.  B part p holds rows 64 p .. 64 p + 63.
+#pragma once
+#include <stdlib.h>
+
+#include "gemm_epi.h"
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+#define P8_BM 256
+#define P8_PART 8192
+#define P8_EPI_BYTES 32768
+
+template <int NTW> struct P8Cfg {
+    static constexpr int BN = 64 * NTW;              // 4 waves x NTW MFMA tiles of 16 columns
+    static constexpr int WN = 16 * NTW;
+    static constexpr int a_bytes = 4 * P8_PART;
+    static constexpr int stage_bytes = (4 + NTW) * P8_PART;
+    static constexpr int lds_bytes = 2 * stage_bytes + P8_EPI_BYTES;
+};
+
+__device__ __forceinline__ int p8_mn_swz(int k) { return (((k >> 1) & 1) | (((k >> 3) & 1) << 1)) << 1; }
+
+// Per-lane element offset (from the tile's first element at the current K position) of the 16 bytes this lane's
+// LDS-DMA piece `wid` of part `p` fetches.  is_a: the A-part row set (two 32-row runs 128 apart), else 64 p + row.
+template <bool KMAJOR>
+__device__ __forceinline__ int p8_src_off(bool is_a, int p, int wid, int lane, int64_t ld, int valid) {
+    const int r = 8 * wid + (lane >> 3);          // row (k-major) or k (mn-major) within the part
+    if (KMAJOR) {
+        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+        int R = is_a ? (r < 32 ? 32 * p + r : 96 + 32 * p + r) : 64 * p + r;
+        R = R < valid ? R : valid - 1;            // LDS-DMA cannot zero-fill: rows beyond the edge mirror a valid row
+        return (int)(R * ld) + chunk * 8;
+    } else {
+        const int chunk = (lane & 7) ^ p8_mn_swz(r);
+        int col = is_a ? (chunk < 4 ? 32 * p + 8 * chunk : 96 + 32 * p + 8 * chunk) : 64 * p + 8 * chunk;
+        col = col < valid ? col : 0;
+        return (int)(r * ld) + col;
+    }
+}
+
+// 16 (rows r16 .. r16+15 of the part) x 32 (k sub-step s) operand fragment.
+template <bool KMAJOR>
+__device__ __forceinline__ bf16x8 p8_frag(const char* part, int r16, int s, int lane) {
+    if (KMAJOR) {
+        const int row = r16 + (lane & 15);
+        const int chunk = (4 * s + (lane >> 4)) ^ ((row >> 1) & 7);
+        return *reinterpret_cast<const bf16x8*>(part + row * 128 + (chunk << 4));
+    } else {
+        const int li = lane & 15, q = li >> 2, p = li & 3;
+        const int kb = 32 * s + 8 * (lane >> 4) + q;
+        const int ch = ((r16 >> 3) + (p >> 1)) ^ p8_mn_swz(kb);
+        const char* a0 = part + kb * 128 + (ch << 4) + 8 * (p & 1);
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)a0);
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(a0 + 512));   // k + 4: same swizzle
+        bf16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return r;
+    }
+}
+
+template <bool AK, bool BKM, int NTW, int EPI>
+__global__ void __launch_bounds__(512, 2)
+gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb, int nk_total,
+               int tiles_m, int tiles_n, int n_split, EpiDev e, int team_delay) {
+    using Cfg = P8Cfg<NTW>;
+    constexpr int LS = 4 + NTW;                                  // DMA pieces per wave and K tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A parts 0-3 | B parts] | 8 x 4 KiB epilogue images
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    // ---- static item list: G resident workgroups; XCD x (workgroups b = x mod 8) owns a contiguous run of every round ----
+    const int G = gridDim.x, n_tiles = tiles_m * tiles_n, n_items = n_tiles * n_split;
+    int it_cur;
+    {
+        const int b = blockIdx.x, x = b & 7, q = G >> 3, r = G & 7;
+        it_cur = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+    }
+    const int nk_per = (nk_total + n_split - 1) / n_split;
+    const int64_t a_step = AK ? 64 : 64 * lda, b_step = BKM ? 64 : 64 * ldb;
+
+    // ---- the DMA stream (runs ahead of the MFMAs; its own item / K-tile position) ----
+    int iss_item = it_cur, iss_kt = 0, iss_nk = 0, iss_stage = 0;
+    bool iss_done = iss_item >= n_items;
+    const bf16_t *iss_a = A, *iss_b = B;
+    int off_a[4], off_b[NTW];
+    auto iss_open = [&]() {                       // position the stream on the first K tile of item iss_item
+        const int split = iss_item / n_tiles, tile = iss_item - split * n_tiles;
+        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+        const int64_t m0 = (int64_t)tm * P8_BM, n0 = (int64_t)tn * Cfg::BN;
+        const int kt0 = split * nk_per;
+        iss_nk = kt0 + nk_per <= nk_total ? nk_per : nk_total - kt0;
+        iss_kt = 0;
+        const int mvalid = e.M - m0 < P8_BM ? (int)(e.M - m0) : P8_BM;
+        const int nvalid = e.N - n0 < Cfg::BN ? (int)(e.N - n0) : Cfg::BN;
+        iss_a = (AK ? A + m0 * lda : A + m0) + kt0 * a_step;
+        iss_b = (BKM ? B + n0 * ldb : B + n0) + kt0 * b_step;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) off_a[p] = p8_src_off<AK>(true, p, wid, lane, lda, mvalid);
+#pragma unroll
+        for (int p = 0; p < NTW; ++p) off_b[p] = p8_src_off<BKM>(false, p, wid, lane, ldb, nvalid);
+    };
+    if (!iss_done) iss_open();
+    // piece c of the stream order [B parts 0..NTW-1, A parts 0..3]
+    auto iss_piece = [&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        if (iss_done) return;
+        char* dst = smem + iss_stage * Cfg::stage_bytes + wid * 1024;
+        if (c < NTW) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(iss_b + off_b[c < NTW ? c : 0]), (lds_ptr_t)(dst + Cfg::a_bytes + c * P8_PART), 16, 0, 0);
+        else __builtin_amdgcn_global_load_lds((gbl_ptr_t)(iss_a + off_a[c >= NTW ? c - NTW : 0]), (lds_ptr_t)(dst + (c - NTW) * P8_PART), 16, 0, 0);
+    };
+    auto iss_advance = [&]() {                    // after the last piece of a K tile
+        if (iss_done) return;
+        iss_stage ^= 1;
+        iss_a += a_step;
+        iss_b += b_step;
+        if (++iss_kt == iss_nk) {
+            iss_item += G;
+            if (iss_item >= n_items) iss_done = true;
+            else iss_open();
+        }
+    };
+#define P8_PIECE(c) iss_piece(std::integral_constant<int, (c)>{})
+    // issue slots of the four phases (stream positions; NTW = 4: 2,2,2,2; NTW = 3: 2,2,2,1)
+    auto issue_ph1 = [&]() { P8_PIECE(4); P8_PIECE(5); };
+    auto issue_ph2 = [&]() { P8_PIECE(6); if (LS == 8) P8_PIECE(LS - 1); iss_advance(); };
+    auto issue_ph3 = [&]() { P8_PIECE(0); P8_PIECE(1); };
+    auto issue_ph4 = [&]() { P8_PIECE(2); P8_PIECE(3); };
+    // counted waits: pieces younger than the one the NEXT phase reads (derivation in DESIGN.md §5)
+#define P8_WAIT(n_full)                                                                     \
+    do {                                                                                    \
+        if (iss_done) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      \
+        else asm volatile("s_waitcnt vmcnt(" #n_full ")" ::: "memory");                     \
+    } while (0)
+
+    // prologue: K tile 0 of the stream completely, the ph3/ph4 slots of K tile 1
+    if (!iss_done) {
+        P8_PIECE(0); P8_PIECE(1); P8_PIECE(2); P8_PIECE(3); P8_PIECE(4); P8_PIECE(5); P8_PIECE(6);
+        if (LS == 8) P8_PIECE(LS - 1);
+        iss_advance();
+        issue_ph3();
+        issue_ph4();
+    }
+    if (team_delay > 0 && ((blockIdx.x >> 3) & 1)) {
+        // every other workgroup of an XCD starts `team_delay` x 10 ns late (its first K tiles are already in flight): the
+        // two teams then reach their HBM-bound epilogues at different times instead of all 256 CUs storing at once
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        while (__builtin_amdgcn_s_memrealtime() - t0 < (uint64_t)team_delay) __builtin_amdgcn_s_sleep(16);
+    }
+    P8_WAIT(7);
+    __builtin_amdgcn_s_barrier();
+
+    int stage = 0;
+    const int wn0 = wc * Cfg::WN;
+    for (; it_cur < n_items; it_cur += G) {
+        const int split = it_cur / n_tiles, tile = it_cur - split * n_tiles;
+        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+        const int64_t m0 = (int64_t)tm * P8_BM, n0 = (int64_t)tn * Cfg::BN;
+        const int kt0 = split * nk_per;
+        const int nk = kt0 + nk_per <= nk_total ? nk_per : nk_total - kt0;
+        f32x4 acc[8][NTW];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int u = 0; u < NTW; ++u) acc[i][u] = f32x4{0, 0, 0, 0};
+        if (wr == 1) __builtin_amdgcn_s_barrier();       // waves 4-7 run half a phase behind waves 0-3
+        int lane_k = lane;
+        asm volatile("" : "+v"(lane_k));      // opaque per item: fragment addresses are rebuilt per item, not kept live (and
+                                              // spilled) across the epilogue, whose register budget is the tight one
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* st = smem + stage * Cfg::stage_bytes;
+            stage ^= 1;
+            bf16x8 bfr[2][NTW], af[2][2];
+            auto load_a = [&](int j) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) af[s][t] = p8_frag<AK>(st + j * P8_PART, wr * 32 + 16 * t, s, lane_k);
+            };
+#define P8_MMA(j)                                                                                                     \
+    do {                                                                                                              \
+        __builtin_amdgcn_s_setprio(1);                                                                                \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                                 \
+            _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                             \
+                _Pragma("unroll") for (int u = 0; u < NTW; ++u)                                                       \
+                    acc[2 * (j) + t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[s][u], af[s][t], acc[2 * (j) + t][u], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                                \
+    } while (0)
+            // ---- phase 1: B fragments of the whole K tile + A quarter 0
+#pragma unroll
+            for (int u = 0; u < NTW; ++u) {
+                const int n = wn0 + 16 * u;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) bfr[s][u] = p8_frag<BKM>(st + Cfg::a_bytes + (n >> 6) * P8_PART, n & 63, s, lane_k);
+            }
+            load_a(0);
+            issue_ph1();
+            P8_WAIT(8);
+            __builtin_amdgcn_s_barrier();
+            P8_MMA(0);
+            __builtin_amdgcn_s_barrier();
+            // ---- phase 2
+            load_a(1);
+            issue_ph2();
+            if (LS == 8) P8_WAIT(9); else P8_WAIT(8);
+            __builtin_amdgcn_s_barrier();
+            P8_MMA(1);
+            __builtin_amdgcn_s_barrier();
+            // ---- phase 3
+            load_a(2);
+            issue_ph3();
+            if (LS == 8) P8_WAIT(10); else P8_WAIT(9);
+            __builtin_amdgcn_s_barrier();
+            P8_MMA(2);
+            __builtin_amdgcn_s_barrier();
+            // ---- phase 4
+            load_a(3);
+            issue_ph4();
+            P8_WAIT(7);
+            __builtin_amdgcn_s_barrier();
+            P8_MMA(3);
+            __builtin_amdgcn_s_barrier();
+        }
+        if (wr == 0) __builtin_amdgcn_s_barrier();       // level the two wave rows: both run their epilogues together
+
+        if (e.debug == 1) {   // measurement only (VAW_GEMM_DEBUG=1): no epilogue; one never-taken store keeps the accumulators alive
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int u = 0; u < NTW; ++u) t += acc[i][u][0] + acc[i][u][1] + acc[i][u][2] + acc[i][u][3];
+            if (t == 12345.678f) ((float*)e.C)[0] = t;
+            continue;
+        }
+        // ---- epilogue: 8 row tiles of 16 rows through this wave's private LDS image ----
+        char* ep = smem + 2 * Cfg::stage_bytes + wid * 4096;
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));      // opaque per item: the epilogue's per-lane addresses are recomputed here instead of
+                                              // being hoisted out of the item loop and kept (spilled) across the K loop
+        const int wr_row = lane_e & 15, wr_g = lane_e >> 4;             // accumulator layout: row, group of 4 columns
+        const int rd_row = lane_e >> 3, rd_c8 = lane_e & 7;             // read-back layout: row within 8, group of 8 columns
+        // The image is written and read with inline-asm DS instructions: the compiler orders an ordinary LDS store behind
+        // every pending LDS-DMA with s_waitcnt vmcnt(0), which would drain the prefetch of the next item and every global
+        // store of the previous step, 16 times per item.  DS operations of one wave execute in order, so the write ->
+        // read -> write sequence on this wave-private image needs no further fence.
+        // 16-byte chunk c of row r lives at r * 256 + ((c ^ r) << 4): (4u + g) ^ r = ((4u) ^ (r & 12)) + (g ^ (r & 3)).
+        const unsigned ep_base = (unsigned)(uintptr_t)(lds_ptr_t)ep;
+        const unsigned ep_w = ep_base + wr_row * 256 + ((wr_g ^ (wr_row & 3)) << 4);
+        unsigned ep_r[2];
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int rr = pass * 8 + rd_row;
+            ep_r[pass] = ep_base + rr * 256 + (((2 * rd_c8) ^ rr) << 4);     // chunk 2c; chunk 2c + 1 is this address ^ 16
+        }
+        const int64_t n = n0 + wn0 + 8 * rd_c8;
+        const bool col_ok = 8 * rd_c8 < Cfg::WN && n < e.N;             // N % 8 == 0: a group is in or out as a whole
+        using EK = EpiKind<EPI>;
+        // lanes beyond the matrix edge mirror a valid row / column for their loads and skip their stores
+        const int64_t n_ld = col_ok ? n : n0;
+        const int64_t m_last = e.M - 1;
+        f32x4 b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
+        if (EPI != P8_SLAB && EPI != P8_DGELU && e.bias) {
+            b0 = load4(e.bias + n_ld);
+            b1 = load4(e.bias + n_ld + 4);
+            asm volatile("" ::"v"(b0), "v"(b1));   // the compiler waits for the bias HERE, once (this drains the DMA prefetch of
+                                                   // the next item, issued 2-4 phases ago), instead of with a vmcnt(0) in
+                                                   // every step, which would drain the stores of the step before
+        }
+        f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
+        // output buffers based at the tile's first element (m0, n0); loc_col = this lane's column offset in the tile
+        const int loc_col = wn0 + 8 * rd_c8;
+        const bool c_f32 = EK::out_f32(e);
+        const int64_t tile_off = m0 * e.ldc + n0;
+        const __amdgpu_buffer_rsrc_t rs_c =
+            EPI == P8_SLAB ? epi_rsrc(e.slab + (int64_t)split * e.M * e.N + m0 * e.N + n0)
+                           : epi_rsrc(c_f32 ? (const void*)((const float*)e.C + tile_off) : (const void*)((const bf16_t*)e.C + tile_off));
+        const __amdgpu_buffer_rsrc_t rs_aux = epi_rsrc(EK::aux_out(e) ? (const void*)((const bf16_t*)e.aux_out + tile_off) : (const void*)e.C);
+        // rows of this lane, step k = 2 i + pass: m = mrow0 + 8 k; (sample, row in sample) carried along for gate / rowadd
+        const int64_t mrow0 = m0 + wr * 128 + rd_row;
+        const unsigned rpb = (unsigned)e.rpb;
+        unsigned smp = 0, rin = 0;
+        EpiOps ops[2];
+        const bool with_ops = EK::loads && (EK::act2(e) || EK::gate(e) || EK::resid(e) || EK::rowadd(e));
+        if (with_ops) {
+            const int64_t mc = mrow0 < m_last ? mrow0 : m_last;
+            smp = (unsigned)mc / rpb;
+            rin = (unsigned)mc % rpb;
+            epi_load8<EPI>(e, (unsigned)mc, n_ld, smp, rin, ops[0]);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int u = 0; u < NTW; ++u)
+                asm volatile("ds_write_b128 %0, %1" ::"v"(ep_w + (unsigned)(((4 * u) ^ (wr_row & 12)) << 4)), "v"(acc[i][u]) : "memory");
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                const int k = 2 * i + pass;
+                const int64_t m = mrow0 + 8 * k;
+                if (with_ops && k + 1 < 16) {        // operands of the next step: in flight while this step computes and stores
+                    int64_t mn = m + 8;
+                    if (mn <= m_last) {
+                        rin += 8;
+                        if (rin >= rpb) {
+                            if (rpb >= 8) { rin -= rpb; smp += 1; }
+                            else { smp += rin / rpb; rin %= rpb; }
+                        }
+                    } else {
+                        mn = m_last;                 // beyond the edge: any valid row (its result is not stored)
+                        smp = (unsigned)mn / rpb;
+                        rin = (unsigned)mn % rpb;
+                    }
+                    epi_load8<EPI>(e, (unsigned)mn, n_ld, smp, rin, ops[(k + 1) & 1]);
+                }
+                f32x4 v0, v1;
+                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(v0), "=&v"(v1)
+                             : "v"(ep_r[pass]), "v"(ep_r[pass] ^ 16u)
+                             : "memory");
+                __builtin_amdgcn_sched_barrier(0);   // nothing that reads v0 / v1 may move above the wait (rule 18)
+                const bool ok = col_ok && m <= m_last;
+                const int loc = ok ? (int)((m - m0) * e.ldc) + loc_col : -1;
+                if (EPI == P8_SLAB) {
+                    // split-K partials are re-read at once by the reduce: default cache policy
+                    const unsigned bo = ok ? 4u * (unsigned)((m - m0) * e.N + loc_col) : EPI_OOB;
+                    buf_store16(rs_c, bo, v0, false);
+                    buf_store16(rs_c, ok ? bo + 16u : EPI_OOB, v1, false);
+                } else {
+                    const int64_t mc = m <= m_last ? m : m_last;
+                    epi_apply8<EPI>(e, rs_c, rs_aux, loc, (const float*)e.C + mc * e.ldc + n_ld, v0, v1, b0, b1, ops[k & 1]);
+                    if (EK::may_colsum) {      // unconditional arithmetic (a run-time condition here makes the compiler keep
+                                               // all 16 steps' values alive and sum them at the end: spills)
+                        const f32x4 z = {0, 0, 0, 0};
+                        s0 += ok ? v0 : z;
+                        s1 += ok ? v1 : z;
+                        asm volatile("" : "+v"(s0), "+v"(s1));   // pins the adds here (the compiler otherwise sinks the whole chain
+                                                                 // into the `if (colsum)` block below and spills its 16 inputs)
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);   // keep the 16 unrolled steps apart: hoisting across them spills
+            }
+        }
+        if (EK::colsum(e)) {
+            // 8 row groups of the read-back layout: fold lane bits 3, 4, 5 in a fixed order; one partial row per wave row
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s0[j] += __shfl_xor(s0[j], 8, 64); s0[j] += __shfl_xor(s0[j], 16, 64); s0[j] += __shfl_xor(s0[j], 32, 64);
+                s1[j] += __shfl_xor(s1[j], 8, 64); s1[j] += __shfl_xor(s1[j], 16, 64); s1[j] += __shfl_xor(s1[j], 32, 64);
+            }
+            if (lane_e < 8 && col_ok && m0 + wr * 128 < e.M) {
+                float* cp = e.colpart + (2 * (int64_t)tm + wr) * e.N + n;
+                store4(cp, s0);
+                store4(cp + 4, s1);
+            }
+        }
+    }
+}
+
+
+template <bool AK, bool BKM, int NTW, int EPI>
+static void p8_launch_one(const bf16_t* a, int64_t lda, const bf16_t* b, int64_t ldb, int nk, int tiles_m, int tiles_n, int split,
+                          int grid, const EpiDev& e, hipStream_t s, int team_delay) {
+    static bool attr_done = false;
+    const int lds = P8Cfg<NTW>::lds_bytes;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)gemm_p8_kernel<AK, BKM, NTW, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_done = true;
+    }
+    gemm_p8_kernel<AK, BKM, NTW, EPI><<<grid, 512, lds, s>>>(a, lda, b, ldb, nk, tiles_m, tiles_n, split, e, team_delay);
+}
+
+// arguments of one launch, as the per-layout translation units receive them
+struct P8Launch {
+    const bf16_t *a, *b;
+    int64_t lda, ldb;
+    int nk, tiles_m, tiles_n, split, grid, ntw, epi, team_delay;
+};
+#define P8_CASE(AKv, BKv, EPIv)                                                                                                  \
+    case EPIv:                                                                                                                  \
+        if (L.ntw == 4) p8_launch_one<AKv, BKv, 4, EPIv>(L.a, L.lda, L.b, L.ldb, L.nk, L.tiles_m, L.tiles_n, L.split, L.grid, e, s, L.team_delay); \
+        else p8_launch_one<AKv, BKv, 3, EPIv>(L.a, L.lda, L.b, L.ldb, L.nk, L.tiles_m, L.tiles_n, L.split, L.grid, e, s, L.team_delay);           \
+        break

@@ -109,9 +109,11 @@ class FlatModule(nn.Module):
         new = cls.__new__(cls)
         memo[id(self)] = new
         import copy
-        skip = {"_flat", "_flat_grad", "_flat_shadow", "_flat_params", "_ws"}
+        skip = {"_flat", "_flat_grad", "_flat_shadow", "_flat_params"}
+        # per-batch workspaces / tapes / descriptors hold activations of the source model: the copy starts with none
+        fresh = {"_ws": dict, "_ws_cur": lambda: None, "_adesc": lambda: None, "_tape": list}
         for k, v in self.__dict__.items():
-            new.__dict__[k] = None if k in skip else copy.deepcopy(v, memo)
+            new.__dict__[k] = None if k in skip else fresh[k]() if k in fresh else copy.deepcopy(v, memo)
         new._flat_dirty = True
         return new
 

@@ -336,3 +336,8 @@ def ema_update(ema, src, decay):
 
 def cast_bf16(src, dst):
     check(L.lib().vaw_cast_bf16(ptr(src), ptr(dst), src.numel(), stream_ptr()), "vaw_cast_bf16")
+
+
+def uncast_bf16(src, dst, scale=1.0):
+    """dst (f32) = scale * src (bf16), on the current stream."""
+    check(L.lib().vaw_uncast_bf16(ptr(src), ptr(dst), src.numel(), float(scale), stream_ptr()), "vaw_uncast_bf16")

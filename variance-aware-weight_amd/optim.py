@@ -93,18 +93,65 @@ class FusedAdamW(torch.optim.Optimizer):
     def zero_grad(self, set_to_none=True):
         self.model.zero_grad_flat()
 
+    # ---- checkpoint format: torch.optim.AdamW's, indexed like AdamW(model.parameters()) of the reference (main.py:354,
+    # tools/utils.py:93-106), so optimizer states move between the reference and this engine in both directions ----
+    def _ckpt_params(self):
+        """[(name, param, trainable)] in model.parameters() order -- the index space of the reference's optimizer state."""
+        m = self.model
+        return [(n, p, n in m._flat_offsets and m._flat_offsets[n][0] < m._flat_n_train and p.requires_grad)
+                for n, p in m.named_parameters()]
+
+    def _moment_view(self, buf, name, p):
+        m = self.model
+        o, k = m._flat_offsets[name]
+        return m._view_as_param(buf[o:o + k], p, m._flat_cl[name])
+
     def state_dict(self):
-        sd = super().state_dict()
-        sd["vaw_flat"] = {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self.step_count}
-        return sd
+        self.model.ensure_flat()
+        grp = {k: v for k, v in self.param_groups[0].items() if k != "params"}
+        entries = self._ckpt_params()
+        grp["params"] = list(range(len(entries)))
+        state = {}
+        if self.step_count > 0:
+            for i, (n, p, trainable) in enumerate(entries):
+                if trainable:
+                    state[i] = {"step": torch.tensor(float(self.step_count)),
+                                "exp_avg": self._moment_view(self.exp_avg, n, p).contiguous().clone(),
+                                "exp_avg_sq": self._moment_view(self.exp_avg_sq, n, p).contiguous().clone()}
+        return {"state": state, "param_groups": [grp]}
 
     def load_state_dict(self, sd):
-        flat = sd.get("vaw_flat")
+        self.model.ensure_flat()
+        flat = sd.get("vaw_flat")                      # round-1 private format
         if flat is not None:
             self.exp_avg.copy_(flat["exp_avg"])
             self.exp_avg_sq.copy_(flat["exp_avg_sq"])
             self.step_count = int(flat["step"])
+        else:
+            state = sd.get("state", {})
+            entries = self._ckpt_params()
+            groups = sd.get("param_groups", [])
+            n_saved = sum(len(g.get("params", [])) for g in groups)
+            if state and n_saved != len(entries):
+                raise ValueError(f"optimizer state covers {n_saved} parameters, the model has {len(entries)}")
+            steps = set()
+            self.exp_avg.zero_()
+            self.exp_avg_sq.zero_()
+            for i, (n, p, trainable) in enumerate(entries):
+                st = state.get(i, state.get(str(i)))
+                if st is None:
+                    continue
+                if not trainable:
+                    raise ValueError(f"optimizer state for frozen parameter {n}")
+                if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                    raise ValueError(f"optimizer state of {n}: shape {tuple(st['exp_avg'].shape)} != {tuple(p.shape)}")
+                self._moment_view(self.exp_avg, n, p).copy_(st["exp_avg"])
+                self._moment_view(self.exp_avg_sq, n, p).copy_(st["exp_avg_sq"])
+                steps.add(int(float(st["step"])))
+            if len(steps) > 1:
+                raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): the fused kernel keeps one")
+            self.step_count = steps.pop() if steps else 0
         for g_new, g_old in zip(self.param_groups, sd["param_groups"]):
             for k in ("lr", "betas", "eps", "weight_decay", "initial_lr"):
                 if k in g_old:
-                    g_new[k] = g_old[k]
+                    g_new[k] = tuple(g_old[k]) if k == "betas" else g_old[k]

@@ -21,12 +21,19 @@ from .flat import FlatModule
 
 
 class DistributedDataParallel(nn.Module):
-    def __init__(self, module, device_ids=None, output_device=None, process_group=None, broadcast=True):
+    """bucket_dtype: "f32" (reference DDP semantics: f32 buckets, main.py:347-348) or "bf16": each bucket is cast to bf16 on
+    the side stream, all-reduced at half the wire bytes (xGMI is per-link bound: SURVEY.md §5) and widened back into the f32
+    gradient buffer before the optimizer reads it.  The sum itself is then taken in bf16 by RCCL: a throughput option, off
+    in parity runs."""
+
+    def __init__(self, module, device_ids=None, output_device=None, process_group=None, broadcast=True, bucket_dtype="f32"):
         super().__init__()
         if not isinstance(module, FlatModule):
             raise TypeError("vaw_amd.DistributedDataParallel wraps FlatModule denoisers (e.g. vaw_amd.DiT)")
         if not dist.is_initialized():
             raise RuntimeError("init the process group first (vaw_amd.dist_util.setup_dist)")
+        if bucket_dtype not in ("f32", "bf16"):
+            raise ValueError("bucket_dtype must be 'f32' or 'bf16'")
         self.module = module
         self.pg = process_group
         self.world = dist.get_world_size(process_group)
@@ -36,11 +43,17 @@ class DistributedDataParallel(nn.Module):
         self._cuda = module._flat.is_cuda
         self._comm = torch.cuda.Stream() if self._cuda else None
         self._backend_avg = dist.get_backend(process_group) == "nccl"     # RCCL has ReduceOp.AVG; gloo does not
+        self._wire = None
+        if bucket_dtype == "bf16":
+            self._wire = torch.empty(module._flat_n_train, device=module._flat.device, dtype=torch.bfloat16)
         if broadcast:
             dist.broadcast(module._flat, src=0, group=process_group)     # one collective for all parameters
             if getattr(module, "_flat_shadow", None) is not None:
                 module._shadow_version = None                            # the bf16 copy must follow the new weights
         self._ranges = self._stage_ranges()
+        n_buckets = sum(len(r) if isinstance(r, list) else 1 for r in self._ranges.values())
+        self._events = [torch.cuda.Event() for _ in range(n_buckets)] if self._cuda else []   # one per bucket, reused every step
+        self._issued = 0
         module.grad_ready_hook = self._on_stage
 
     # stage -> (start, end) element range of the flat gradient buffer that is final once `stage` fires
@@ -63,35 +76,74 @@ class DistributedDataParallel(nn.Module):
         finally:
             self._sync = prev
 
+    def _to_wire(self, g, lo, hi):
+        """f32 gradient range -> its bf16 wire buffer (current stream)."""
+        w = self._wire[lo:hi]
+        if self._cuda:
+            from . import ops
+            ops.cast_bf16(g, w)
+        else:
+            w.copy_(g)
+        return w
+
+    def _from_wire(self, w, g):
+        """Reduced bf16 bucket -> f32 gradients, with the 1/world of backends that can only sum (current stream)."""
+        scale = 1.0 if self._backend_avg else 1.0 / self.world
+        if self._cuda:
+            from . import ops
+            ops.uncast_bf16(w, g, scale)
+        else:
+            g.copy_(w.float() * scale)
+
+    def _retire(self, entry):
+        """Wait for one bucket's collective and put its result where the optimizer reads it (current stream)."""
+        work, g, w = entry
+        work.wait()
+        if w is not None:
+            self._from_wire(w, g)
+        elif not self._backend_avg:
+            g.div_(self.world)
+
     def _on_stage(self, stage):
         if not self._sync or self.world == 1:
             return
         rngs = self._ranges.get(stage)
         if rngs is not None and not isinstance(rngs, list):
             rngs = [rngs]
-        for rng in rngs or ():
-            if rng[1] <= rng[0]:
+        op = dist.ReduceOp.AVG if self._backend_avg else dist.ReduceOp.SUM
+        for lo, hi in rngs or ():
+            if hi <= lo:
                 continue
-            g = self.module.flat_grads()[rng[0]:rng[1]]
-            op = dist.ReduceOp.AVG if self._backend_avg else dist.ReduceOp.SUM
+            g = self.module.flat_grads()[lo:hi]
             if self._cuda:
-                ev = torch.cuda.Event()
+                ev = self._events[self._issued % len(self._events)]
+                self._issued += 1
                 ev.record()
                 with torch.cuda.stream(self._comm):
+                    # RCCL work.wait() only orders the side stream behind the collective: retiring the previous bucket here
+                    # widens it back to f32 while backward is still running (gloo would block the host: it retires in finish)
+                    if self._backend_avg and self._pending:
+                        self._retire(self._pending.pop(0))
                     self._comm.wait_event(ev)
-                    w = dist.all_reduce(g, op=op, group=self.pg, async_op=True)
+                    buf = self._to_wire(g, lo, hi) if self._wire is not None else g
+                    work = dist.all_reduce(buf, op=op, group=self.pg, async_op=True)
             else:
-                w = dist.all_reduce(g, op=op, group=self.pg, async_op=True)
-            self._pending.append((w, None if self._backend_avg else g))
+                buf = self._to_wire(g, lo, hi) if self._wire is not None else g
+                work = dist.all_reduce(buf, op=op, group=self.pg, async_op=True)
+            self._pending.append((work, g, buf if self._wire is not None else None))
         if stage == 0:
             self.finish()
 
     def finish(self):
-        """Make the compute stream wait for every bucket (called at the end of backward)."""
-        for w, g in self._pending:
-            w.wait()
-            if g is not None:
-                g.div_(self.world)
-        if self._cuda and self._pending:
-            torch.cuda.current_stream().wait_stream(self._comm)
+        """Retire every outstanding bucket and make the compute stream wait for the side stream (end of backward)."""
+        if self._cuda:
+            with torch.cuda.stream(self._comm):
+                for entry in self._pending:
+                    self._retire(entry)
+            if self._pending or self._issued:
+                torch.cuda.current_stream().wait_stream(self._comm)
+        else:
+            for entry in self._pending:
+                self._retire(entry)
         self._pending = []
+        self._issued = 0

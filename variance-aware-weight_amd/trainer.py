@@ -82,7 +82,9 @@ class Trainer:
         if self._use_graph:
             why = ("needs vaw_amd.FusedAdamW" if not self._fused else "not with DDP (args.parallel)" if args.parallel else
                    "not with grad_accumulation > 1" if max(1, args.grad_accumulation) > 1 else
-                   "not with args.cpu_rng" if self._cpu_rng else "needs a CUDA device" if torch.device(device).type != "cuda" else None)
+                   "not with args.cpu_rng" if self._cpu_rng else "needs a CUDA device" if torch.device(device).type != "cuda" else
+                   "the model draws its label-drop mask on the host every step (UNet drop_label_prob > 0)"
+                   if getattr(inner, "host_rng_in_forward", False) else None)
             if why:
                 raise ValueError(f"args.hip_graph: {why}")
             optimizer.enable_device_hyper()
@@ -137,7 +139,8 @@ class Trainer:
         self._apply_gradient_clipping()
         self.optimizer.step()
         self.optimizer.zero_grad()
-        return loss.detach(), loss_dict["mse"].detach().mean()
+        # pure KL / RESCALED_KL objectives carry no "mse" term (reference tools/trainer.py:116 guards the same way)
+        return loss.detach(), (loss_dict["mse"].detach().mean() if "mse" in loss_dict else torch.zeros_like(loss.detach()))
 
     def _train_step_graph(self, step):
         a = self.args
@@ -196,7 +199,7 @@ class Trainer:
                 loss = loss_dict["loss"].mean() / accum
                 loss.backward()
             ld = loss.detach()
-            md = loss_dict["mse"].detach().mean() / accum
+            md = loss_dict["mse"].detach().mean() / accum if "mse" in loss_dict else torch.zeros_like(ld)
             total = ld if total is None else total + ld
             mse_avg = md if mse_avg is None else mse_avg + md
             if (i + 1) % accum == 0:

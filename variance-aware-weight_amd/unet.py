@@ -182,6 +182,7 @@ class UNetModel(FlatModule):
         self.emb_cols = off
         self.set_compute_dtype(compute_dtype)
         self._anchor = torch.zeros(1, requires_grad=True)
+        self._tape, self._tape_gen, self._rec, self._record_next = [], 0, True, True
         self.grad_ready_hook = None
 
     # ---- flat storage -----------------------------------------------------------------------
@@ -236,7 +237,14 @@ class UNetModel(FlatModule):
                     drop = force_drop_ids == 1
                 y = torch.where(drop, self.num_classes, y)
             assert y.shape == (x.shape[0],)
+        self._record_next = torch.is_grad_enabled()
         return _UNetFn.apply(self._anchor, self, x, timesteps, y)
+
+    @property
+    def host_rng_in_forward(self):
+        """True when forward() draws random numbers on the host (the CFG label-drop mask, reference models/unet.py:644-653):
+        such a step cannot be captured into a hipGraph (the mask would freeze at its capture-time value)."""
+        return self.num_classes > 0 and self.drop_label_prob > 0
 
     # ---- engine helpers -----------------------------------------------------------------------
     def _w(self, name):
@@ -279,7 +287,7 @@ class UNetModel(FlatModule):
                                           L.stream_ptr()), "groupnorm_bwd")
             a.grad = dx
             y.grad = None
-        self._tape.append(bw)
+        self._push(bw)
         return y
 
     def _conv3(self, a, mod, resid=None):
@@ -340,7 +348,7 @@ class UNetModel(FlatModule):
             if resid is not None:
                 self._acc(resid, dy)
             y.grad = None
-        self._tape.append(bw)
+        self._push(bw)
         return y
 
     def _linear(self, a, wname, bname, Co, resid=None):
@@ -361,7 +369,7 @@ class UNetModel(FlatModule):
             if resid is not None:
                 self._acc(resid, dy)
             y.grad = None
-        self._tape.append(bw)
+        self._push(bw)
         return y
 
     def _resample(self, a, up):
@@ -376,7 +384,7 @@ class UNetModel(FlatModule):
             L.check(lib.vaw_resample2(dt, ptr(y.grad), ptr(dx), a.B, a.H, a.W, C, 0 if up else 1, 1.0 if up else 0.25, L.stream_ptr()), "resample2")
             self._acc(a, dx)
             y.grad = None
-        self._tape.append(bw)
+        self._push(bw)
         return y
 
     def _cat(self, a, b):
@@ -390,7 +398,7 @@ class UNetModel(FlatModule):
             self._acc(a, da)
             self._acc(b, db)
             y.grad = None
-        self._tape.append(bw)
+        self._push(bw)
         return y
 
     def _attention(self, a, mod):
@@ -418,7 +426,7 @@ class UNetModel(FlatModule):
             ops.attn_bwd(dt, desc, q, q + ko, q + vo, ptr(o.t), ptr(o.grad), ptr(lse), ptr(delta), dq, dq + ko, dq + vo)
             self._acc(qkv, dqkv)
             o.grad = None
-        self._tape.append(bw)
+        self._push(bw)
         return self._linear(o, name + ".proj_out.weight", name + ".proj_out.bias", C, resid=a)
 
     def _resblock(self, x, rb):
@@ -462,7 +470,31 @@ class UNetModel(FlatModule):
             L.check(L.lib().vaw_add_inplace(self._dt, ptr(a.grad), ptr(g), g.numel(), L.stream_ptr()), "add_inplace")
 
     # ---- whole-model forward / backward ---------------------------------------------------------------------------
-    def _forward_impl(self, x, t, y, need_dx):
+    def _push(self, bw):
+        if self._rec:
+            self._tape.append(bw)
+
+    _FWD_STATE = ("_s", "_x_act", "_out_act", "_emb_base", "_need_dx")
+
+    def _forward_impl(self, x, t, y, need_dx, record=True):
+        """record=False (forward under torch.no_grad(): sampling, evaluation) builds no tape and leaves the tape and the
+        saved activations of a pending training forward untouched."""
+        if not record:
+            keep = {k: getattr(self, k, None) for k in self._FWD_STATE}
+            tape = self._tape
+            try:
+                self._rec = False
+                return self._forward_body(x, t, y, False)
+            finally:
+                self._rec = True
+                self._tape = tape
+                for k, v in keep.items():
+                    setattr(self, k, v)
+        self._rec = True
+        self._tape_gen += 1
+        return self._forward_body(x, t, y, need_dx)
+
+    def _forward_body(self, x, t, y, need_dx):
         self.ensure_flat()
         dt, lib, st = self._dt, L.lib(), L.stream_ptr()
         self._adt = L.TORCH_DTYPE[dt]
@@ -473,7 +505,9 @@ class UNetModel(FlatModule):
             self._wbase, self._wsize = self._flat.data_ptr(), 4
         B, C, H, W = x.shape
         assert C == self.in_channels and H == W == self.image_size
-        self._tape, self._need_dx = [], need_dx
+        self._need_dx = need_dx
+        if self._rec:
+            self._tape = []
         ted, mc, f32 = self.time_embed_dim, self.model_channels, torch.float32
         x = x.float().contiguous()
         tf = t.float().contiguous()
@@ -507,9 +541,9 @@ class UNetModel(FlatModule):
         for blk in self.input_blocks:
             h = self._run(blk, h)
             hs.append(h)
-        self._tape.append(lambda: self._stage_done(2))      # popped once middle_block has been back-propagated
+        self._push(lambda: self._stage_done(2))      # popped once middle_block has been back-propagated
         h = self._run(self.middle_block, h)
-        self._tape.append(lambda: self._stage_done(3))      # ... once output_blocks + out have been
+        self._push(lambda: self._stage_done(3))      # ... once output_blocks + out have been
         for blk in self.output_blocks:
             h = self._run(blk, self._cat(h, hs.pop()))
         h = self._conv3(self._gn(h, self.out[0], silu=True), self.out[2])
@@ -578,13 +612,16 @@ class _UNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, model, x, t, y):
         ctx.model = model
-        return model._forward_impl(x, t, y, x.requires_grad)
+        out = model._forward_impl(x, t, y, x.requires_grad, record=model._record_next)
+        ctx.gen = model._tape_gen
+        return out
 
     @staticmethod
     def backward(ctx, dout):
         m = ctx.model
-        if not m._tape:
-            raise L.VawError("UNet backward: the tape of this forward was already consumed (or a later forward replaced it)")
+        if not m._tape or m._tape_gen != ctx.gen:
+            raise L.VawError("UNet backward: the tape of this forward was already consumed, or a later forward of the same "
+                             "module replaced it (run sampling / evaluation forwards under torch.no_grad())")
         dx = m._backward_impl(dout.contiguous())
         return torch.zeros_like(m._anchor), None, dx, None, None
 
