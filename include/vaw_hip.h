@@ -122,6 +122,25 @@ int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int64_t N, int
              const void* B, int64_t ldb, void* C, int64_t ldc, const vaw_epilogue* epi_host, float* workspace,
              int64_t workspace_floats, vaw_stream stream);
 
+/* Weight gradients of many Linear layers in ONE launch: dW_p[M_p,N_p] = beta*dW_p + dy_p[K,M_p]^T . x_p[K,N_p] for
+ * p = 0..n_problems-1, all sharing K (= tokens of the batch).  Replaces the per-layer `dy^T x` GEMMs that autograd
+ * issues in the reference (models/dit.py:118-155 backward of qkv / proj / fc1 / fc2), deferred to the end of backward:
+ * with K = B*T long and M_p*N_p small, a per-layer launch must split K over the chip and move every tile through an
+ * f32 slab; all layers together give enough whole tiles for every CU, and only the tiles of the last, partial round are
+ * K-split (folded in a fixed order: results do not depend on scheduling).
+ * problems: HOST array; desc_dev: device scratch of vaw_wgrad_grouped_desc_bytes(n) bytes that holds the device copy
+ * of the table -- upload != 0 (re)writes it on `stream` (pass 1 the first time and whenever a pointer changed).
+ * workspace: f32 slabs for the K-split tiles (256 * 256 * n_CUs floats are always enough; smaller ones lower the split). */
+typedef struct {
+    const void* dy;        /* act dtype (bf16) [K][M], row stride ld_dy */
+    const void* x;         /* act dtype (bf16) [K][N], row stride ld_x */
+    float* dw;             /* f32 [M][N], row stride ld_dw */
+    int64_t M, N, ld_dy, ld_x, ld_dw;
+} vaw_wgrad_problem;
+int64_t vaw_wgrad_grouped_desc_bytes(int n_problems);
+int vaw_wgrad_grouped(vaw_dtype dt, int n_problems, const vaw_wgrad_problem* problems, int64_t K, float beta, void* desc_dev,
+                      int upload, float* workspace, int64_t workspace_floats, vaw_stream stream);
+
 /* 1 when vaw_gemm would run these operands on the bf16 MFMA kernel (M%128==0, N%128==0, K%64==0, 16-byte
  * aligned rows), 0 when it takes the exact-f32 generic kernel.  For measurement and tests. */
 int vaw_gemm_uses_bf16_mfma(vaw_dtype dt, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,

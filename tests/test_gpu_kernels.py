@@ -304,6 +304,36 @@ def _gemm_epilogues(dtype):
                                **(tol if dtype == torch.float32 else dict(rtol=2e-2, atol=5e-2)))
 
 
+@pytest.mark.parametrize("case", ["few_tiles_split", "full_rounds_plus_split", "n192", "edges_accumulate"])
+def test_wgrad_grouped_exact_integers(case):
+    """vaw_wgrad_grouped: many dW_p (+)= dy_p^T x_p in one launch; whole tiles + K-split tiles of the last round + fixup.
+    Small integers are exact in bf16 / f32, so every tile of every problem must match bit for bit."""
+    g = torch.Generator().manual_seed(11)
+    shapes, K, beta = {
+        "few_tiles_split": ([(768, 768), (2304, 768), (256, 512)], 1024, 0.0),            # 9 + 27 + 2 tiles: all K-split
+        "full_rounds_plus_split": ([(512, 512)] * 70, 2560, 0.0),                          # 280 tiles: 256 whole + 24 split
+        "n192": ([(384, 1152), (1152, 384), (256, 192)], 512, 0.0),                        # every N % 192 == 0: 192-column tiles
+        "edges_accumulate": ([(200, 264), (520, 72), (136, 1000)], 320, 1.0),              # edge tiles in M and N, beta = 1
+    }[case]
+    probs, keep, refs = [], [], []
+    for (M, N) in shapes:
+        dy = torch.randint(-2, 3, (K, M), generator=g).float()
+        x = torch.randint(-2, 3, (K, N), generator=g).float()
+        dw0 = torch.randint(-5, 6, (M, N), generator=g).float()
+        dyd, xd, dwd = dy.to(DEV).bfloat16(), x.to(DEV).bfloat16(), dw0.to(DEV).clone()
+        keep += [dyd, xd, dwd]
+        probs.append((ptr(dyd), ptr(xd), ptr(dwd), M, N, M, N, N))
+        refs.append((dwd, beta * dw0.double() + dy.double().t() @ x.double()))
+    grp = ops.WgradGroup(probs, K, torch.device(DEV))
+    grp.launch(BF16, beta)
+    for i, (got, ref) in enumerate(refs):
+        assert torch.equal(got.cpu().double(), ref), (case, i, shapes[i], (got.cpu().double() - ref).abs().max())
+    if beta == 0.0:      # second launch reuses the uploaded table and must reproduce the result
+        grp.launch(BF16, 0.0)
+        for got, ref in refs:
+            assert torch.equal(got.cpu().double(), ref)
+
+
 def test_gemm_rejects_bad_arguments():
     A = torch.zeros(8, 8, device=DEV)
     with pytest.raises(vaw_amd.VawError):

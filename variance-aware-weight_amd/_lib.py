@@ -70,6 +70,7 @@ _PROTOS = {
     "vaw_ema_update": [_p, _p, _l, _f, _p],
     "vaw_cast_bf16": [_p, _p, _l, _p],
     "vaw_uncast_bf16": [_p, _p, _l, _f, _p],
+    "vaw_wgrad_grouped": [_i, _i, _p, _l, _f, _p, _i, _p, _l, _p],
 }
 
 _lib = None
@@ -101,6 +102,8 @@ def lib():
         L.vaw_conv3x3_wgrad_small_workspace_floats.restype = _l
         L.vaw_groupnorm_workspace_floats.argtypes = [_i, _i, _i]
         L.vaw_groupnorm_workspace_floats.restype = _l
+        L.vaw_wgrad_grouped_desc_bytes.argtypes = [_i]
+        L.vaw_wgrad_grouped_desc_bytes.restype = _l
         L.vaw_sumsq_workspace_floats.argtypes = []
         L.vaw_sumsq_workspace_floats.restype = _l
         L.vaw_debug_force_rowwise_attention.argtypes = [_i]
@@ -115,7 +118,7 @@ def lib():
 
 def exported_symbols():
     return sorted(list(_PROTOS) + ["vaw_version", "vaw_last_error_string", "vaw_colsum_workspace_floats",
-                                   "vaw_sumsq_workspace_floats", "vaw_groupnorm_workspace_floats",
+                                   "vaw_sumsq_workspace_floats", "vaw_groupnorm_workspace_floats", "vaw_wgrad_grouped_desc_bytes",
                                    "vaw_conv3x3_wgrad_small_workspace_floats", "vaw_row_bwd_workspace_floats"])
 
 

@@ -100,3 +100,87 @@ void vaw_p8_launch(const P8Plan& pl, int a_kmajor, int b_kmajor, int64_t M, int6
     else if (!a_kmajor && !b_kmajor) p8_launch_wgrad(L, e, s);
     else p8_launch_tn(L, e, s);
 }
+
+// ---- grouped weight gradients -----------------------------------------------------------------------------------
+#include <vector>
+
+extern "C" int64_t vaw_wgrad_grouped_desc_bytes(int n_problems) { return (int64_t)n_problems * (int64_t)sizeof(P8Prob); }
+
+extern "C" int vaw_wgrad_grouped(vaw_dtype dt, int n_problems, const vaw_wgrad_problem* problems, int64_t K, float beta,
+                                 void* desc_dev, int upload, float* workspace, int64_t workspace_floats, vaw_stream stream) {
+    VAW_CHECK_ARG(dt == VAW_BF16, "wgrad_grouped: bf16 activations only (the f32 parity mode runs vaw_gemm per layer)");
+    VAW_CHECK_ARG(n_problems > 0 && problems && desc_dev && K > 0 && K % 64 == 0, "wgrad_grouped: bad arguments (K %% 64)");
+    bool all192 = true, any_not256 = false;
+    for (int i = 0; i < n_problems; ++i) {
+        const vaw_wgrad_problem& q = problems[i];
+        VAW_CHECK_ARG(q.dy && q.x && q.dw && q.M >= 16 && q.N >= 16 && q.M % 8 == 0 && q.N % 8 == 0, "wgrad_grouped: problem %d: M, N", i);
+        VAW_CHECK_ARG(q.ld_dy >= q.M && q.ld_x >= q.N && q.ld_dw >= q.N && q.ld_dy % 8 == 0 && q.ld_x % 8 == 0 && q.ld_dw % 4 == 0,
+                      "wgrad_grouped: problem %d: leading dimensions", i);
+        VAW_CHECK_ARG((((uintptr_t)q.dy | (uintptr_t)q.x | (uintptr_t)q.dw) & 15) == 0, "wgrad_grouped: problem %d: alignment", i);
+        VAW_CHECK_ARG(q.M < (1 << 30) && q.N < (1 << 30), "wgrad_grouped: problem %d too large", i);
+        all192 = all192 && q.N % 192 == 0;
+        any_not256 = any_not256 || q.N % 256 != 0;
+    }
+    const int ntw = (all192 && any_not256) ? 3 : 4, bn = 64 * ntw;
+    static thread_local std::vector<P8Prob> host;
+    host.resize(n_problems);
+    int64_t t_total = 0;
+    for (int i = 0; i < n_problems; ++i) {
+        const vaw_wgrad_problem& q = problems[i];
+        P8Prob& h = host[i];
+        h.a = (const bf16_t*)q.dy; h.b = (const bf16_t*)q.x; h.c = q.dw;
+        h.lda = q.ld_dy; h.ldb = q.ld_x; h.ldc = q.ld_dw;
+        h.M = (int)q.M; h.N = (int)q.N;
+        h.tiles_n = (int)((q.N + bn - 1) / bn);
+        h.tile0 = (int)t_total;
+        t_total += ((q.M + 255) / 256) * h.tiles_n;
+        VAW_CHECK_ARG(t_total < (1 << 30), "wgrad_grouped: too many tiles");
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (upload) {
+        const hipError_t rc = hipMemcpyAsync(desc_dev, host.data(), sizeof(P8Prob) * n_problems, hipMemcpyHostToDevice, s);
+        VAW_CHECK_ARG(rc == hipSuccess, "wgrad_grouped: descriptor upload failed: %s", hipGetErrorString(rc));
+    }
+    const int cus = p8_num_cus(), nk = (int)(K / 64);
+    P8Group grp{};
+    grp.n_prob = n_problems;
+    grp.t_full = (int)(t_total / cus) * cus;
+    grp.t_rem = (int)(t_total - grp.t_full);
+    grp.n_split = 1;
+    grp.slab = workspace;
+    if (grp.t_rem > 0) {
+        int64_t sp = cus / grp.t_rem;                               // the K-split tiles fill one more round of workgroups
+        if (sp > nk / 4) sp = nk / 4;                               // every split keeps >= 4 K tiles
+        const int64_t per_split = (int64_t)grp.t_rem * 256 * bn;
+        if (workspace_floats <= 0 || !workspace) sp = 0;
+        else if (sp > workspace_floats / per_split) sp = workspace_floats / per_split;
+        if (sp < 2) {                                               // no room / too little K to split: whole tiles, a partial round
+            grp.t_full = (int)t_total;
+            grp.t_rem = 0;
+        } else {
+            const int per = (nk + (int)sp - 1) / (int)sp;
+            grp.n_split = (nk + per - 1) / per;                     // no empty splits
+        }
+    }
+    const int64_t items = grp.t_full + (int64_t)grp.t_rem * grp.n_split;
+    const int grid = (int)(items < cus ? items : cus);
+    EpiDev e{};
+    e.alpha = 1.f;
+    e.beta = beta;
+    e.out_f32 = 1;
+    e.rpb = 1;
+    e.nt_off = 1;
+    {
+        static int dbg = -1;
+        if (dbg < 0) { const char* v = getenv("VAW_GEMM_DEBUG"); dbg = v ? atoi(v) : 0; }
+        e.debug = dbg;
+    }
+    if (ntw == 4) p8_launch_group<4>(nk, grid, e, (const P8Prob*)desc_dev, grp, s);
+    else p8_launch_group<3>(nk, grid, e, (const P8Prob*)desc_dev, grp, s);
+    if (grp.t_rem > 0) {
+        if (ntw == 4) p8_group_fixup_kernel<256><<<grp.t_rem * 8, 256, 0, s>>>((const P8Prob*)desc_dev, grp, beta);
+        else p8_group_fixup_kernel<192><<<grp.t_rem * 8, 256, 0, s>>>((const P8Prob*)desc_dev, grp, beta);
+    }
+    VAW_CHECK_LAUNCH("wgrad_grouped");
+    return VAW_OK;
+}

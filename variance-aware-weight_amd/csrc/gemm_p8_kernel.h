@@ -89,10 +89,33 @@ __device__ __forceinline__ bf16x8 p8_frag(const char* part, int r16, int s, int 
     }
 }
 
-template <bool AK, bool BKM, int NTW, int EPI>
+// ---- grouped mode (GRP): one launch walks the tiles of MANY weight-gradient problems dW_p = dy_p^T x_p that share K (the
+// tokens of the batch).  Whole tiles first (no K split: the workgroups that run concurrently work on neighbouring tiles of
+// the same problem at the same K position, so every operand panel is fetched once for all of them), then the tiles of the
+// last, partial round of workgroups, K-split into slabs that p8_group_fixup_kernel folds in a fixed order.
+struct P8Prob {
+    const bf16_t* a;        // dy  [K][M]
+    const bf16_t* b;        // x   [K][N]
+    float* c;               // dW  [M][N] f32
+    int64_t lda, ldb, ldc;
+    int M, N, tiles_n, tile0;   // tile0: index of this problem's first tile in the launch's tile list
+};
+struct P8Group {
+    int n_prob, t_full, t_rem, n_split;   // items: tiles [0, t_full) whole; tiles [t_full, t_full + t_rem) in n_split K ranges
+    float* slab;                          // [n_split][t_rem][256][BN] f32
+};
+// the work item a workgroup (or its DMA stream) is positioned on
+struct P8Item {
+    const bf16_t *a, *b;      // operand bases (problem level)
+    int64_t lda, ldb, m0, n0;
+    int M, N, kt0, nk, split, prob, tm, rem;   // split < 0: whole tile (GRP); rem: index among the K-split tiles (GRP)
+};
+
+template <bool AK, bool BKM, int NTW, int EPI, bool GRP = false>
 __global__ void __launch_bounds__(512, 2)
 gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb, int nk_total,
-               int tiles_m, int tiles_n, int n_split, EpiDev e, int team_delay) {
+               int tiles_m, int tiles_n, int n_split, EpiDev e, int team_delay, const P8Prob* __restrict__ probs = nullptr,
+               P8Group grp = P8Group{}) {
     using Cfg = P8Cfg<NTW>;
     constexpr int LS = 4 + NTW;                                  // DMA pieces per wave and K tile
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A parts 0-3 | B parts] | 8 x 4 KiB epilogue images
@@ -100,35 +123,67 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wid >> 2, wc = wid & 3;
     // ---- static item list: G resident workgroups; XCD x (workgroups b = x mod 8) owns a contiguous run of every round ----
-    const int G = gridDim.x, n_tiles = tiles_m * tiles_n, n_items = n_tiles * n_split;
+    const int G = gridDim.x, n_tiles = tiles_m * tiles_n;
+    const int n_items = GRP ? grp.t_full + grp.t_rem * grp.n_split : n_tiles * n_split;
     int it_cur;
     {
         const int b = blockIdx.x, x = b & 7, q = G >> 3, r = G & 7;
         it_cur = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
     }
-    const int nk_per = (nk_total + n_split - 1) / n_split;
-    const int64_t a_step = AK ? 64 : 64 * lda, b_step = BKM ? 64 : 64 * ldb;
+    const int nk_per = GRP ? (nk_total + grp.n_split - 1) / grp.n_split : (nk_total + n_split - 1) / n_split;
+    auto decode = [&](int it) {
+        P8Item t;
+        if (GRP) {
+            int g;
+            if (it < grp.t_full) { g = it; t.split = -1; t.rem = 0; t.kt0 = 0; t.nk = nk_total; }
+            else {
+                const int j = it - grp.t_full;
+                t.split = j / grp.t_rem;
+                t.rem = j - t.split * grp.t_rem;
+                g = grp.t_full + t.rem;
+                t.kt0 = t.split * nk_per;
+                t.nk = t.kt0 + nk_per <= nk_total ? nk_per : nk_total - t.kt0;
+            }
+            int pi = 0;
+            while (pi + 1 < grp.n_prob && probs[pi + 1].tile0 <= g) ++pi;      // uniform: scalar loads
+            const P8Prob& pr = probs[pi];
+            const int tile = g - pr.tile0, tm = tile / pr.tiles_n;
+            t.prob = pi; t.tm = tm;
+            t.a = pr.a; t.b = pr.b; t.lda = pr.lda; t.ldb = pr.ldb; t.M = pr.M; t.N = pr.N;
+            t.m0 = (int64_t)tm * P8_BM;
+            t.n0 = (int64_t)(tile - tm * pr.tiles_n) * Cfg::BN;
+        } else {
+            const int split = it / n_tiles, tile = it - split * n_tiles, tm = tile / tiles_n;
+            t.split = split; t.rem = 0; t.prob = 0; t.tm = tm;
+            t.a = A; t.b = B; t.lda = lda; t.ldb = ldb; t.M = (int)e.M; t.N = (int)e.N;
+            t.m0 = (int64_t)tm * P8_BM;
+            t.n0 = (int64_t)(tile - tm * tiles_n) * Cfg::BN;
+            t.kt0 = split * nk_per;
+            t.nk = t.kt0 + nk_per <= nk_total ? nk_per : nk_total - t.kt0;
+        }
+        return t;
+    };
 
     // ---- the DMA stream (runs ahead of the MFMAs; its own item / K-tile position) ----
     int iss_item = it_cur, iss_kt = 0, iss_nk = 0, iss_stage = 0;
     bool iss_done = iss_item >= n_items;
     const bf16_t *iss_a = A, *iss_b = B;
     int off_a[4], off_b[NTW];
+    int64_t a_step = 0, b_step = 0;
     auto iss_open = [&]() {                       // position the stream on the first K tile of item iss_item
-        const int split = iss_item / n_tiles, tile = iss_item - split * n_tiles;
-        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-        const int64_t m0 = (int64_t)tm * P8_BM, n0 = (int64_t)tn * Cfg::BN;
-        const int kt0 = split * nk_per;
-        iss_nk = kt0 + nk_per <= nk_total ? nk_per : nk_total - kt0;
+        const P8Item t = decode(iss_item);
+        iss_nk = t.nk;
         iss_kt = 0;
-        const int mvalid = e.M - m0 < P8_BM ? (int)(e.M - m0) : P8_BM;
-        const int nvalid = e.N - n0 < Cfg::BN ? (int)(e.N - n0) : Cfg::BN;
-        iss_a = (AK ? A + m0 * lda : A + m0) + kt0 * a_step;
-        iss_b = (BKM ? B + n0 * ldb : B + n0) + kt0 * b_step;
+        const int mvalid = t.M - t.m0 < P8_BM ? (int)(t.M - t.m0) : P8_BM;
+        const int nvalid = t.N - t.n0 < Cfg::BN ? (int)(t.N - t.n0) : Cfg::BN;
+        a_step = AK ? 64 : 64 * t.lda;
+        b_step = BKM ? 64 : 64 * t.ldb;
+        iss_a = (AK ? t.a + t.m0 * t.lda : t.a + t.m0) + t.kt0 * a_step;
+        iss_b = (BKM ? t.b + t.n0 * t.ldb : t.b + t.n0) + t.kt0 * b_step;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) off_a[p] = p8_src_off<AK>(true, p, wid, lane, lda, mvalid);
+        for (int p = 0; p < 4; ++p) off_a[p] = p8_src_off<AK>(true, p, wid, lane, t.lda, mvalid);
 #pragma unroll
-        for (int p = 0; p < NTW; ++p) off_b[p] = p8_src_off<BKM>(false, p, wid, lane, ldb, nvalid);
+        for (int p = 0; p < NTW; ++p) off_b[p] = p8_src_off<BKM>(false, p, wid, lane, t.ldb, nvalid);
     };
     if (!iss_done) iss_open();
     // piece c of the stream order [B parts 0..NTW-1, A parts 0..3]
@@ -183,11 +238,15 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
     int stage = 0;
     const int wn0 = wc * Cfg::WN;
     for (; it_cur < n_items; it_cur += G) {
-        const int split = it_cur / n_tiles, tile = it_cur - split * n_tiles;
-        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-        const int64_t m0 = (int64_t)tm * P8_BM, n0 = (int64_t)tn * Cfg::BN;
-        const int kt0 = split * nk_per;
-        const int nk = kt0 + nk_per <= nk_total ? nk_per : nk_total - kt0;
+        const P8Item item = decode(it_cur);
+        const int split = item.split, tm = item.tm, nk = item.nk;
+        const int64_t m0 = item.m0, n0 = item.n0;
+        // per-item view of the epilogue descriptor: in grouped mode the output tensor changes from item to item
+        EpiDev ei = e;
+        if (GRP) {
+            const P8Prob& pr = probs[item.prob];
+            ei.C = pr.c; ei.ldc = pr.ldc; ei.M = pr.M; ei.N = pr.N;
+        }
         f32x4 acc[8][NTW];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -253,13 +312,13 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
         }
         if (wr == 0) __builtin_amdgcn_s_barrier();       // level the two wave rows: both run their epilogues together
 
-        if (e.debug == 1) {   // measurement only (VAW_GEMM_DEBUG=1): no epilogue; one never-taken store keeps the accumulators alive
+        if (ei.debug == 1) {   // measurement only (VAW_GEMM_DEBUG=1): no epilogue; one never-taken store keeps the accumulators alive
             float t = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
                 for (int u = 0; u < NTW; ++u) t += acc[i][u][0] + acc[i][u][1] + acc[i][u][2] + acc[i][u][3];
-            if (t == 12345.678f) ((float*)e.C)[0] = t;
+            if (t == 12345.678f) ((float*)ei.C)[0] = t;
             continue;
         }
         // ---- epilogue: 8 row tiles of 16 rows through this wave's private LDS image ----
@@ -283,15 +342,15 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
             ep_r[pass] = ep_base + rr * 256 + (((2 * rd_c8) ^ rr) << 4);     // chunk 2c; chunk 2c + 1 is this address ^ 16
         }
         const int64_t n = n0 + wn0 + 8 * rd_c8;
-        const bool col_ok = 8 * rd_c8 < Cfg::WN && n < e.N;             // N % 8 == 0: a group is in or out as a whole
+        const bool col_ok = 8 * rd_c8 < Cfg::WN && n < ei.N;             // N % 8 == 0: a group is in or out as a whole
         using EK = EpiKind<EPI>;
         // lanes beyond the matrix edge mirror a valid row / column for their loads and skip their stores
         const int64_t n_ld = col_ok ? n : n0;
-        const int64_t m_last = e.M - 1;
+        const int64_t m_last = ei.M - 1;
         f32x4 b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
-        if (EPI != P8_SLAB && EPI != P8_DGELU && e.bias) {
-            b0 = load4(e.bias + n_ld);
-            b1 = load4(e.bias + n_ld + 4);
+        if (EPI != P8_SLAB && EPI != P8_DGELU && EPI != P8_WGRAD && ei.bias) {
+            b0 = load4(ei.bias + n_ld);
+            b1 = load4(ei.bias + n_ld + 4);
             asm volatile("" ::"v"(b0), "v"(b1));   // the compiler waits for the bias HERE, once (this drains the DMA prefetch of
                                                    // the next item, issued 2-4 phases ago), instead of with a vmcnt(0) in
                                                    // every step, which would drain the stores of the step before
@@ -299,23 +358,28 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
         f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
         // output buffers based at the tile's first element (m0, n0); loc_col = this lane's column offset in the tile
         const int loc_col = wn0 + 8 * rd_c8;
-        const bool c_f32 = EK::out_f32(e);
-        const int64_t tile_off = m0 * e.ldc + n0;
+        const bool c_f32 = EK::out_f32(ei);
+        const int64_t tile_off = m0 * ei.ldc + n0;
+        // raw partial sums: the whole launch (P8_SLAB: slabs [split][M][N]) or the K-split items of a grouped launch
+        // (slabs [split][tile][256][BN], dense tiles)
+        const bool to_slab = EPI == P8_SLAB || (GRP && split >= 0);
+        const int64_t slab_ld = GRP ? Cfg::BN : ei.N;
         const __amdgpu_buffer_rsrc_t rs_c =
-            EPI == P8_SLAB ? epi_rsrc(e.slab + (int64_t)split * e.M * e.N + m0 * e.N + n0)
-                           : epi_rsrc(c_f32 ? (const void*)((const float*)e.C + tile_off) : (const void*)((const bf16_t*)e.C + tile_off));
-        const __amdgpu_buffer_rsrc_t rs_aux = epi_rsrc(EK::aux_out(e) ? (const void*)((const bf16_t*)e.aux_out + tile_off) : (const void*)e.C);
+            to_slab ? epi_rsrc(GRP ? grp.slab + ((int64_t)split * grp.t_rem + item.rem) * (P8_BM * Cfg::BN)
+                                   : ei.slab + (int64_t)split * ei.M * ei.N + m0 * ei.N + n0)
+                    : epi_rsrc(c_f32 ? (const void*)((const float*)ei.C + tile_off) : (const void*)((const bf16_t*)ei.C + tile_off));
+        const __amdgpu_buffer_rsrc_t rs_aux = epi_rsrc(EK::aux_out(ei) ? (const void*)((const bf16_t*)ei.aux_out + tile_off) : (const void*)ei.C);
         // rows of this lane, step k = 2 i + pass: m = mrow0 + 8 k; (sample, row in sample) carried along for gate / rowadd
         const int64_t mrow0 = m0 + wr * 128 + rd_row;
-        const unsigned rpb = (unsigned)e.rpb;
+        const unsigned rpb = (unsigned)ei.rpb;
         unsigned smp = 0, rin = 0;
         EpiOps ops[2];
-        const bool with_ops = EK::loads && (EK::act2(e) || EK::gate(e) || EK::resid(e) || EK::rowadd(e));
+        const bool with_ops = EK::loads && (EK::act2(ei) || EK::gate(ei) || EK::resid(ei) || EK::rowadd(ei));
         if (with_ops) {
             const int64_t mc = mrow0 < m_last ? mrow0 : m_last;
             smp = (unsigned)mc / rpb;
             rin = (unsigned)mc % rpb;
-            epi_load8<EPI>(e, (unsigned)mc, n_ld, smp, rin, ops[0]);
+            epi_load8<EPI>(ei, (unsigned)mc, n_ld, smp, rin, ops[0]);
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -339,7 +403,7 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
                         smp = (unsigned)mn / rpb;
                         rin = (unsigned)mn % rpb;
                     }
-                    epi_load8<EPI>(e, (unsigned)mn, n_ld, smp, rin, ops[(k + 1) & 1]);
+                    epi_load8<EPI>(ei, (unsigned)mn, n_ld, smp, rin, ops[(k + 1) & 1]);
                 }
                 f32x4 v0, v1;
                 asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
@@ -348,15 +412,15 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
                              : "memory");
                 __builtin_amdgcn_sched_barrier(0);   // nothing that reads v0 / v1 may move above the wait (rule 18)
                 const bool ok = col_ok && m <= m_last;
-                const int loc = ok ? (int)((m - m0) * e.ldc) + loc_col : -1;
-                if (EPI == P8_SLAB) {
+                const int loc = ok ? (int)((m - m0) * ei.ldc) + loc_col : -1;
+                if (to_slab) {
                     // split-K partials are re-read at once by the reduce: default cache policy
-                    const unsigned bo = ok ? 4u * (unsigned)((m - m0) * e.N + loc_col) : EPI_OOB;
+                    const unsigned bo = ok ? 4u * (unsigned)((m - m0) * slab_ld + loc_col) : EPI_OOB;
                     buf_store16(rs_c, bo, v0, false);
                     buf_store16(rs_c, ok ? bo + 16u : EPI_OOB, v1, false);
                 } else {
                     const int64_t mc = m <= m_last ? m : m_last;
-                    epi_apply8<EPI>(e, rs_c, rs_aux, loc, (const float*)e.C + mc * e.ldc + n_ld, v0, v1, b0, b1, ops[k & 1]);
+                    epi_apply8<EPI>(ei, rs_c, rs_aux, loc, (const float*)ei.C + mc * ei.ldc + n_ld, v0, v1, b0, b1, ops[k & 1]);
                     if (EK::may_colsum) {      // unconditional arithmetic (a run-time condition here makes the compiler keep
                                                // all 16 steps' values alive and sum them at the end: spills)
                         const f32x4 z = {0, 0, 0, 0};
@@ -369,15 +433,15 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
                 __builtin_amdgcn_sched_barrier(0);   // keep the 16 unrolled steps apart: hoisting across them spills
             }
         }
-        if (EK::colsum(e)) {
+        if (EK::colsum(ei)) {
             // 8 row groups of the read-back layout: fold lane bits 3, 4, 5 in a fixed order; one partial row per wave row
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 s0[j] += __shfl_xor(s0[j], 8, 64); s0[j] += __shfl_xor(s0[j], 16, 64); s0[j] += __shfl_xor(s0[j], 32, 64);
                 s1[j] += __shfl_xor(s1[j], 8, 64); s1[j] += __shfl_xor(s1[j], 16, 64); s1[j] += __shfl_xor(s1[j], 32, 64);
             }
-            if (lane_e < 8 && col_ok && m0 + wr * 128 < e.M) {
-                float* cp = e.colpart + (2 * (int64_t)tm + wr) * e.N + n;
+            if (lane_e < 8 && col_ok && m0 + wr * 128 < ei.M) {
+                float* cp = ei.colpart + (2 * (int64_t)tm + wr) * ei.N + n;
                 store4(cp, s0);
                 store4(cp + 4, s1);
             }
@@ -396,6 +460,41 @@ static void p8_launch_one(const bf16_t* a, int64_t lda, const bf16_t* b, int64_t
         attr_done = true;
     }
     gemm_p8_kernel<AK, BKM, NTW, EPI><<<grid, 512, lds, s>>>(a, lda, b, ldb, nk, tiles_m, tiles_n, split, e, team_delay);
+}
+
+template <int NTW>
+static void p8_launch_group(int nk, int grid, const EpiDev& e, const P8Prob* probs_dev, const P8Group& grp, hipStream_t s) {
+    static bool attr_done = false;
+    const int lds = P8Cfg<NTW>::lds_bytes;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)gemm_p8_kernel<false, false, NTW, P8_WGRAD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_done = true;
+    }
+    gemm_p8_kernel<false, false, NTW, P8_WGRAD, true><<<grid, 512, lds, s>>>(nullptr, 0, nullptr, 0, nk, 0, 0, 1, e, 0, probs_dev, grp);
+}
+
+// C_tile = beta * C_tile + sum_s slab[s][r] (fixed order) for the K-split tiles r of a grouped launch: one workgroup per
+// (tile, 32-row band).
+template <int BN>
+__global__ void p8_group_fixup_kernel(const P8Prob* __restrict__ probs, P8Group grp, float beta) {
+    const int r = blockIdx.x >> 3, band = blockIdx.x & 7, g = grp.t_full + r;
+    int pi = 0;
+    while (pi + 1 < grp.n_prob && probs[pi + 1].tile0 <= g) ++pi;
+    const P8Prob pr = probs[pi];
+    const int tile = g - pr.tile0, tm = tile / pr.tiles_n, tn = tile - tm * pr.tiles_n;
+    const int64_t m0 = (int64_t)tm * P8_BM + 32 * band, n0 = (int64_t)tn * BN;
+    constexpr int C4 = BN / 4;
+    for (int i = threadIdx.x; i < 32 * C4; i += blockDim.x) {
+        const int row = i / C4, c4 = (i - row * C4) * 4;
+        const int64_t m = m0 + row, n = n0 + c4;
+        if (m >= pr.M || n >= pr.N) continue;                       // N % 8 == 0: a group of 4 is in or out as a whole
+        f32x4 acc = {0, 0, 0, 0};
+        for (int sp = 0; sp < grp.n_split; ++sp)
+            acc += load4(grp.slab + ((int64_t)sp * grp.t_rem + r) * (P8_BM * BN) + (int64_t)(32 * band + row) * BN + c4);
+        float* c = pr.c + m * pr.ldc + n;
+        if (beta != 0.f) acc += beta * load4(c);
+        store4(c, acc);
+    }
 }
 
 // arguments of one launch, as the per-layout translation units receive them

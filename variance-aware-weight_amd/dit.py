@@ -125,6 +125,13 @@ class _Workspace:
         # backward scratch (shared by all blocks)
         self.dotok, self.dres, self.dD = e(M, m.No), e(M, D, dtype=f32), e(M, D)
         self.dDm, self.dqkv, self.dao = e(M, m.Dm), e(M, 3 * D), e(M, D)
+        # deferred weight gradients (bf16 mode): every block keeps the four dy operands of its Linear layers until ONE grouped
+        # launch at the end of backward consumes them (226 MB per DiT-B/4 block at batch 256; sized for 288 GB of HBM)
+        self.defer = bool(m.defer_wgrad) and adt == torch.bfloat16 and M % 64 == 0
+        if self.defer:
+            for b in self.blk:
+                b.update(dy2=e(M, D), dDm=e(M, m.Dm), dy1=e(M, D), dqkv=e(M, 3 * D))
+        self.wgrad_groups = {}
         self.delta = e(B * m.num_heads * T, dtype=f32)
         self.dmod, self.dmod_a = e(B, m.mod_cols, dtype=f32), e(B, m.mod_cols)
         self.dcs, self.dc, self.dc_a = e(B, D, dtype=f32), e(B, D, dtype=f32), e(B, D)
@@ -183,6 +190,10 @@ class DiT(FlatModule):
         self._anchor = torch.zeros(1, requires_grad=True)
         self._ws, self._ws_cur = {}, None
         self.grad_ready_hook = None      # callable(stage:int) -> None; stage counts down from depth+1 to 0
+        # bf16 mode: the weight gradients of the blocks' Linear layers are deferred and run as grouped launches
+        # (vaw_wgrad_grouped): one for all blocks at the end of backward, or two (upper / lower half of the blocks) when a
+        # gradient hook listens, so that the first half's all-reduce still overlaps the rest of backward.  False: per layer.
+        self.defer_wgrad = True
 
     # ---- reference surface -----------------------------------------------------------------
     def initialize_weights(self):
@@ -408,41 +419,81 @@ class DiT(FlatModule):
         if hook:
             hook(Lyr + 1)
         es = self._wsize
+        defer = ws.defer and dt == BF16
+        pending = []                      # blocks whose weight gradients wait for the next grouped launch
+        group_cut = Lyr // 2 if (hook and Lyr >= 4) else 0      # with a listener: flush once half-way, once at the end
+
+        def flush():
+            """One grouped launch for the weight gradients of the blocks in `pending`, then their gradient-ready stages."""
+            if not pending:
+                return
+            key = (pending[0], pending[-1], self._gbase)
+            grp = ws.wgrad_groups.get(key)
+            if grp is None:
+                probs = []
+                for l in pending:
+                    b, pre = ws.blk[l], f"blocks.{l}."
+                    for name, dy, x, Nw, Kw in ((pre + "mlp.fc2.", b["dy2"], b["a"], D, Dm), (pre + "mlp.fc1.", b["dDm"], b["xm2"], Dm, D),
+                                                (pre + "attn.proj.", b["dy1"], b["ao"], D, D), (pre + "attn.qkv.", b["dqkv"], b["xm"], 3 * D, D)):
+                        probs.append((ptr(dy), ptr(x), self._g(name + "weight"), Nw, Kw, Nw, Kw, Kw))
+                grp = ws.wgrad_groups[key] = ops.WgradGroup(probs, M, dout.device)
+            grp.launch(dt, beta)
+            if hook:
+                for l in pending:
+                    hook(l + 1)
+            pending.clear()
+
         for l in reversed(range(Lyr)):
             b, pre = ws.blk[l], f"blocks.{l}."
             mo, dmo = mod + 4 * (6 * l * D), dmod + 4 * (6 * l * D)
             xin, xmid = ptr(ws.xres[2 * l]), ptr(ws.xres[2 * l + 1])
+            dy2, dhid, dy1, dq = ((ptr(b["dy2"]), ptr(b["dDm"]), ptr(b["dy1"]), ptr(b["dqkv"])) if defer
+                                  else (dD, dDm, dD, ptr(ws.dqkv)))
             # MLP branch
             # bias gradients ride on the kernels that produce dy (per-sample partials / GEMM epilogue): no re-read
-            ops.gate_bwd(dt, dres, ptr(b["y2"]), mo + 4 * 5 * D, ld, dD, dmo + 4 * 5 * D, ld, B, T, D, colpart)
+            ops.gate_bwd(dt, dres, ptr(b["y2"]), mo + 4 * 5 * D, ld, dy2, dmo + 4 * 5 * D, ld, B, T, D, colpart)
             ops.reduce_rows(colpart, B, D, self._g(pre + "mlp.fc2.bias"), beta)
-            self._wgrad(dt, pre + "mlp.fc2.", dD, ptr(b["a"]), D, Dm, M, beta, bias=False)
-            ops.gemm(dt, 1, 0, M, Dm, D, dD, D, self._w(pre + "mlp.fc2.weight"), Dm, dDm, Dm, act=2, aux_in=ptr(b["hpre"]),
+            if not defer:
+                self._wgrad(dt, pre + "mlp.fc2.", dy2, ptr(b["a"]), D, Dm, M, beta, bias=False)
+            ops.gemm(dt, 1, 0, M, Dm, D, dy2, D, self._w(pre + "mlp.fc2.weight"), Dm, dhid, Dm, act=2, aux_in=ptr(b["hpre"]),
                      colsum_out=self._g(pre + "mlp.fc1.bias"), colsum_beta=beta)
-            self._wgrad(dt, pre + "mlp.fc1.", dDm, ptr(b["xm2"]), Dm, D, M, beta, bias=False)
-            ops.gemm(dt, 1, 0, M, D, Dm, dDm, Dm, self._w(pre + "mlp.fc1.weight"), D, dD, D)
+            if not defer:
+                self._wgrad(dt, pre + "mlp.fc1.", dhid, ptr(b["xm2"]), Dm, D, M, beta, bias=False)
+            ops.gemm(dt, 1, 0, M, D, Dm, dhid, Dm, self._w(pre + "mlp.fc1.weight"), D, dD, D)
             ops.ln_modulate_bwd(dt, dD, xmid, ptr(b["mean2"]), ptr(b["rstd2"]), mo + 4 * 4 * D, ld, dres, dres,
                                 dmo + 4 * 3 * D, dmo + 4 * 4 * D, ld, B, T, D)
             # attention branch
-            ops.gate_bwd(dt, dres, ptr(b["y1"]), mo + 4 * 2 * D, ld, dD, dmo + 4 * 2 * D, ld, B, T, D, colpart)
+            ops.gate_bwd(dt, dres, ptr(b["y1"]), mo + 4 * 2 * D, ld, dy1, dmo + 4 * 2 * D, ld, B, T, D, colpart)
             ops.reduce_rows(colpart, B, D, self._g(pre + "attn.proj.bias"), beta)
-            self._wgrad(dt, pre + "attn.proj.", dD, ptr(b["ao"]), D, D, M, beta, bias=False)
-            ops.gemm(dt, 1, 0, M, D, D, dD, D, self._w(pre + "attn.proj.weight"), D, ptr(ws.dao), D)
-            q, dq = ptr(b["qkv"]), ptr(ws.dqkv)
+            if not defer:
+                self._wgrad(dt, pre + "attn.proj.", dy1, ptr(b["ao"]), D, D, M, beta, bias=False)
+            ops.gemm(dt, 1, 0, M, D, D, dy1, D, self._w(pre + "attn.proj.weight"), D, ptr(ws.dao), D)
+            q = ptr(b["qkv"])
             ops.attn_bwd(dt, self._attn_desc(B), q, q + es * D, q + 2 * es * D, ptr(b["ao"]), ptr(ws.dao), ptr(b["lse"]),
                          ptr(ws.delta), dq, dq + es * D, dq + 2 * es * D)
-            self._wgrad(dt, pre + "attn.qkv.", dq, ptr(b["xm"]), 3 * D, D, M, beta)
+            if defer:      # the qkv bias gradient = column sums of dqkv (the per-layer launch takes them from its staged dy tiles)
+                ops.colsum(dt, dq, M, 3 * D, 3 * D, self._g(pre + "attn.qkv.bias"), beta, device=dout.device)
+            else:
+                self._wgrad(dt, pre + "attn.qkv.", dq, ptr(b["xm"]), 3 * D, D, M, beta)
             ops.gemm(dt, 1, 0, M, D, 3 * D, dq, 3 * D, self._w(pre + "attn.qkv.weight"), D, dD, D)
             ops.ln_modulate_bwd(dt, dD, xin, ptr(b["mean1"]), ptr(b["rstd1"]), mo + 4 * D, ld, dres, dres, dmo, dmo + 4 * D,
                                 ld, B, T, D)
+            if defer:
+                pending.append(l)
+                if l == group_cut:
+                    pending.reverse()
+                    flush()
             if hook:
-                hook(l + 1)
+                if not defer:
+                    hook(l + 1)
                 if l == ada_half:
                     # data-parallel runs: the adaLN rows of blocks >= l (and the final layer's) are final now -- weight and
                     # bias gradients of that part of the packed matrix leave with their own bucket while blocks l-1..0 run
                     r0 = 6 * l * D
                     self._adaln_wgrad(dt, ws, r0, ld - r0, B, beta)
                     hook("ada_hi")
+        pending.reverse()
+        flush()
         # patch embedding: d(x0) = dres
         if dt == BF16:
             ops.cast_bf16(ws.dres, ws.dD)

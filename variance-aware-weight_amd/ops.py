@@ -161,6 +161,38 @@ def gemm(dt, a_kmajor, b_kmajor, M, N, K, A, lda, B, ldb, Cp, ldc, *, bias=None,
         tr.add(L.lib().vaw_gemm_uses_bf16_mfma(dt, M, N, K, A, lda, B, ldb), bool(a_kmajor), bool(b_kmajor), M, N, K, e0, e1)
 
 
+class WgradProblem(C.Structure):
+    """vaw_wgrad_problem of include/vaw_hip.h."""
+    _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("M", C.c_int64), ("N", C.c_int64),
+                ("ld_dy", C.c_int64), ("ld_x", C.c_int64), ("ld_dw", C.c_int64)]
+
+
+class WgradGroup:
+    """The weight gradients dW_p (+)= dy_p^T x_p of many Linear layers as ONE launch (vaw_wgrad_grouped).  `problems` is a list of
+    (dy_addr, x_addr, dw_addr, M, N, ld_dy, ld_x, ld_dw); the addresses are workspace / flat-buffer addresses that stay put
+    between steps, so the device copy of the table is uploaded once."""
+
+    def __init__(self, problems, K, device):
+        self.n, self.K, self.device = len(problems), int(K), device
+        self.table = (WgradProblem * self.n)(*[WgradProblem(*p) for p in problems])
+        self.flop = sum(2.0 * p[3] * p[4] * K for p in problems)
+        self.desc = torch.empty(L.lib().vaw_wgrad_grouped_desc_bytes(self.n), device=device, dtype=torch.uint8)
+        self.uploaded = False
+
+    def launch(self, dt, beta):
+        ws = scratch_f32(self.device, 0)
+        tr = gemm_trace
+        if tr is not None:
+            e0, e1 = tr.events()
+            e0.record()
+        check(L.lib().vaw_wgrad_grouped(dt, self.n, C.cast(self.table, C.c_void_p), self.K, float(beta), self.desc.data_ptr(),
+                                        0 if self.uploaded else 1, ws.data_ptr(), ws.numel(), stream_ptr()), "vaw_wgrad_grouped")
+        self.uploaded = True
+        if tr is not None:
+            e1.record()
+            tr.add_flop(1, False, False, self.flop, e0, e1)
+
+
 def beta_or_plain(bias, act, aux_out, gate, resid, rowadd):
     """True when the epilogue is alpha/beta only: the launches that may run split-K."""
     return not (bias or act or aux_out or gate or resid or rowadd)
@@ -198,16 +230,19 @@ class GemmTrace:
         return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     def add(self, mfma, ak, bk, M, N, K, e0, e1):
-        self.rows.append((mfma, ak, bk, M, N, K, e0, e1))
+        self.rows.append((mfma, ak, bk, 2.0 * M * N * K, e0, e1))
+
+    def add_flop(self, mfma, ak, bk, flop, e0, e1):
+        self.rows.append((mfma, ak, bk, flop, e0, e1))
 
     def summarize(self):
         """-> {variant: {launches, flop, ms}} after a device synchronize."""
         out = {}
-        for mfma, ak, bk, M, N, K, e0, e1 in self.rows:
+        for mfma, ak, bk, flop, e0, e1 in self.rows:
             name = ("bf16_mfma" if mfma else "generic_f32mfma") + ("/fwd" if ak and bk else "/dgrad" if ak else "/wgrad")
             d = out.setdefault(name, {"launches": 0, "flop": 0.0, "ms": 0.0})
             d["launches"] += 1
-            d["flop"] += 2.0 * M * N * K
+            d["flop"] += flop
             d["ms"] += e0.elapsed_time(e1)
         return out
 
