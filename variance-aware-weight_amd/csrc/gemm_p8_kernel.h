@@ -82,8 +82,15 @@ __device__ __forceinline__ bf16x8 p8_frag(const char* part, int r16, int s, int 
         const int kb = 32 * s + 8 * (lane >> 4) + q;
         const int ch = ((r16 >> 3) + (p >> 1)) ^ p8_mn_swz(kb);
         const char* a0 = part + kb * 128 + (ch << 4) + 8 * (p & 1);
-        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)a0);
-        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(a0 + 512));   // k + 4: same swizzle
+        // inline asm, not __builtin_amdgcn_ds_read_tr16_b64: the compiler orders the builtin behind every pending LDS-DMA with
+        // s_waitcnt vmcnt(0) (it may alias the DMA's LDS writes), which drains the whole prefetch ring in every phase.  The
+        // caller waits with an explicit s_waitcnt lgkmcnt(0) after the phase barrier (P8_LGKM_FENCE) before the MFMAs.
+        const unsigned addr = (unsigned)(uintptr_t)(lds_ptr_t)a0;
+        bf16x4 lo, hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:512"      // k + 4: same swizzle
+                     : "=&v"(lo), "=&v"(hi)
+                     : "v"(addr)
+                     : "memory");
         bf16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return r;
     }
@@ -268,6 +275,10 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
             };
 #define P8_MMA(j)                                                                                                     \
     do {                                                                                                              \
+        if (!AK || !BKM) {      /* fragments read by inline asm: the compiler does not wait for them itself */          \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+        }                                                                                                             \
         __builtin_amdgcn_s_setprio(1);                                                                                \
         _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                                 \
             _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                             \
