@@ -394,6 +394,59 @@ def gen_trainer_vb():
     json.dump(rec, open(os.path.join(HERE, "trainer_vb.json"), "w"), indent=1)
 
 
+BIG_CONFIGS = {
+    # BASELINE.json configs 2, 3, 5 at batch 2 (the full batches are exercised on the GPU through size-independent properties)
+    "unet64": dict(kind="unet", factory="UNet_64", kw=dict(class_cond=False), size=64, chans=3, classes=0),
+    "adm64": dict(kind="unet", factory="ADM_64", kw=dict(num_classes=1000, class_cond=True), size=64, chans=3, classes=1000),
+    "dit_xl2": dict(kind="dit", factory="DiT_XL", kw=dict(image_size=32, patch_size=2, in_channels=4, class_dropout_prob=0.0,
+                                                           num_classes=1000, learn_sigma=False), size=32, chans=8, classes=1000),
+}
+
+
+def gen_bigcfg():
+    """Full-size models of BASELINE configs 2, 3 and 5, rebuilt from a seed (torch.manual_seed(42) + the constructor, then
+    perturb_(model, 7) so that zero-initialised layers carry gradient): per-sample terms['mse'], fingerprints of every
+    parameter gradient of loss = mse.mean(), and two Trainer steps.  Reference: models/unet.py:993,1013, models/dit.py:373,
+    tools/gaussian_diffusion.py:834-930, tools/trainer.py:68-150."""
+    import random
+    from models import unet as U
+    from models import dit as D
+    from tools import gaussian_diffusion as gd
+    out = {}
+    for name, c in BIG_CONFIGS.items():
+        latent = c["kind"] == "dit"
+
+        def make_model(c=c):
+            m = getattr(U if c["kind"] == "unet" else D, c["factory"])(**c["kw"])
+            perturb_(m, 7, std=0.02)
+            return m
+        args = base_args(in_chans=4 if latent else 3, class_cond=bool(c["classes"]), dataset="Latent" if latent else "ImageNet",
+                         image_size=c["size"])
+        random.seed(42); np.random.seed(42); torch.manual_seed(42)
+        model = make_model()
+        g = torch.Generator().manual_seed(31)
+        Cx = 4 if latent else 3
+        x = torch.randn(2, Cx, c["size"], c["size"], generator=g) * (0.7 if latent else 0.5)
+        noise = torch.randn(2, Cx, c["size"], c["size"], generator=g)
+        t = torch.tensor([37, 912])
+        y = torch.tensor([3, 998]) if c["classes"] else None
+        diff = gd.GaussianDiffusion(args=args, betas=gd.get_named_beta_schedule("cosine", 1000),
+                                    model_mean_type=gd.ModelMeanType.EPSILON, model_var_type=gd.ModelVarType.FIXED_LARGE,
+                                    loss_type=gd.LossType.MSE, rescale_timesteps=True, device="cpu")
+        terms = diff.training_losses(model, x, None, t=t, model_kwargs={"y": y} if y is not None else {}, noise=noise)
+        terms["loss"].mean().backward()
+        rec = {"x": x, "noise": noise, "t": t, "y": y if y is not None else torch.zeros(0, dtype=torch.long),
+               "mse": terms["mse"].detach().double(), "n_params": sum(p.numel() for p in model.parameters()),
+               "params": summarize({k: v for k, v in model.named_parameters()}),
+               "grads": summarize({k: v.grad for k, v in model.named_parameters() if v.grad is not None})}
+        del model, terms
+        loader = synth_loader(2, c["chans"], c["size"], 2, c["classes"], latent=latent)
+        rec["trainer"] = run_trainer(make_model, args, loader, 2)
+        out[name] = rec
+        print("  bigcfg", name, rec["n_params"], [round(float(v), 6) for v in rec["mse"]], rec["trainer"]["losses"], flush=True)
+    torch.save(out, os.path.join(HERE, "bigcfg.pt"))
+
+
 def sampling_model(x, t, **kw):
     """Deterministic stand-in denoiser for the sampling goldens: bounded, depends on x, t (as the wrapped model sees it) and y;
     2C channels when asked (second half = variance values in [-1, 1])."""
@@ -492,7 +545,7 @@ def main():
     from tools import gaussian_diffusion as gd
     jobs = {"tables": lambda: gen_tables(gd), "weights": lambda: gen_loss_weights(gd),
             "objective": lambda: gen_objective(gd), "dit": gen_dit_tiny, "unet": gen_unet_tiny, "misc": gen_misc,
-            "trainer": gen_trainer, "vb": lambda: gen_vb(gd), "trainer_vb": gen_trainer_vb, "sampling": lambda: gen_sampling(gd)}
+            "trainer": gen_trainer, "bigcfg": gen_bigcfg, "vb": lambda: gen_vb(gd), "trainer_vb": gen_trainer_vb, "sampling": lambda: gen_sampling(gd)}
     for name in (sys.argv[1:] or list(jobs)):
         jobs[name]()
         print("wrote", name)

@@ -1,0 +1,147 @@
+"""BASELINE.json configs 2, 3 and 5 at full model size on the GPU: `UNet_64(class_cond=False)`, `ADM_64(num_classes=1000)` and
+`DiT_XL(32, patch 2)` (reference models/unet.py:993,1013, models/dit.py:373).
+
+  * f32 parity mode at batch 2 against tests/golden/bigcfg.pt (written by tests/golden/make_goldens.py from the unmodified
+    reference): the seed-reconstructed weights, per-sample terms['mse'] (1e-4 relative, the north_star tolerance), every
+    parameter gradient, and two `Trainer` steps;
+  * bf16 throughput mode at batch 2: drift against the same fixture, asserted loosely and REPORTED;
+  * the configs' full batches (128 / 256 / 128 per GPU) in bf16 through size-independent properties: determinism, per-sample
+    independence, finite non-zero gradients.
+The fp8 variant of config 5 is not covered here."""
+import copy
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import Pbar, assert_fingerprints, base_args, load_pt, perturb_, synth_loader
+
+pytestmark = pytest.mark.gpu
+
+import vaw_amd
+
+DEV = "cuda"
+
+CONFIGS = {
+    "unet64": dict(kind="unet", make=lambda dt: vaw_amd.UNet_64(class_cond=False, compute_dtype=dt), size=64, chans=3, classes=0,
+                   full_batch=128),
+    "adm64": dict(kind="unet", make=lambda dt: vaw_amd.ADM_64(num_classes=1000, class_cond=True, compute_dtype=dt), size=64, chans=3,
+                  classes=1000, full_batch=256),
+    "dit_xl2": dict(kind="dit", make=lambda dt: vaw_amd.DiT_XL(image_size=32, patch_size=2, in_channels=4, class_dropout_prob=0.0,
+                                                               num_classes=1000, learn_sigma=False, compute_dtype=dt),
+                    size=32, chans=8, classes=1000, full_batch=128),
+}
+
+
+def _args(c, **kw):
+    latent = c["kind"] == "dit"
+    return base_args(in_chans=4 if latent else 3, class_cond=bool(c["classes"]), dataset="Latent" if latent else "ImageNet",
+                     image_size=c["size"], **kw)
+
+
+def _build(c, dtype):
+    """Same construction as the fixture: seed 42, the reference constructor's RNG order, then perturb_(model, 7, 0.02)."""
+    random.seed(42); np.random.seed(42); torch.manual_seed(42)
+    m = c["make"](dtype)
+    perturb_(m, 7, std=0.02)
+    return m
+
+
+def _diffusion(args):
+    return vaw_amd.GaussianDiffusion(args=args, betas=vaw_amd.get_named_beta_schedule("cosine", 1000),
+                                     model_mean_type=vaw_amd.ModelMeanType.EPSILON, model_var_type=vaw_amd.ModelVarType.FIXED_LARGE,
+                                     loss_type=vaw_amd.LossType.MSE, rescale_timesteps=True)
+
+
+def _objective(model, c, g):
+    diff = _diffusion(_args(c))
+    kw = {"y": g["y"].to(DEV)} if c["classes"] else {}
+    terms = diff.training_losses(model, g["x"].to(DEV), None, t=g["t"].to(DEV), model_kwargs=kw, noise=g["noise"].to(DEV))
+    terms["loss"].mean().backward()
+    return terms["mse"].detach().double().cpu(), {k: p.grad.detach().cpu() for k, p in model.named_parameters() if p.grad is not None}
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_full_size_model_fp32_objective_and_gradients_vs_reference(name):
+    c, g = CONFIGS[name], load_pt("bigcfg.pt")[name]
+    m = _build(c, "fp32")
+    assert sum(p.numel() for p in m.parameters()) == g["n_params"]
+    assert_fingerprints({k: v.detach() for k, v in m.named_parameters()}, g["params"], 1e-6, 1e-9, "seed-reconstructed weights")
+    m = m.to(DEV).train()
+    mse, grads = _objective(m, c, g)
+    torch.testing.assert_close(mse, g["mse"], rtol=1e-4, atol=0)
+    # gradients: 1e-4 of each tensor's rms on the strided sample, 1e-3 on its l2 norm (f32 accumulation order differs)
+    assert_fingerprints(grads, g["grads"], 1e-4, 2e-6, "parameter gradients")
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_full_size_model_fp32_trainer_steps_vs_reference(name):
+    """Two reference `Trainer.train_step`s (AdamW 1e-4, EMA, CPU RNG stream injected) at batch 2: losses within 1e-4."""
+    c, g = CONFIGS[name], load_pt("bigcfg.pt")[name]["trainer"]
+    args = _args(c, cpu_rng=True)
+    random.seed(42); np.random.seed(42); torch.manual_seed(42)
+    model = c["make"]("fp32")
+    perturb_(model, 7, std=0.02)
+    model = model.to(DEV)
+    ema_model = copy.deepcopy(model)
+    opt = vaw_amd.FusedAdamW(model, lr=args.lr, betas=(0.9, 0.95), weight_decay=0.0, eps=1e-8)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=vaw_amd.get_lr_lambda(args))
+    loader = synth_loader(2, c["chans"], c["size"], 2, c["classes"], latent=c["kind"] == "dit")
+    tr = vaw_amd.Trainer(args, torch.device(DEV), model, ema_model, opt, sched, _diffusion(args), loader, Pbar())
+    losses = [tr.train_step(s) for s in (1, 2)]
+    np.testing.assert_allclose(losses, g["losses"], rtol=1e-4)
+    psum = float(sum(p.double().abs().sum() for p in model.parameters()))
+    esum = float(sum(v.double().abs().sum() for v in ema_model.state_dict().values()))
+    assert psum == pytest.approx(g["param_abs_sum"], rel=1e-5)
+    assert esum == pytest.approx(g["ema_abs_sum"], rel=1e-6)
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_full_size_model_bf16_drift_vs_reference(name, record_property):
+    """bf16 MFMA kernels (the ones bench.py times) against the f32 reference fixture: per-sample loss within 2e-2 and every
+    gradient tensor's l2 norm within 8e-2 of the reference's; the measured drift is reported (pytest -rA / junit properties)."""
+    c, g = CONFIGS[name], load_pt("bigcfg.pt")[name]
+    m = _build(c, "bf16").to(DEV).train()
+    mse, grads = _objective(m, c, g)
+    rel = ((mse - g["mse"]).abs() / g["mse"].abs()).max().item()
+    worst, worst_k = 0.0, ""
+    for k, v in grads.items():
+        ref = float(g["grads"][k]["stats"][2])
+        if ref > 1e-6:
+            d = abs(float(v.double().norm()) - ref) / ref
+            if d > worst:
+                worst, worst_k = d, k
+    record_property("bf16_mse_rel_drift", rel)
+    record_property("bf16_worst_grad_l2_drift", f"{worst:.4f} ({worst_k})")
+    print(f"[bf16 drift] {name}: per-sample mse {rel:.2e}, worst gradient l2 {worst:.2e} at {worst_k}")
+    assert rel < 2e-2
+    assert worst < 8e-2, worst_k
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_full_batch_properties_bf16(name):
+    """The config's full per-GPU batch in bf16 (no oracle run at this size): determinism (bitwise equal losses and gradients
+    on a repeat), per-sample independence (a sample's loss alone == its loss in the batch), finite non-zero gradients."""
+    c = CONFIGS[name]
+    B, Cx, S = c["full_batch"], (4 if c["kind"] == "dit" else 3), c["size"]
+    m = _build(c, "bf16").to(DEV).train()
+    diff = _diffusion(_args(c))
+    g = torch.Generator().manual_seed(1)
+    x0 = (torch.randn(B, Cx, S, S, generator=g) * 0.5).to(DEV)
+    noise = torch.randn(B, Cx, S, S, generator=g).to(DEV)
+    t = torch.randint(0, 1000, (B,), generator=g).to(DEV)
+    y = torch.randint(0, 1000, (B,), generator=g).to(DEV)
+    kw = (lambda idx: {"y": y[idx]}) if c["classes"] else (lambda idx: {})
+    every = torch.arange(B, device=DEV)
+    t1 = diff.training_losses(m, x0, None, t=t, model_kwargs=kw(every), noise=noise)
+    t1["loss"].mean().backward()
+    g1 = m.flat_grads().clone()
+    m.zero_grad_flat()
+    t2 = diff.training_losses(m, x0, None, t=t, model_kwargs=kw(every), noise=noise)
+    t2["loss"].mean().backward()
+    assert torch.equal(t1["mse"], t2["mse"]) and torch.equal(g1, m.flat_grads())
+    idx = torch.tensor([1, B - 3], device=DEV)
+    sub = diff.training_losses(m, x0[idx], None, t=t[idx], model_kwargs=kw(idx), noise=noise[idx])
+    torch.testing.assert_close(sub["mse"], t1["mse"][idx], rtol=2e-3, atol=1e-5)
+    assert torch.isfinite(g1).all() and float(g1.abs().max()) > 0 and torch.isfinite(t1["mse"]).all()

@@ -328,3 +328,85 @@ def test_trainer_with_loss_second_moment_sampler():
     assert all(np.isfinite(losses))
     w = tr.schedule_sampler.weights()
     assert tr.schedule_sampler._warmed_up() and abs(w.sum() - 1.0) < 1e-9 and w.std() > 0
+
+
+@pytest.mark.parametrize("wrapped", [False, True])
+def test_checkpoint_resume_hip_dit_fused_adamw_is_bitwise(tmp_path, wrapped):
+    """Reference checkpoint dict {'model','optimizer','step','ema_model'} (tools/utils.py:93-120) on the real path: 3 steps of
+    a HIP DiT (bf16 kernels, flat storage) + FusedAdamW + EMA, save, FRESH objects, load, 3 more steps == 6 uninterrupted
+    steps, bit for bit (losses, parameters, EMA, both Adam moments).  wrapped: through vaw_amd.DistributedDataParallel, whose
+    state_dict carries the 'module.' prefix like torch DDP's; the checkpoint is then loaded into a bare model and vice versa.
+    The optimizer entry is in torch.optim.AdamW's own format, indexed like AdamW(model.parameters())."""
+    import os
+    import socket
+    import torch.distributed as dist
+    kw = dict(image_size=8, patch_size=2, in_channels=4, hidden_size=64, depth=2, num_heads=2, class_dropout_prob=0.0,
+              num_classes=10, learn_sigma=False, compute_dtype="bf16")
+    args = base_args(in_chans=4, class_cond=True, dataset="Latent", image_size=8, lr=1e-3, amp=True, cpu_rng=True, warmup_steps=2,
+                     cosine_decay=True, total_steps=20, final_lr=1e-5, logdir=str(tmp_path), model="DiT-tiny", mean_type="EPSILON")
+    batches = synth_loader(8, 8, 8, 3, 10, latent=True)
+    started = False
+    if wrapped:
+        sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        vaw_amd.dist_util.setup_dist(backend="gloo", device_index=0)
+        started = True
+
+    def fresh(wrap):
+        torch.manual_seed(5)
+        model = vaw_amd.DiT(**kw)
+        perturb_(model, 9)
+        model = model.to(DEV)
+        ema_model = copy.deepcopy(model)
+        net = vaw_amd.DistributedDataParallel(model) if wrap else model
+        opt = vaw_amd.FusedAdamW(model, lr=args.lr, betas=(0.9, 0.95), weight_decay=0.01, eps=1e-8)
+        sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=vaw_amd.get_lr_lambda(args))
+        diff = vaw_amd.GaussianDiffusion(args=args, betas=vaw_amd.get_named_beta_schedule("cosine", 1000),
+                                         model_mean_type=vaw_amd.ModelMeanType.EPSILON, model_var_type=vaw_amd.ModelVarType.FIXED_LARGE,
+                                         loss_type=vaw_amd.LossType.MSE, rescale_timesteps=True)
+        tr = vaw_amd.Trainer(args, torch.device(DEV), net, ema_model, opt, sched, diff, batches, Pbar())
+        return model, net, ema_model, opt, sched, tr
+
+    def steps(tr, first, n):
+        out = []
+        for s in range(first, first + n):
+            torch.manual_seed(1000 + s)           # the CPU RNG stream of step s (noise, t, latent sampling)
+            out.append(tr.train_step(s))
+        return out
+
+    try:
+        model_a, _, ema_a, opt_a, _, tr_a = fresh(wrapped)
+        ref = steps(tr_a, 1, 6)
+        model_b, net_b, ema_b, opt_b, sched_b, tr_b = fresh(wrapped)
+        first = steps(tr_b, 1, 3)
+        path = vaw_amd.save_checkpoint(args, 3, net_b, opt_b, ema_model=ema_b, scheduler=sched_b)
+        ck = torch.load(path, map_location="cpu", weights_only=True)
+        assert set(ck) == {"model", "optimizer", "step", "ema_model", "scheduler"}
+        assert all(k.startswith("module.") for k in ck["model"]) == wrapped
+        n_train = sum(1 for p in model_b.parameters() if p.requires_grad)
+        assert len(ck["optimizer"]["state"]) == n_train and len(ck["optimizer"]["param_groups"][0]["params"]) == len(list(model_b.parameters()))
+        # the optimizer entry loads into a stock torch AdamW over the same parameters (reference main.py:354)
+        stock = torch.optim.AdamW([torch.nn.Parameter(p.detach().clone()) for p in model_b.parameters()], lr=1e-3)
+        stock.load_state_dict(ck["optimizer"])
+        del model_b, net_b, ema_b, opt_b, sched_b, tr_b
+        model_c, net_c, ema_c, opt_c, sched_c, tr_c = fresh(wrapped)
+        with torch.no_grad():                      # make sure nothing survives from the constructor
+            model_c.flat_params().add_(1.0)
+            ema_c.flat_params().mul_(0.0)
+        got = vaw_amd.load_checkpoint(path, model=net_c, optimizer=opt_c, ema_model=ema_c, scheduler=sched_c)
+        assert got["step"] == 3 and opt_c.step_count == 3
+        second = steps(tr_c, 4, 3)
+        assert first + second == ref
+        for (k, v), (_, w) in zip(model_c.state_dict().items(), model_a.state_dict().items()):   # (the flat buffers also hold
+            assert torch.equal(v, w), k                                                            # alignment gaps: compare entries)
+        for (k, v), (_, w) in zip(ema_c.state_dict().items(), ema_a.state_dict().items()):
+            assert torch.equal(v, w), k
+        assert torch.equal(opt_c.exp_avg, opt_a.exp_avg) and torch.equal(opt_c.exp_avg_sq, opt_a.exp_avg_sq)
+        if wrapped:      # cross-loading: the 'module.'-prefixed checkpoint into a bare model
+            model_d = fresh(False)[0]
+            vaw_amd.load_checkpoint(path, model=model_d)
+            for k, v in model_d.state_dict().items():
+                assert torch.equal(v.cpu(), ck["model"]["module." + k]), k
+    finally:
+        if started:
+            vaw_amd.dist_util.cleanup_dist()

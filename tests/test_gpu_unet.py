@@ -109,10 +109,20 @@ def test_conv3x3_via_gemm_matches_torch_and_weight_layout():
     torch.testing.assert_close(_nchw(y.cpu().double(), B, H, H), ref, rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 8, 8, 64, 128), (3, 8, 8, 128, 192), (1, 16, 8, 192, 64), (4, 4, 4, 64, 64)])
-def test_implicit_gemm_conv3x3_fwd_dgrad_wgrad(B, H, W, Ci, Co):
+@pytest.mark.parametrize("tile", [-1, 2, 3])      # kernel by shape / forced persistent kernel with 256- / 192-column tiles
+@pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 8, 8, 64, 128), (3, 8, 8, 128, 192), (1, 16, 8, 192, 64), (4, 4, 4, 64, 64),
+                                         (8, 16, 16, 64, 192), (2, 32, 32, 128, 192), (3, 8, 24, 192, 384)])
+def test_implicit_gemm_conv3x3_fwd_dgrad_wgrad(B, H, W, Ci, Co, tile):
     """vaw_conv3x3 (no patch matrix; padding taps read a zero page) vs torch.conv2d and its gradients.  Small-integer
     data makes the f32 weight gradient exact, so a wrong tap/pixel/channel address shows as a wrong integer."""
+    lib().vaw_debug_gemm_tile(tile)
+    try:
+        _implicit_conv_case(B, H, W, Ci, Co)
+    finally:
+        lib().vaw_debug_gemm_tile(-1)
+
+
+def _implicit_conv_case(B, H, W, Ci, Co):
     g = torch.Generator().manual_seed(B * H + Ci)
     x = torch.randint(-2, 3, (B, Ci, H, W), generator=g).float()
     w = torch.randint(-1, 2, (Co, Ci, 3, 3), generator=g).float()

@@ -183,6 +183,31 @@ def test_unet_factory_param_counts():
     assert sum(p.numel() for p in ounet.ADM_64(num_classes=1000, class_cond=True).parameters()) == g["nparams/ADM_64_c1000"]
 
 
+@pytest.mark.parametrize("name", ["unet64", "adm64", "dit_xl2"])
+def test_full_size_oracle_models_vs_reference_objective(name):
+    """BASELINE configs 2, 3, 5 at full model size, batch 2 (tests/golden/bigcfg.pt, written from the unmodified reference):
+    the oracle's seed-reconstructed weights and its per-sample terms['mse'] (forward only: the CPU suite stays short; the
+    gradients and Trainer steps of the same fixture are checked on the GPU path, tests/test_gpu_bigcfg.py)."""
+    g = load_pt("bigcfg.pt")[name]
+    random.seed(42); np.random.seed(42); torch.manual_seed(42)
+    if name == "unet64":
+        m, args = ounet.UNet_64(class_cond=False), base_args(image_size=64, dataset="ImageNet")
+    elif name == "adm64":
+        m, args = ounet.ADM_64(num_classes=1000, class_cond=True), base_args(image_size=64, dataset="ImageNet", class_cond=True)
+    else:
+        m = odit.DiT_XL(image_size=32, patch_size=2, in_channels=4, class_dropout_prob=0.0, num_classes=1000, learn_sigma=False)
+        args = base_args(in_chans=4, class_cond=True, dataset="Latent", image_size=32)
+    perturb_(m, 7, std=0.02)
+    assert sum(p.numel() for p in m.parameters()) == g["n_params"]
+    assert_fingerprints({k: v.detach() for k, v in m.named_parameters()}, g["params"], 1e-6, 1e-9, "seed-reconstructed weights")
+    diff = od.GaussianDiffusion(args=args, betas=od.get_named_beta_schedule("cosine", 1000), model_mean_type=od.ModelMeanType.EPSILON,
+                                model_var_type=od.ModelVarType.FIXED_LARGE, loss_type=od.LossType.MSE, rescale_timesteps=True)
+    kw = {"y": g["y"]} if g["y"].numel() else {}
+    with torch.no_grad():
+        terms = diff.training_losses(m, g["x"], None, t=g["t"], model_kwargs=kw, noise=g["noise"])
+    torch.testing.assert_close(terms["mse"].double(), g["mse"], rtol=2e-6, atol=0)
+
+
 def _run_trainer(make_model, args, batches, steps, betas2=(0.9, 0.95), var_type="FIXED_LARGE"):
     random.seed(42); np.random.seed(42); torch.manual_seed(42)
     model = make_model()

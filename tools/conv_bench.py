@@ -57,7 +57,12 @@ if __name__ == "__main__":
     ap.add_argument("--shapes", default="unet64")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--modes", default="0,1,2")
+    ap.add_argument("--tiles", default="-1", help="comma list of vaw_debug_gemm_tile modes: -1 by shape, 0 128x128 kernel, 2 / 3 persistent 256 / 192 columns")
     a = ap.parse_args()
+    from vaw_amd._lib import lib
     for (B, H, Ci, Co) in SHAPES[a.shapes]:
         for m in [int(v) for v in a.modes.split(",")]:
-            run(B, H, Ci, Co, m, a.iters)
+            for t in [int(v) for v in a.tiles.split(",")]:
+                lib().vaw_debug_gemm_tile(t)
+                print(f"[tile {t:2d}] ", end="")
+                run(B, H, Ci, Co, m, a.iters)

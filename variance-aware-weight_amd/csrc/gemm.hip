@@ -726,6 +726,8 @@ struct P8Plan {
     int ntw, split, grid;
 };
 P8Plan vaw_p8_plan(int64_t M, int64_t N, int64_t K, bool plain_f32, bool want_colsum, int64_t ws_floats, int force);
+bool vaw_p8_conv(int mode, const bf16_t* act, const bf16_t* act2, const bf16_t* w, void* out, int B, int H, int W, int Ci, int Co,
+                 EpiDev e, float* workspace, int64_t workspace_floats, int force, hipStream_t s);
 void vaw_p8_launch(const P8Plan& pl, int a_kmajor, int b_kmajor, int64_t M, int64_t N, int64_t K, const bf16_t* a, int64_t lda,
                    const bf16_t* b, int64_t ldb, const EpiDev& e, hipStream_t s);
 
@@ -1021,6 +1023,19 @@ extern "C" int vaw_conv3x3(vaw_dtype dt, int mode, const void* act, const void* 
     if (!epi_aligned) return VAW_ERR_UNSUPPORTED;
     VAW_CHECK_ARG(!colsum_out || (workspace && workspace_floats >= ((M + 127) / 128) * N), "conv3x3: colsum_out needs a workspace");
     hipStream_t s = (hipStream_t)stream;
+    {   // the persistent 256-row-tile kernel first (gemm_p8_conv.hip); shapes it declines stay on the 128 x 128 kernel below
+        if (g_gemm_tile == -2) { const char* v = getenv("VAW_GEMM_BIG"); g_gemm_tile = v ? atoi(v) : -1; }
+        const int force = g_gemm_tile == -1 ? -1 : g_gemm_tile == 4 ? 1 : (g_gemm_tile == 2 || g_gemm_tile == 3) ? g_gemm_tile : 0;
+        float* rowsum_out8 = ep ? ep->rowsum_a_out : nullptr;
+        if (!colsum_out && (mode != 2 || act2) && force != 0 &&
+            vaw_p8_conv(mode, (const bf16_t*)act, (const bf16_t*)act2, (const bf16_t*)w, out, B, H, W, Ci, Co, e, workspace, workspace_floats,
+                        force, s)) {
+            VAW_CHECK_LAUNCH("conv3x3_p8");
+            if (rowsum_out8)        // bias gradient = column sums of dy [Mpix][Co] (this kernel does not take them from its staged tiles)
+                return vaw_colsum(dt, act, Mpix, Co, Co, rowsum_out8, ep->rowsum_a_beta, workspace, workspace_floats, stream);
+            return VAW_OK;
+        }
+    }
     const int tiles_n = (int)((N + BN - 1) / BN);
     const int64_t n_wg = ((M + BM - 1) / BM) * tiles_n;
     const int nk_total = (int)(K / 64);

@@ -165,20 +165,21 @@ enum { P8_STORE = 0,   // value = acc*alpha (+ bias) -> C (act dtype or f32)    
        P8_GATE = 3,    // (+ bias) -> aux_out (bf16) -> * gate + resid (f32) -> C (f32)           proj / fc2 forward
        P8_SLAB = 4,    // raw f32 partial sums of one K split                                     weight gradients
        P8_ANY = 5,
-       P8_WGRAD = 6 }; // grouped weight gradients: whole tiles C = beta * C + acc (f32), K-split tiles raw into their slab
+       P8_WGRAD = 6,   // weight gradients: whole tiles C = beta * C + acc (f32), K-split tiles raw into their slab
+       P8_RESID = 7 }; // (+ bias) + resid (act dtype) -> C (bf16)                                  conv forward with a fused skip add
 template <int EPI> struct EpiKind {
     static __device__ __forceinline__ bool act1(const EpiDev& e) { return EPI == P8_GELU || (EPI == P8_ANY && e.act == 1); }
     static __device__ __forceinline__ bool act2(const EpiDev& e) { return EPI == P8_DGELU || (EPI == P8_ANY && e.act == 2); }
     static __device__ __forceinline__ bool gate(const EpiDev& e) { return EPI == P8_GATE || (EPI == P8_ANY && e.gate != nullptr); }
-    static __device__ __forceinline__ bool resid(const EpiDev& e) { return EPI == P8_GATE || (EPI == P8_ANY && e.resid != nullptr); }
-    static __device__ __forceinline__ bool resid_act(const EpiDev& e) { return EPI == P8_ANY && e.resid_act; }
+    static __device__ __forceinline__ bool resid(const EpiDev& e) { return EPI == P8_GATE || EPI == P8_RESID || (EPI == P8_ANY && e.resid != nullptr); }
+    static __device__ __forceinline__ bool resid_act(const EpiDev& e) { return EPI == P8_RESID || (EPI == P8_ANY && e.resid_act); }
     static __device__ __forceinline__ bool rowadd(const EpiDev& e) { return EPI == P8_ANY && e.rowadd != nullptr; }
     static __device__ __forceinline__ bool aux_out(const EpiDev& e) { return EPI == P8_GELU || EPI == P8_GATE || (EPI == P8_ANY && e.aux_out != nullptr); }
     static __device__ __forceinline__ bool out_f32(const EpiDev& e) { return EPI == P8_GATE || EPI == P8_WGRAD || ((EPI == P8_ANY || EPI == P8_STORE) && e.out_f32); }
     static __device__ __forceinline__ bool beta(const EpiDev& e) { return (EPI == P8_ANY || EPI == P8_WGRAD) && e.beta != 0.f; }
     static __device__ __forceinline__ bool colsum(const EpiDev& e) { return (EPI == P8_DGELU || EPI == P8_STORE || EPI == P8_ANY) && e.colpart != nullptr; }
     static constexpr bool may_colsum = EPI == P8_DGELU || EPI == P8_STORE || EPI == P8_ANY;   // the sums are then always carried
-    static constexpr bool loads = EPI == P8_DGELU || EPI == P8_GATE || EPI == P8_ANY;     // epi_load8 has something to fetch
+    static constexpr bool loads = EPI == P8_DGELU || EPI == P8_GATE || EPI == P8_RESID || EPI == P8_ANY;     // epi_load8 has something to fetch
 };
 // Two operand slots: x = GELU'-argument (act == 2) or gate; y = residual or row-add (each pair is mutually exclusive in every
 // launch of the training step; the dispatcher keeps launches that set both members of a pair on the other kernel).

@@ -48,7 +48,14 @@ P8Plan vaw_p8_plan(int64_t M, int64_t N, int64_t K, bool plain_f32, bool want_co
         if (force == 3 && ntw != 3) continue;
         const int bn = 64 * ntw;
         const int64_t tiles = ((M + 255) / 256) * ((N + bn - 1) / bn);
-        if (ntw == 3 && force != 3 && tiles * 3 / 4 <= cus) continue;      // 192 only for multi-round launches
+        if (ntw == 3 && force != 3) {
+            // 192-column tiles: where they cut the padded width (N = 192 k that is not a multiple of 256: the conv channel
+            // counts 192 / 576 / 960 ...), or save whole rounds of a multi-round launch; never for a single round of
+            // equally padded work (N = 768: measured no faster)
+            const int64_t pad4 = ((N + 255) / 256) * 256, pad3 = ((N + 191) / 192) * 192;
+            const int64_t tiles4 = ((M + 255) / 256) * ((N + 255) / 256);
+            if (pad3 > pad4 || (pad3 == pad4 && tiles4 <= cus)) continue;
+        }
         int smax = 1;
         if (plain_f32 && !want_colsum && ws_floats > 0) {
             int64_t s = nk / 4;                                  // every split keeps >= 4 K tiles (256 of K)

@@ -42,6 +42,27 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 #define P8_PART 8192
 #define P8_EPI_BYTES 32768
 
+// ---- implicit-GEMM conv3x3 (stride 1, pad 1, NHWC activations), template parameter CONV (same arithmetic as the CONV modes
+// of gemm_bf16_kernel in gemm.hip; reference ResBlock / stem / head convs, models/unet.py:182-213,492,625):
+//   1 forward         A[m][k=(tap,ci)] = x[pix(m)+s(tap)][ci] (gathered, k-major)   B = W[co][(tap,ci)]            (k-major)
+//   2 input gradient  A[m][k=(tap,co)] = dy[pix(m)+s(tap)][co] (gathered, k-major)  B[k][n=ci] = W[co][8-tap][ci]  (mn-major window)
+//   3 weight gradient, TRANSPOSED: dW^T[(tap,ci)][co] = patches^T . dy
+//                     A[k=pix][m=(tap,ci)] = x[pix+s(tap)][ci] (gathered, mn-major)  B = dy [pix][co]               (mn-major)
+//     (9*Ci rows fill 256-row tiles far better than Co = 192 k would; the slab reduce transposes back to [co][(tap,ci)])
+// The patch matrix never exists: the per-lane SOURCE address of each 16-byte DMA chunk is computed from (pixel, tap,
+// channel); padding taps pass an out-of-range buffer offset and read zeros.  K tiles never straddle a tap (channel counts are multiples of 64).
+// K order of modes 1 and 2: (64-channel block, tap) with the TAP fastest -- nine consecutive K tiles re-read the same
+// 64-channel slab of the tile's pixel neighbourhood (386 pixels x 128 B = 49 KB per workgroup, which the XCD's L2 holds for all
+// its workgroups), where the (tap, channel) order of the weight layout walks the whole neighbourhood (Ci x 772 B: 150-600 KB)
+// once per tap and thrashes the L2.  The weights need no relayout: a K tile is still 64 contiguous elements of a W row.
+struct P8Conv {
+    int H, W, Ci, Co;
+};
+
+__device__ __forceinline__ void p8_dma16(__amdgpu_buffer_rsrc_t rs, char* lds_dst, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)lds_dst, 16, voff, soff, 0, 0);
+}
+
 template <int NTW> struct P8Cfg {
     static constexpr int BN = 64 * NTW;              // 4 waves x NTW MFMA tiles of 16 columns
     static constexpr int WN = 16 * NTW;
@@ -118,11 +139,13 @@ struct P8Item {
     int M, N, kt0, nk, split, prob, tm, rem;   // split < 0: whole tile (GRP); rem: index among the K-split tiles (GRP)
 };
 
-template <bool AK, bool BKM, int NTW, int EPI, bool GRP = false>
+template <bool AK, bool BKM, int NTW, int EPI, bool GRP = false, int CONV = 0>
 __global__ void __launch_bounds__(512, 2)
 gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb, int nk_total,
                int tiles_m, int tiles_n, int n_split, EpiDev e, int team_delay, const P8Prob* __restrict__ probs = nullptr,
-               P8Group grp = P8Group{}) {
+               P8Group grp = P8Group{}, P8Conv cg = P8Conv{}) {
+    static_assert(CONV == 0 || !GRP, "grouped launches are plain GEMMs");
+    static_assert(CONV == 0 || (CONV == 1 && AK && BKM) || (CONV == 2 && AK && !BKM) || (CONV == 3 && !AK && !BKM), "conv layouts");
     using Cfg = P8Cfg<NTW>;
     constexpr int LS = 4 + NTW;                                  // DMA pieces per wave and K tile
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A parts 0-3 | B parts] | 8 x 4 KiB epilogue images
@@ -172,25 +195,84 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
     };
 
     // ---- the DMA stream (runs ahead of the MFMAs; its own item / K-tile position) ----
+    // LDS-DMA by `buffer_load_dwordx4 ... lds`: a scalar buffer resource per operand (base = the item's tile at its first K
+    // tile), a 32-bit per-lane byte offset that is fixed for the whole item, and a scalar byte offset that walks K.  No
+    // 64-bit per-lane address arithmetic in the loop, and a lane that must read zeros (conv padding) simply passes an
+    // out-of-range offset: the hardware returns 0 for it.
     int iss_item = it_cur, iss_kt = 0, iss_nk = 0, iss_stage = 0;
     bool iss_done = iss_item >= n_items;
-    const bf16_t *iss_a = A, *iss_b = B;
-    int off_a[4], off_b[NTW];
-    int64_t a_step = 0, b_step = 0;
+    __amdgpu_buffer_rsrc_t rs_a = epi_rsrc(A), rs_b = epi_rsrc(B);
+    unsigned so_a = 0, so_b = 0, step_a = 0, step_b = 0;
+    unsigned off_a[4], off_b[NTW];
+    // gather modes.  CONV 1/2: (th, tw) = tap of the K tile the stream is on, c0 = its first channel; vm_a[p] bit t = "tap t of this
+    // lane's pixel lies inside the image".  CONV 3: per A piece the pixel (h, w) of this lane's k row, carried from K tile to K
+    // tile, and the tap shift of its column.
+    const int conv_cin = CONV == 1 ? cg.Ci : cg.Co;
+    int iss_th = 0, iss_tw = 0, iss_c0 = 0;
+    unsigned vm_a[4];
+    int ga_h[4], ga_w[4], ga_dh[4], ga_dw[4];
+    const int step_w = CONV == 3 ? 64 % cg.W : 0, step_h = CONV == 3 ? (64 / cg.W) % cg.H : 0;
+    auto conv_point = [&]() {                     // CONV 1/2: scalar offsets of the K tile (tap, c0); bases sit (W + 1) pixels early
+        so_a = (unsigned)(((iss_th * cg.W + iss_tw) * conv_cin + iss_c0) * 2);
+        if (CONV == 1) so_b = (unsigned)(((3 * iss_th + iss_tw) * cg.Ci + iss_c0) * 2);
+        if (CONV == 2) so_b = (unsigned)((iss_c0 * (int)ldb + (8 - 3 * iss_th - iss_tw) * cg.Ci) * 2);
+    };
     auto iss_open = [&]() {                       // position the stream on the first K tile of item iss_item
         const P8Item t = decode(iss_item);
         iss_nk = t.nk;
         iss_kt = 0;
         const int mvalid = t.M - t.m0 < P8_BM ? (int)(t.M - t.m0) : P8_BM;
         const int nvalid = t.N - t.n0 < Cfg::BN ? (int)(t.N - t.n0) : Cfg::BN;
-        a_step = AK ? 64 : 64 * t.lda;
-        b_step = BKM ? 64 : 64 * t.ldb;
-        iss_a = (AK ? t.a + t.m0 * t.lda : t.a + t.m0) + t.kt0 * a_step;
-        iss_b = (BKM ? t.b + t.n0 * t.ldb : t.b + t.n0) + t.kt0 * b_step;
+        const int64_t a_el = AK ? 64 : 64 * t.lda, b_el = BKM ? 64 : 64 * t.ldb;      // elements per K tile
+        step_a = (unsigned)(a_el * 2);
+        step_b = (unsigned)(b_el * 2);
+        so_a = so_b = 0;
+        if (CONV == 0) {
+            rs_a = epi_rsrc((AK ? t.a + t.m0 * t.lda : t.a + t.m0) + t.kt0 * a_el);
+            rs_b = epi_rsrc((BKM ? t.b + t.n0 * t.ldb : t.b + t.n0) + t.kt0 * b_el);
 #pragma unroll
-        for (int p = 0; p < 4; ++p) off_a[p] = p8_src_off<AK>(true, p, wid, lane, t.lda, mvalid);
+            for (int p = 0; p < 4; ++p) off_a[p] = 2u * (unsigned)p8_src_off<AK>(true, p, wid, lane, t.lda, mvalid);
+        } else if (CONV == 1 || CONV == 2) {
+            const int r = 8 * wid + (lane >> 3), chunk = (lane & 7) ^ ((r >> 1) & 7);
 #pragma unroll
-        for (int p = 0; p < NTW; ++p) off_b[p] = p8_src_off<BKM>(false, p, wid, lane, t.ldb, nvalid);
+            for (int p = 0; p < 4; ++p) {         // this lane's row of A part p is one pixel for the whole item
+                int R = r < 32 ? 32 * p + r : 96 + 32 * p + r;
+                R = R < mvalid ? R : mvalid - 1;
+                const int64_t pix = t.m0 + R;
+                const int w = (int)(pix % cg.W), h = (int)((pix / cg.W) % cg.H);
+                unsigned m = 0;
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp)
+                    m |= ((unsigned)(h + tp / 3 - 1) < (unsigned)cg.H && (unsigned)(w + tp % 3 - 1) < (unsigned)cg.W) ? (1u << tp) : 0u;
+                vm_a[p] = m;
+                off_a[p] = (unsigned)((R * conv_cin + chunk * 8) * 2);
+            }
+            iss_th = (t.kt0 % 9) / 3;             // K tile index = 9 * channel block + tap
+            iss_tw = (t.kt0 % 9) % 3;
+            iss_c0 = (t.kt0 / 9) * 64;
+            rs_a = epi_rsrc(t.a + (t.m0 - (cg.W + 1)) * conv_cin);
+            rs_b = epi_rsrc(CONV == 1 ? t.b + t.n0 * t.ldb : t.b + t.n0);
+            conv_point();
+        } else {                                  // CONV 3: A = patches^T, gathered: column m = (tap, ci), k row = pixel
+            const int kr = 8 * wid + (lane >> 3), chunk = (lane & 7) ^ p8_mn_swz(kr);
+            const int64_t pix = (int64_t)t.kt0 * 64 + kr;
+            const int w0 = (int)(pix % cg.W), h0 = (int)((pix / cg.W) % cg.H);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int col = (int)t.m0 + (chunk < 4 ? 32 * p + 8 * chunk : 96 + 32 * p + 8 * chunk);
+                const int tap = col < t.M ? col / cg.Ci : -1;             // beyond 9*Ci (edge tile): zeros, always
+                ga_dh[p] = tap >= 0 ? tap / 3 - 1 : (1 << 20);
+                ga_dw[p] = tap >= 0 ? tap % 3 - 1 : 0;
+                ga_h[p] = h0;
+                ga_w[p] = w0;
+                off_a[p] = tap >= 0 ? (unsigned)(((kr + (ga_dh[p] + 1) * cg.W + ga_dw[p] + 1) * cg.Ci + (col - tap * cg.Ci)) * 2) : EPI_OOB;
+            }
+            rs_a = epi_rsrc(t.a + ((int64_t)t.kt0 * 64 - (cg.W + 1)) * cg.Ci);
+            rs_b = epi_rsrc(t.b + t.n0 + t.kt0 * b_el);
+            step_a = (unsigned)(64 * cg.Ci * 2);
+        }
+#pragma unroll
+        for (int p = 0; p < NTW; ++p) off_b[p] = 2u * (unsigned)p8_src_off<BKM>(false, p, wid, lane, t.ldb, nvalid);
     };
     if (!iss_done) iss_open();
     // piece c of the stream order [B parts 0..NTW-1, A parts 0..3]
@@ -198,18 +280,39 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
         constexpr int c = decltype(cc)::value;
         if (iss_done) return;
         char* dst = smem + iss_stage * Cfg::stage_bytes + wid * 1024;
-        if (c < NTW) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(iss_b + off_b[c < NTW ? c : 0]), (lds_ptr_t)(dst + Cfg::a_bytes + c * P8_PART), 16, 0, 0);
-        else __builtin_amdgcn_global_load_lds((gbl_ptr_t)(iss_a + off_a[c >= NTW ? c - NTW : 0]), (lds_ptr_t)(dst + (c - NTW) * P8_PART), 16, 0, 0);
+        if (c < NTW) {
+            p8_dma16(rs_b, dst + Cfg::a_bytes + c * P8_PART, off_b[c < NTW ? c : 0], so_b);
+        } else {
+            constexpr int p = c >= NTW ? c - NTW : 0;
+            unsigned voff = off_a[p];
+            if (CONV == 1 || CONV == 2) {
+                voff = ((vm_a[p] >> (3 * iss_th + iss_tw)) & 1u) ? voff : EPI_OOB;
+            } else if (CONV == 3) {
+                const bool in = (unsigned)(ga_h[p] + ga_dh[p]) < (unsigned)cg.H && (unsigned)(ga_w[p] + ga_dw[p]) < (unsigned)cg.W;
+                voff = in ? voff : EPI_OOB;
+                ga_w[p] += step_w;                // the next K tile of this piece: 64 pixels further on
+                if (ga_w[p] >= cg.W) { ga_w[p] -= cg.W; ga_h[p] += 1; }
+                ga_h[p] += step_h;
+                if (ga_h[p] >= cg.H) ga_h[p] -= cg.H;
+            }
+            p8_dma16(rs_a, dst + p * P8_PART, voff, so_a);
+        }
     };
     auto iss_advance = [&]() {                    // after the last piece of a K tile
         if (iss_done) return;
         iss_stage ^= 1;
-        iss_a += a_step;
-        iss_b += b_step;
+        if (CONV == 1 || CONV == 2) {
+            if (++iss_tw == 3) { iss_tw = 0; if (++iss_th == 3) { iss_th = 0; iss_c0 += 64; } }
+        } else {
+            so_a += step_a;
+            so_b += step_b;
+        }
         if (++iss_kt == iss_nk) {
             iss_item += G;
             if (iss_item >= n_items) iss_done = true;
             else iss_open();
+        } else if (CONV == 1 || CONV == 2) {
+            conv_point();
         }
     };
 #define P8_PIECE(c) iss_piece(std::integral_constant<int, (c)>{})
@@ -461,16 +564,28 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
 }
 
 
+template <bool AK, bool BKM, int NTW, int EPI, int CONV>
+static void p8_launch_conv(const bf16_t* a, int64_t lda, const bf16_t* b, int64_t ldb, int nk, int tiles_m, int tiles_n, int split,
+                           int grid, const EpiDev& e, const P8Conv& cg, hipStream_t s) {
+    static bool attr_done = false;
+    const int lds = P8Cfg<NTW>::lds_bytes;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)gemm_p8_kernel<AK, BKM, NTW, EPI, false, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_done = true;
+    }
+    gemm_p8_kernel<AK, BKM, NTW, EPI, false, CONV><<<grid, 512, lds, s>>>(a, lda, b, ldb, nk, tiles_m, tiles_n, split, e, 0, nullptr, P8Group{}, cg);
+}
+
 template <bool AK, bool BKM, int NTW, int EPI>
 static void p8_launch_one(const bf16_t* a, int64_t lda, const bf16_t* b, int64_t ldb, int nk, int tiles_m, int tiles_n, int split,
                           int grid, const EpiDev& e, hipStream_t s, int team_delay) {
     static bool attr_done = false;
     const int lds = P8Cfg<NTW>::lds_bytes;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gemm_p8_kernel<AK, BKM, NTW, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm_p8_kernel<AK, BKM, NTW, EPI, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
-    gemm_p8_kernel<AK, BKM, NTW, EPI><<<grid, 512, lds, s>>>(a, lda, b, ldb, nk, tiles_m, tiles_n, split, e, team_delay);
+    gemm_p8_kernel<AK, BKM, NTW, EPI, false, 0><<<grid, 512, lds, s>>>(a, lda, b, ldb, nk, tiles_m, tiles_n, split, e, team_delay);
 }
 
 template <int NTW>
