@@ -282,6 +282,16 @@ int vaw_resample2(vaw_dtype dt, const void* in, void* out, int B, int Ho, int Wo
 int vaw_concat_channels(vaw_dtype dt, void* a, void* b, void* cat, int64_t M, int Ca, int Cb, int split,
                         vaw_stream stream);
 int vaw_add_inplace(vaw_dtype dt, void* dst, const void* src, int64_t n, vaw_stream stream);
+/* ResBlock / resampling variants that no reference factory uses but its constructor accepts (models/unet.py:81-140,206-256):
+ *   vaw_mul         out = a * b (act dtype): nn.Dropout(p) as a product with a pre-scaled keep mask (--dropout, main.py:99)
+ *   vaw_subsample2  mode 0: out[b,i,j,:] = in[b,2i,2j,:] -- Downsample's stride-2 conv = the stride-1 conv sampled at the even
+ *                   pixels; mode 1: its transpose (zeros at the odd pixels).  out is [B,Ho,Wo,C] in both modes
+ *   vaw_rowvec_add  h[b,p,:] += e[b,:] (f32 e, row stride ld): `h + emb_out` of use_scale_shift_norm=False
+ *   vaw_rowvec_sum  de[b,:] = beta*de[b,:] + sum_p dh[b,p,:]: its backward (fixed-order reduction) */
+int vaw_mul(vaw_dtype dt, const void* a, const void* b, void* out, int64_t n, vaw_stream stream);
+int vaw_subsample2(vaw_dtype dt, const void* in, void* out, int B, int Ho, int Wo, int C, int mode, vaw_stream stream);
+int vaw_rowvec_add(vaw_dtype dt, void* h, const float* e, int64_t ld, int B, int HW, int C, vaw_stream stream);
+int vaw_rowvec_sum(vaw_dtype dt, const void* dh, float* de, int64_t ld, int B, int HW, int C, float beta, vaw_stream stream);
 int vaw_nchw_to_nhwc(vaw_dtype dt, const float* nchw, void* nhwc, int B, int C, int HW, vaw_stream stream);
 int vaw_nhwc_to_nchw(vaw_dtype dt, const void* nhwc, float* nchw, int B, int C, int HW, vaw_stream stream);
 

@@ -315,6 +315,30 @@ def gen_unet_tiny():
     torch.save(rec, os.path.join(HERE, "unet_tiny.pt"))
 
 
+def gen_unet_dropout():
+    """nn.Dropout(0.1) inside the ResBlocks (--dropout, main.py:99; models/unet.py:206-213): training-mode forward / backward
+    under torch.manual_seed(5) (the masks come from the CPU generator), plus the eval-mode forward."""
+    from models import unet as U
+    kw = dict(image_size=16, in_channels=3, model_channels=32, out_channels=3, num_res_blocks=1, attention_resolutions=(2,),
+              channel_mult=(1, 2), num_classes=10, num_heads=2, dropout=0.1, use_scale_shift_norm=True, resblock_updown=True,
+              use_new_attention_order=True)
+    g = torch.Generator().manual_seed(14)
+    torch.manual_seed(21)
+    m = U.UNetModel(**kw)
+    m.train()
+    perturb_(m, 77, std=0.03)
+    x = torch.randn(2, 3, 16, 16, generator=g)
+    t, y = torch.tensor([12.0, 845.0]), torch.tensor([3, 7])
+    gout = torch.randn(2, 3, 16, 16, generator=g)
+    torch.manual_seed(5)
+    out, gx, grads = fwd_bwd(m, x, t, y, gout)
+    m.eval()
+    with torch.no_grad():
+        out_eval = m(x, t, y=y)
+    torch.save({"kw": kw, "x": x, "t": t, "y": y, "gout": gout, "out": out, "gx": gx, "grads": summarize(grads),
+                "out_eval": out_eval}, os.path.join(HERE, "unet_dropout.pt"))
+
+
 def synth_loader(B, C, H, n_batches, num_classes, seed=123, latent=False):
     g = torch.Generator().manual_seed(seed)
     batches = []
@@ -544,7 +568,7 @@ def main():
     torch.set_num_threads(8)
     from tools import gaussian_diffusion as gd
     jobs = {"tables": lambda: gen_tables(gd), "weights": lambda: gen_loss_weights(gd),
-            "objective": lambda: gen_objective(gd), "dit": gen_dit_tiny, "unet": gen_unet_tiny, "misc": gen_misc,
+            "objective": lambda: gen_objective(gd), "dit": gen_dit_tiny, "unet": gen_unet_tiny, "unet_dropout": gen_unet_dropout, "misc": gen_misc,
             "trainer": gen_trainer, "bigcfg": gen_bigcfg, "vb": lambda: gen_vb(gd), "trainer_vb": gen_trainer_vb, "sampling": lambda: gen_sampling(gd)}
     for name in (sys.argv[1:] or list(jobs)):
         jobs[name]()

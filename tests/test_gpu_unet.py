@@ -218,8 +218,8 @@ def test_resample_concat_layout(dtype):
     torch.testing.assert_close(back, xin, rtol=1e-2 if dtype == torch.bfloat16 else 0, atol=1e-2 if dtype == torch.bfloat16 else 0)
 
 
-@pytest.mark.parametrize("tag", ["new", "legacy_ss"])
-def test_unet_tiny_fp32_matches_reference_golden(tag):
+@pytest.mark.parametrize("tag", ["new", "legacy_ss", "legacy"])     # legacy: use_scale_shift_norm=False, resblock_updown=False (conv
+def test_unet_tiny_fp32_matches_reference_golden(tag):                 # Upsample / stride-2 Downsample), legacy attention order
     g = load_pt("unet_tiny.pt")
     torch.manual_seed(21)
     m = vaw_amd.UNetModel(compute_dtype="fp32", **g[f"{tag}/kw"])
@@ -242,6 +242,41 @@ def test_unet_tiny_fp32_matches_reference_golden(tag):
     for k, p in m.named_parameters():
         if p.grad is not None:
             torch.testing.assert_close(p.grad.cpu(), 2 * g1[k], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_unet_tiny_dropout_vs_reference_golden(dtype):
+    """--dropout (reference main.py:99, models/unet.py:206-213): nn.Dropout(0.1) inside every ResBlock.  The keep masks come from
+    the CPU generator in the reference's order (host_dropout_rng), so the training-mode forward / backward of the unmodified
+    reference under the same seed is reproduced; eval mode must ignore dropout."""
+    g = load_pt("unet_dropout.pt")
+    torch.manual_seed(21)
+    m = vaw_amd.UNetModel(compute_dtype=dtype, **g["kw"])
+    m = m.to(DEV).train()
+    perturb_(m, 77, std=0.03)
+    m.host_dropout_rng = True
+    x, t, gout, y = (g[k].to(DEV) for k in ("x", "t", "gout", "y"))
+    xr = x.clone().requires_grad_(True)
+    torch.manual_seed(5)
+    out = m(xr, t, y=y)
+    (out * gout).sum().backward()
+    grads = {k: p.grad.cpu() for k, p in m.named_parameters() if p.grad is not None}
+    if dtype == "fp32":
+        torch.testing.assert_close(out.detach().cpu(), g["out"], rtol=1e-4, atol=2e-5)
+        torch.testing.assert_close(xr.grad.cpu(), g["gx"], rtol=1e-4, atol=2e-5)
+        assert_fingerprints(grads, g["grads"], 1e-4, 2e-5, "parameter gradients")
+    else:
+        assert float((out.detach().cpu() - g["out"]).norm() / g["out"].norm()) < 4e-2
+    m.eval()
+    with torch.no_grad():
+        oe = m(x, t, y=y)
+    if dtype == "fp32":
+        torch.testing.assert_close(oe.cpu(), g["out_eval"], rtol=1e-4, atol=2e-5)
+    # device-RNG masks (throughput mode): about 10 % of the activations dropped, different draws give different outputs
+    m.train()
+    m.host_dropout_rng = False
+    o1, o2 = m(x, t, y=y).detach(), m(x, t, y=y).detach()
+    assert not torch.equal(o1, o2) and torch.isfinite(o1).all()
 
 
 def test_unet_tiny_bf16_close_to_reference():

@@ -177,6 +177,23 @@ def test_unet_tiny_matches_reference(tag):
     torch.testing.assert_close(ounet.timestep_embedding(g["temb/t"], 33), g["temb/out33"], rtol=0, atol=0)
 
 
+def test_unet_dropout_oracle_vs_reference():
+    """nn.Dropout inside the ResBlocks: the oracle under the reference's seed reproduces its masks, hence outputs and gradients."""
+    g = load_pt("unet_dropout.pt")
+    torch.manual_seed(21)
+    m = ounet.UNetModel(**g["kw"])
+    m.train()
+    perturb_(m, 77, std=0.03)
+    torch.manual_seed(5)
+    out, gx, grads = _fwd_bwd(m, g["x"], g["t"], g["y"], g["gout"])
+    torch.testing.assert_close(out, g["out"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(gx, g["gx"], rtol=1e-5, atol=1e-6)
+    assert_fingerprints(grads, g["grads"], 1e-4, 1e-6, "grads")
+    m.eval()
+    with torch.no_grad():
+        torch.testing.assert_close(m(g["x"], g["t"], y=g["y"]), g["out_eval"], rtol=1e-5, atol=1e-6)
+
+
 def test_unet_factory_param_counts():
     g = load_pt("unet_tiny.pt")
     assert sum(p.numel() for p in ounet.UNet_64(class_cond=False).parameters()) == g["nparams/UNet_64_uncond"]

@@ -62,6 +62,10 @@ _PROTOS = {
     "vaw_resample2": [_i, _p, _p, _i, _i, _i, _i, _i, _f, _p],
     "vaw_concat_channels": [_i, _p, _p, _p, _l, _i, _i, _i, _p],
     "vaw_add_inplace": [_i, _p, _p, _l, _p],
+    "vaw_mul": [_i, _p, _p, _p, _l, _p],
+    "vaw_subsample2": [_i, _p, _p, _i, _i, _i, _i, _i, _p],
+    "vaw_rowvec_add": [_i, _p, _p, _l, _i, _i, _i, _p],
+    "vaw_rowvec_sum": [_i, _p, _p, _l, _i, _i, _i, _f, _p],
     "vaw_nchw_to_nhwc": [_i, _p, _p, _i, _i, _i, _p],
     "vaw_nhwc_to_nchw": [_i, _p, _p, _i, _i, _i, _p],
     "vaw_sumsq": [_p, _l, _p, _i, _p, _p],

@@ -727,7 +727,8 @@ struct P8Plan {
 };
 P8Plan vaw_p8_plan(int64_t M, int64_t N, int64_t K, bool plain_f32, bool want_colsum, int64_t ws_floats, int force);
 bool vaw_p8_conv(int mode, const bf16_t* act, const bf16_t* act2, const bf16_t* w, void* out, int B, int H, int W, int Ci, int Co,
-                 EpiDev e, float* workspace, int64_t workspace_floats, int force, hipStream_t s);
+                 EpiDev e, float* workspace, int64_t workspace_floats, int force, hipStream_t s, float* bias_grad, float bias_beta,
+                 int* bias_done);
 void vaw_p8_launch(const P8Plan& pl, int a_kmajor, int b_kmajor, int64_t M, int64_t N, int64_t K, const bf16_t* a, int64_t lda,
                    const bf16_t* b, int64_t ldb, const EpiDev& e, hipStream_t s);
 
@@ -1027,11 +1028,12 @@ extern "C" int vaw_conv3x3(vaw_dtype dt, int mode, const void* act, const void* 
         if (g_gemm_tile == -2) { const char* v = getenv("VAW_GEMM_BIG"); g_gemm_tile = v ? atoi(v) : -1; }
         const int force = g_gemm_tile == -1 ? -1 : g_gemm_tile == 4 ? 1 : (g_gemm_tile == 2 || g_gemm_tile == 3) ? g_gemm_tile : 0;
         float* rowsum_out8 = ep ? ep->rowsum_a_out : nullptr;
+        int bias_done = 0;
         if (!colsum_out && (mode != 2 || act2) && force != 0 &&
             vaw_p8_conv(mode, (const bf16_t*)act, (const bf16_t*)act2, (const bf16_t*)w, out, B, H, W, Ci, Co, e, workspace, workspace_floats,
-                        force, s)) {
+                        force, s, mode == 2 ? rowsum_out8 : nullptr, ep ? ep->rowsum_a_beta : 0.f, &bias_done)) {
             VAW_CHECK_LAUNCH("conv3x3_p8");
-            if (rowsum_out8)        // bias gradient = column sums of dy [Mpix][Co] (this kernel does not take them from its staged tiles)
+            if (rowsum_out8 && !bias_done)     // bias gradient = column sums of dy [Mpix][Co], as a pass of its own
                 return vaw_colsum(dt, act, Mpix, Co, Co, rowsum_out8, ep->rowsum_a_beta, workspace, workspace_floats, stream);
             return VAW_OK;
         }

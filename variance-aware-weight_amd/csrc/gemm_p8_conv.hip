@@ -10,8 +10,16 @@ P8Plan vaw_p8_plan(int64_t M, int64_t N, int64_t K, bool plain_f32, bool want_co
 
 // out[n][m] = beta * out[n][m] + sum_s slab[s][m][n]: the slab reduce of the transposed weight-gradient problem
 // (slab rows = (tap, ci), columns = co; out = dW [Co][9*Ci]).  32 x 32 tiles through LDS so both sides stay coalesced.
-__global__ void p8_conv_wgrad_reduce_kernel(const float* __restrict__ slab, int S, int Mt, int Nt, float* __restrict__ out, float beta) {
+__global__ void p8_conv_wgrad_reduce_kernel(const float* __restrict__ slab, int S, int Mt, int Nt, float* __restrict__ out, float beta,
+                                            const float* __restrict__ rowpart, float* __restrict__ bias_out, float bias_beta) {
     __shared__ float tile[32][33];
+    if (rowpart && blockIdx.x == 0 && blockIdx.y == 0) {      // the bias gradient: fold the per-split column sums of dy, fixed order
+        for (int n = threadIdx.x; n < Nt; n += blockDim.x) {
+            float t = 0.f;
+            for (int sp = 0; sp < S; ++sp) t += rowpart[(int64_t)sp * Nt + n];
+            bias_out[n] = (bias_beta != 0.f ? bias_beta * bias_out[n] : 0.f) + t;
+        }
+    }
     const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 8 rows / pass
     for (int r = ty; r < 32; r += 8) {
         const int m = m0 + r, n = n0 + tx;
@@ -32,7 +40,8 @@ __global__ void p8_conv_wgrad_reduce_kernel(const float* __restrict__ slab, int 
 
 // mode 0 forward, 1 input gradient, 2 weight gradient.  Returns false when the shape should stay on gemm.hip's kernel.
 bool vaw_p8_conv(int mode, const bf16_t* act, const bf16_t* act2, const bf16_t* w, void* out, int B, int H, int W, int Ci, int Co,
-                 EpiDev e, float* workspace, int64_t workspace_floats, int force, hipStream_t s) {
+                 EpiDev e, float* workspace, int64_t workspace_floats, int force, hipStream_t s, float* bias_grad, float bias_beta,
+                 int* bias_done) {
     const int64_t Mpix = (int64_t)B * H * W;
     if (Mpix * (Ci > Co ? Ci : Co) >= (1LL << 31) || Mpix % 64) return false;
     int64_t M, N, K;
@@ -48,6 +57,12 @@ bool vaw_p8_conv(int mode, const bf16_t* act, const bf16_t* act2, const bf16_t* 
     const int bn = 64 * pl.ntw, tiles_m = (int)((M + 255) / 256), tiles_n = (int)((N + bn - 1) / bn), nk = (int)(K / 64);
     const P8Conv cg{H, W, Ci, Co};
     e.M = M; e.N = N; e.ldc = N; e.C = out; e.slab = workspace; e.colpart = nullptr; e.rowpart = nullptr; e.nt_off = 1;
+    *bias_done = 0;
+    if (mode == 2 && bias_grad && pl.ntw == 3 && workspace_floats >= (int64_t)pl.split * M * N + (int64_t)pl.split * N) {
+        // bias gradient on the same launch (192-column kernel only: the 256-column one has no registers left for it)
+        e.rowpart = workspace + (int64_t)pl.split * M * N;
+        *bias_done = 1;
+    }
 #define P8C(AKv, BKv, EPIv, CV, a, lda, b, ldb)                                                                                   \
     do {                                                                                                                          \
         if (pl.ntw == 4) p8_launch_conv<AKv, BKv, 4, EPIv, CV>(a, lda, b, ldb, nk, tiles_m, tiles_n, pl.split, pl.grid, e, cg, s); \
@@ -62,7 +77,7 @@ bool vaw_p8_conv(int mode, const bf16_t* act, const bf16_t* act2, const bf16_t* 
         const float beta = e.beta;
         P8C(false, false, P8_SLAB, 3, act2, (int64_t)Ci, act, (int64_t)Co);      // A = x (gathered), B = dy
         dim3 grid((unsigned)((M + 31) / 32), (unsigned)((N + 31) / 32));
-        p8_conv_wgrad_reduce_kernel<<<grid, 256, 0, s>>>(workspace, pl.split, (int)M, (int)N, (float*)out, beta);
+        p8_conv_wgrad_reduce_kernel<<<grid, 256, 0, s>>>(workspace, pl.split, (int)M, (int)N, (float*)out, beta, e.rowpart, bias_grad, bias_beta);
     }
     return true;
 }

@@ -266,6 +266,7 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
                 ga_h[p] = h0;
                 ga_w[p] = w0;
                 off_a[p] = tap >= 0 ? (unsigned)(((kr + (ga_dh[p] + 1) * cg.W + ga_dw[p] + 1) * cg.Ci + (col - tap * cg.Ci)) * 2) : EPI_OOB;
+                if (step_w == 0 && (unsigned)(w0 + ga_dw[p]) >= (unsigned)cg.W) off_a[p] = EPI_OOB;
             }
             rs_a = epi_rsrc(t.a + ((int64_t)t.kt0 * 64 - (cg.W + 1)) * cg.Ci);
             rs_b = epi_rsrc(t.b + t.n0 + t.kt0 * b_el);
@@ -288,10 +289,15 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
             if (CONV == 1 || CONV == 2) {
                 voff = ((vm_a[p] >> (3 * iss_th + iss_tw)) & 1u) ? voff : EPI_OOB;
             } else if (CONV == 3) {
-                const bool in = (unsigned)(ga_h[p] + ga_dh[p]) < (unsigned)cg.H && (unsigned)(ga_w[p] + ga_dw[p]) < (unsigned)cg.W;
-                voff = in ? voff : EPI_OOB;
-                ga_w[p] += step_w;                // the next K tile of this piece: 64 pixels further on
-                if (ga_w[p] >= cg.W) { ga_w[p] -= cg.W; ga_h[p] += 1; }
+                if (step_w == 0) {                // W divides 64 (every UNet level): the column never changes, it was folded
+                                                  // into off_a when the item was opened; only the row moves
+                    voff = (unsigned)(ga_h[p] + ga_dh[p]) < (unsigned)cg.H ? voff : EPI_OOB;
+                } else {
+                    const bool in = (unsigned)(ga_h[p] + ga_dh[p]) < (unsigned)cg.H && (unsigned)(ga_w[p] + ga_dw[p]) < (unsigned)cg.W;
+                    voff = in ? voff : EPI_OOB;
+                    ga_w[p] += step_w;            // the next K tile of this piece: 64 pixels further on
+                    if (ga_w[p] >= cg.W) { ga_w[p] -= cg.W; ga_h[p] += 1; }
+                }
                 ga_h[p] += step_h;
                 if (ga_h[p] >= cg.H) ga_h[p] -= cg.H;
             }
@@ -362,6 +368,13 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int u = 0; u < NTW; ++u) acc[i][u] = f32x4{0, 0, 0, 0};
+        // CONV 3: the bias gradient sum_pixels dy[.][co] rides along as column sums of the B operand, taken by the upper wave
+        // row of the first row tile (tm == 0) of every K split; partial sums per split go to e.rowpart [split][N]
+        const bool do_colsum_b = CONV == 3 && e.rowpart != nullptr && tm == 0 && wr == 0;
+        f32x4 accb[NTW];
+#pragma unroll
+        for (int u = 0; u < NTW; ++u) accb[u] = f32x4{0, 0, 0, 0};
+        const bf16x8 ones8 = {(bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f};
         if (wr == 1) __builtin_amdgcn_s_barrier();       // waves 4-7 run half a phase behind waves 0-3
         int lane_k = lane;
         asm volatile("" : "+v"(lane_k));      // opaque per item: fragment addresses are rebuilt per item, not kept live (and
@@ -401,6 +414,12 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
             P8_WAIT(8);
             __builtin_amdgcn_s_barrier();
             P8_MMA(0);
+            if (CONV == 3 && do_colsum_b) {      // column sums of the B tile (dy): B . ones -- every column of the result holds them
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int u = 0; u < NTW; ++u) accb[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[s][u], ones8, accb[u], 0, 0, 0);
+            }
             __builtin_amdgcn_s_barrier();
             // ---- phase 2
             load_a(1);
@@ -426,6 +445,13 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
         }
         if (wr == 0) __builtin_amdgcn_s_barrier();       // level the two wave rows: both run their epilogues together
 
+        if (CONV == 3 && do_colsum_b && (lane & 15) == 0) {      // lane l (column 0 of the MFMA result) holds rows 4 (l >> 4) + reg
+#pragma unroll
+            for (int u = 0; u < NTW; ++u) {
+                const int64_t nn = n0 + wn0 + 16 * u + 4 * (lane >> 4);
+                if (nn < e.N) store4(e.rowpart + (int64_t)split * e.N + nn, accb[u]);        // N % 8 == 0
+            }
+        }
         if (ei.debug == 1) {   // measurement only (VAW_GEMM_DEBUG=1): no epilogue; one never-taken store keeps the accumulators alive
             float t = 0.f;
 #pragma unroll

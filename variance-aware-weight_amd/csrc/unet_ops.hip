@@ -778,6 +778,87 @@ extern "C" int vaw_add_inplace(vaw_dtype dt, void* dst, const void* src, int64_t
     return VAW_OK;
 }
 
+// ---- ResBlock variants off the factory path (reference models/unet.py:81-140, 206-256) -------------------------------
+// out = a * b elementwise (act dtype): nn.Dropout with a pre-scaled keep mask, forward and backward alike
+template <typename T>
+__global__ void mul_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, int64_t n4) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+        store4(out + 4 * i, load4(a + 4 * i) * load4(b + 4 * i));
+}
+extern "C" int vaw_mul(vaw_dtype dt, const void* a, const void* b, void* out, int64_t n, vaw_stream stream) {
+    VAW_CHECK_ARG(a && b && out && n > 0 && n % 4 == 0, "mul: n must be a positive multiple of 4");
+    BY_DTYPE(dt, (mul_kernel<T><<<sgrid(n / 4, 256), 256, 0, (hipStream_t)stream>>>((const T*)a, (const T*)b, (T*)out, n / 4)));
+    VAW_CHECK_LAUNCH("mul");
+    return VAW_OK;
+}
+
+// mode 0: out[b,i,j,:] = in[b,2i,2j,:]  (the even pixels: a stride-2 conv is the stride-1 conv sampled there)
+// mode 1: out[b,i,j,:] = (i, j both even) ? in[b,i/2,j/2,:] : 0   (its transpose); out is [B,Ho,Wo,C] in both modes
+template <typename T>
+__global__ void subsample2_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int Ho, int Wo, int C, int mode) {
+    const int64_t n4 = (int64_t)B * Ho * Wo * C / 4;
+    const int c4n = C / 4;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        const int64_t pix = i / c4n;
+        const int w = (int)(pix % Wo), h = (int)((pix / Wo) % Ho);
+        const int64_t b = pix / ((int64_t)Wo * Ho);
+        f32x4 v = {0, 0, 0, 0};
+        if (mode == 0) v = load4(in + ((b * 2 * Ho + 2 * h) * (2 * Wo) + 2 * w) * C + 4 * c4);
+        else if (!(h & 1) && !(w & 1)) v = load4(in + ((b * (Ho / 2) + h / 2) * (Wo / 2) + w / 2) * C + 4 * c4);
+        store4(out + 4 * i, v);
+    }
+}
+extern "C" int vaw_subsample2(vaw_dtype dt, const void* in, void* out, int B, int Ho, int Wo, int C, int mode, vaw_stream stream) {
+    VAW_CHECK_ARG(in && out && B > 0 && Ho > 0 && Wo > 0 && C % 4 == 0 && (mode == 0 || (mode == 1 && Ho % 2 == 0 && Wo % 2 == 0)),
+                  "subsample2: bad sizes");
+    const int64_t n4 = (int64_t)B * Ho * Wo * C / 4;
+    BY_DTYPE(dt, (subsample2_kernel<T><<<sgrid(n4, 256), 256, 0, (hipStream_t)stream>>>((const T*)in, (T*)out, B, Ho, Wo, C, mode)));
+    VAW_CHECK_LAUNCH("subsample2");
+    return VAW_OK;
+}
+
+// h[b,p,:] += e[b,:]  (use_scale_shift_norm=False: h + emb_out, reference :250-252); e is f32 with row stride ld
+template <typename T>
+__global__ void rowvec_add_kernel(T* __restrict__ h, const float* __restrict__ e, int64_t ld, int HW, int C, int64_t n4) {
+    const int c4n = C / 4;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        const int64_t b = i / ((int64_t)c4n * HW);
+        store4(h + 4 * i, load4(h + 4 * i) + load4(e + b * ld + 4 * c4));
+    }
+}
+extern "C" int vaw_rowvec_add(vaw_dtype dt, void* h, const float* e, int64_t ld, int B, int HW, int C, vaw_stream stream) {
+    VAW_CHECK_ARG(h && e && B > 0 && HW > 0 && C % 4 == 0 && ld % 4 == 0 && ((uintptr_t)e & 15) == 0, "rowvec_add: bad sizes");
+    const int64_t n4 = (int64_t)B * HW * C / 4;
+    BY_DTYPE(dt, (rowvec_add_kernel<T><<<sgrid(n4, 256), 256, 0, (hipStream_t)stream>>>((T*)h, e, ld, HW, C, n4)));
+    VAW_CHECK_LAUNCH("rowvec_add");
+    return VAW_OK;
+}
+// de[b,c] = beta * de[b,c] + sum_p dh[b,p,c]: one workgroup per (sample, 64-channel slab), fixed-order tree
+template <typename T>
+__global__ void rowvec_sum_kernel(const T* __restrict__ dh, float* __restrict__ de, int64_t ld, int HW, int C, float beta) {
+    __shared__ float part[4][64];
+    const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), r = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (c < C)
+        for (int p = r; p < HW; p += 4) acc += to_f32(dh[((int64_t)b * HW + p) * C + c]);
+    part[r][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (r == 0 && c < C) {
+        const float t = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+        float* o = de + (int64_t)b * ld + c;
+        *o = (beta != 0.f ? beta * *o : 0.f) + t;
+    }
+}
+extern "C" int vaw_rowvec_sum(vaw_dtype dt, const void* dh, float* de, int64_t ld, int B, int HW, int C, float beta, vaw_stream stream) {
+    VAW_CHECK_ARG(dh && de && B > 0 && HW > 0 && C > 0 && B < 65536, "rowvec_sum: bad sizes");
+    dim3 grid(ceil_div(C, 64), B);
+    BY_DTYPE(dt, (rowvec_sum_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)dh, de, ld, HW, C, beta)));
+    VAW_CHECK_LAUNCH("rowvec_sum");
+    return VAW_OK;
+}
+
 extern "C" int vaw_nchw_to_nhwc(vaw_dtype dt, const float* nchw, void* nhwc, int B, int C, int HW, vaw_stream stream) {
     VAW_CHECK_ARG(B > 0 && C > 0 && HW > 0, "nchw_to_nhwc: bad sizes");
     const int64_t n = (int64_t)B * C * HW;

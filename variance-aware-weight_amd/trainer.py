@@ -61,6 +61,8 @@ class Trainer:
             want = "bf16" if args.amp else "fp32"
             if inner.compute_dtype != want:
                 inner.set_compute_dtype(want)
+        if hasattr(inner, "host_dropout_rng"):
+            inner.host_dropout_rng = bool(getattr(args, "cpu_rng", False))      # dropout masks from the CPU stream in parity runs
         self._fused = isinstance(optimizer, FusedAdamW)
         if self._fused and ema_model is not None and dist_util.is_main_process():
             optimizer.attach_ema(ema_model, args.ema_decay)

@@ -55,9 +55,34 @@ class _Resample(nn.Module):
         self.up = up
 
 
-class ResBlock(TimestepBlock):
-    def __init__(self, channels, emb_channels, dropout, out_channels=None, use_conv=False, up=False, down=False):
+class Upsample(nn.Module):
+    """nearest x2 (+ conv3x3): reference models/unet.py:81-110 (resblock_updown=False topologies)."""
+
+    def __init__(self, channels, use_conv, dims=2, out_channels=None):
         super().__init__()
+        self.channels, self.out_channels, self.use_conv = channels, out_channels or channels, use_conv
+        if use_conv:
+            self.conv = nn.Conv2d(self.channels, self.out_channels, 3, padding=1)
+
+
+class Downsample(nn.Module):
+    """conv3x3 stride 2 (or 2x2 average pool): reference models/unet.py:113-140."""
+
+    def __init__(self, channels, use_conv, dims=2, out_channels=None):
+        super().__init__()
+        self.channels, self.out_channels, self.use_conv = channels, out_channels or channels, use_conv
+        if use_conv:
+            self.op = nn.Conv2d(self.channels, self.out_channels, 3, stride=2, padding=1)
+        else:
+            assert self.channels == self.out_channels
+            self.op = nn.AvgPool2d(kernel_size=2, stride=2)
+
+
+class ResBlock(TimestepBlock):
+    def __init__(self, channels, emb_channels, dropout, out_channels=None, use_conv=False, up=False, down=False,
+                 use_scale_shift_norm=True):
+        super().__init__()
+        self.use_scale_shift_norm, self.dropout = use_scale_shift_norm, float(dropout)
         self.channels, self.out_channels = channels, out_channels or channels
         self.in_layers = nn.Sequential(GroupNorm32(32, channels), nn.SiLU(), nn.Conv2d(channels, self.out_channels, 3, padding=1))
         self.updown, self.up, self.down = up or down, up, down
@@ -65,7 +90,7 @@ class ResBlock(TimestepBlock):
             self.h_upd, self.x_upd = _Resample(up), _Resample(up)
         else:
             self.h_upd = self.x_upd = nn.Identity()
-        self.emb_layers = nn.Sequential(nn.SiLU(), nn.Linear(emb_channels, 2 * self.out_channels))
+        self.emb_layers = nn.Sequential(nn.SiLU(), nn.Linear(emb_channels, (2 if use_scale_shift_norm else 1) * self.out_channels))
         self.out_layers = nn.Sequential(GroupNorm32(32, self.out_channels), nn.SiLU(), nn.Dropout(p=dropout),
                                         _zero(nn.Conv2d(self.out_channels, self.out_channels, 3, padding=1)))
         if self.out_channels == channels:
@@ -118,11 +143,10 @@ class UNetModel(FlatModule):
                  use_fp16=False, num_heads=1, num_head_channels=-1, num_heads_upsample=-1, use_scale_shift_norm=False,
                  resblock_updown=False, use_new_attention_order=False, drop_label_prob=0.0, compute_dtype="bf16"):
         super().__init__()
-        if not (use_scale_shift_norm and resblock_updown and dims == 2):
-            raise NotImplementedError("the HIP UNet covers the topology of the reference factories (unet.py:936-939): "
-                                      "use_scale_shift_norm=True, resblock_updown=True, dims=2")
-        if dropout:
-            raise NotImplementedError("dropout > 0 is not on the built path (every reference recipe trains with dropout 0)")
+        if dims != 2:
+            raise NotImplementedError("the HIP UNet is 2-D (every reference factory is, unet.py:936-939)")
+        if not 0.0 <= float(dropout) < 1.0:
+            raise ValueError("dropout must be in [0, 1)")
         if model_channels % 32:
             raise ValueError("GroupNorm32 needs channel counts divisible by 32")
         if num_heads_upsample == -1:
@@ -138,7 +162,7 @@ class UNetModel(FlatModule):
             self.label_emb = nn.Embedding(num_classes + int(drop_label_prob > 0), ted)
 
         def res(cin, cout, **kw):
-            return ResBlock(cin, ted, dropout, out_channels=cout, **kw)
+            return ResBlock(cin, ted, dropout, out_channels=cout, use_scale_shift_norm=use_scale_shift_norm, **kw)
 
         def attn(c, heads):
             return AttentionBlock(c, num_heads=heads, num_head_channels=num_head_channels,
@@ -156,7 +180,8 @@ class UNetModel(FlatModule):
                 self.input_blocks.append(TimestepEmbedSequential(*layers))
                 chans.append(ch)
             if level != len(channel_mult) - 1:
-                self.input_blocks.append(TimestepEmbedSequential(res(ch, ch, down=True)))
+                self.input_blocks.append(TimestepEmbedSequential(res(ch, ch, down=True) if resblock_updown
+                                                                 else Downsample(ch, conv_resample, out_channels=ch)))
                 chans.append(ch)
                 ds *= 2
         self.middle_block = TimestepEmbedSequential(res(ch, None), attn(ch, num_heads), res(ch, None))
@@ -168,7 +193,7 @@ class UNetModel(FlatModule):
                 if ds in attention_resolutions:
                     layers.append(attn(ch, num_heads_upsample))
                 if level and i == num_res_blocks:
-                    layers.append(res(ch, ch, up=True))
+                    layers.append(res(ch, ch, up=True) if resblock_updown else Upsample(ch, conv_resample, out_channels=ch))
                     ds //= 2
                 self.output_blocks.append(TimestepEmbedSequential(*layers))
         self.out = nn.Sequential(GroupNorm32(32, ch), nn.SiLU(), _zero(nn.Conv2d(input_ch, out_channels, 3, padding=1)))
@@ -178,11 +203,14 @@ class UNetModel(FlatModule):
         off = 0
         for rb in self._resblocks:
             rb.emb_off = off
-            off += 2 * rb.out_channels
+            off += (2 if rb.use_scale_shift_norm else 1) * rb.out_channels
         self.emb_cols = off
         self.set_compute_dtype(compute_dtype)
         self._anchor = torch.zeros(1, requires_grad=True)
         self._tape, self._tape_gen, self._rec, self._record_next = [], 0, True, True
+        # nn.Dropout inside the ResBlocks (--dropout, reference main.py:99): True = the keep masks come from the CPU generator, in the
+        # order and shapes the reference's CPU run draws them (parity runs; set by Trainer from args.cpu_rng); False = device RNG
+        self.host_dropout_rng = False
         self.grad_ready_hook = None
 
     # ---- flat storage -----------------------------------------------------------------------
@@ -244,7 +272,7 @@ class UNetModel(FlatModule):
     def host_rng_in_forward(self):
         """True when forward() draws random numbers on the host (the CFG label-drop mask, reference models/unet.py:644-653):
         such a step cannot be captured into a hipGraph (the mask would freeze at its capture-time value)."""
-        return self.num_classes > 0 and self.drop_label_prob > 0
+        return (self.num_classes > 0 and self.drop_label_prob > 0) or (self.dropout > 0 and self.host_dropout_rng)
 
     # ---- engine helpers -----------------------------------------------------------------------
     def _w(self, name):
@@ -429,13 +457,67 @@ class UNetModel(FlatModule):
         self._push(bw)
         return self._linear(o, name + ".proj_out.weight", name + ".proj_out.bias", C, resid=a)
 
+    def _dropout(self, a, p):
+        """nn.Dropout(p) in training mode: a * keep / (1 - p).  The mask is drawn like at::dropout draws it,
+        empty_like(input).bernoulli_(1 - p) over the NCHW tensor, from the CPU generator in parity runs."""
+        if self.host_dropout_rng:
+            keep = torch.empty(a.B, a.C, a.H, a.W).bernoulli_(1 - p).div_(1 - p)
+            mask = keep.permute(0, 2, 3, 1).reshape(a.M, a.C).to(self._flat.device, self._adt)
+        else:
+            mask = (torch.rand(a.M, a.C, device=self._flat.device) < (1 - p)).to(self._adt).mul_(1.0 / (1 - p))
+        y = _Act(self._new(a.M, a.C), a.B, a.H, a.W, a.C)
+        L.check(L.lib().vaw_mul(self._dt, ptr(a.t), ptr(mask), ptr(y.t), a.M * a.C, L.stream_ptr()), "mul")
+
+        def bw():
+            dx = self._new(a.M, a.C)
+            L.check(L.lib().vaw_mul(self._dt, ptr(y.grad), ptr(mask), ptr(dx), a.M * a.C, L.stream_ptr()), "mul")
+            self._acc(a, dx)
+            y.grad = None
+        self._push(bw)
+        return y
+
+    def _add_emb(self, a, off):
+        """h + emb_out (use_scale_shift_norm=False, reference :250-252): the block's row of the packed emb_layers output is added
+        to every pixel, in place (a is the fresh output of the preceding conv)."""
+        e = self._emb_base + 4 * off
+        L.check(L.lib().vaw_rowvec_add(self._dt, ptr(a.t), e, self.emb_cols, a.B, a.H * a.W, a.C, L.stream_ptr()), "rowvec_add")
+        y = _Act(a.t, a.B, a.H, a.W, a.C)
+
+        def bw():
+            L.check(L.lib().vaw_rowvec_sum(self._dt, ptr(y.grad), self._demb + 4 * off, self.emb_cols, a.B, a.H * a.W, a.C, 0.0,
+                                           L.stream_ptr()), "rowvec_sum")
+            self._acc(a, y.grad)
+            y.grad = None
+        self._push(bw)
+        return y
+
+    def _subsample(self, a):
+        """the even pixels of a: a stride-2 conv3x3 (pad 1) is the stride-1 conv sampled there (4x the arithmetic of a strided
+        kernel; Downsample convs exist only in resblock_updown=False topologies, which no reference factory builds)."""
+        Ho, Wo = a.H // 2, a.W // 2
+        y = _Act(self._new(a.B * Ho * Wo, a.C), a.B, Ho, Wo, a.C)
+        L.check(L.lib().vaw_subsample2(self._dt, ptr(a.t), ptr(y.t), a.B, Ho, Wo, a.C, 0, L.stream_ptr()), "subsample2")
+
+        def bw():
+            dx = self._new(a.M, a.C)
+            L.check(L.lib().vaw_subsample2(self._dt, ptr(y.grad), ptr(dx), a.B, a.H, a.W, a.C, 1, L.stream_ptr()), "subsample2")
+            self._acc(a, dx)
+            y.grad = None
+        self._push(bw)
+        return y
+
     def _resblock(self, x, rb):
         name = rb._vaw_name
         h = self._gn(x, rb.in_layers[0], silu=True)
         if rb.updown:
             h, x = self._resample(h, rb.up), self._resample(x, rb.up)
         h = self._conv3(h, rb.in_layers[2])
-        h = self._gn(h, rb.out_layers[0], silu=True, film=self._emb_base + 4 * rb.emb_off)
+        if rb.use_scale_shift_norm:
+            h = self._gn(h, rb.out_layers[0], silu=True, film=self._emb_base + 4 * rb.emb_off)
+        else:
+            h = self._gn(self._add_emb(h, rb.emb_off), rb.out_layers[0], silu=True)
+        if rb.dropout > 0 and self.training:
+            h = self._dropout(h, rb.dropout)
         if isinstance(rb.skip_connection, nn.Identity):
             skip = x
         elif rb.skip_connection.kernel_size == (1, 1):
@@ -452,6 +534,16 @@ class UNetModel(FlatModule):
                 h = self._attention(h, layer)
             elif isinstance(layer, nn.Conv2d):
                 h = self._conv3(h, layer)
+            elif isinstance(layer, Downsample):
+                if layer.use_conv:
+                    assert h.H % 2 == 0 and h.W % 2 == 0, "Downsample conv: even image sizes"
+                    h = self._subsample(self._conv3(h, layer.op))
+                else:
+                    h = self._resample(h, False)
+            elif isinstance(layer, Upsample):
+                h = self._resample(h, True)
+                if layer.use_conv:
+                    h = self._conv3(h, layer.conv)
             else:
                 raise TypeError(type(layer))
         return h
