@@ -533,6 +533,39 @@ def gen_sampling(gd):
     torch.save(out, os.path.join(HERE, "sampling.pt"))
 
 
+def gen_samplers(gd):
+    """EDM Euler / Heun sampler over the DDPM chain (tools/cfg_edm.py Net + ablation_sampler) and the FlowMatching SDE sampler
+    (tools/gaussian_diffusion.py:1374-1409), driven with the deterministic stand-in denoiser and the CPU RNG stream."""
+    from tools.cfg_edm import Net, ablation_sampler
+    out = {"edm": {}, "flow_sde": {}}
+    y = torch.tensor([1, 5, 9])
+    lat = torch.randn(3, 3, 8, 8, generator=torch.Generator().manual_seed(8))
+    for name, kw_net, kw_s in [
+        ("edm_heun_cosine_eps", dict(pred_type="EPSILON", noise_schedule="cosine"), dict(num_steps=9, solver="heun")),
+        ("edm_euler_linear_v", dict(pred_type="VELOCITY", noise_schedule="linear"), dict(num_steps=12, solver="euler")),
+        ("vp_heun_logsnr_x0", dict(pred_type="START_X", noise_schedule="linear_logsnr"),
+         dict(num_steps=8, solver="heun", discretization="vp", schedule="vp", scaling="vp")),
+        ("iddpm_heun_churn", dict(pred_type="EPSILON", noise_schedule="cosine"),
+         dict(num_steps=10, solver="heun", discretization="iddpm", S_churn=4.0, S_min=0.05, S_max=50.0, S_noise=1.003)),
+        ("ve_euler", dict(pred_type="EPSILON", noise_schedule="linear"), dict(num_steps=7, solver="euler", discretization="ve", schedule="ve")),
+    ]:
+        net = Net(model=sampling_model, img_channels=3, img_resolution=8, label_dim=10, amp=False, **kw_net)
+        torch.manual_seed(321)
+        x = ablation_sampler(net, latents=lat, class_labels=y, **kw_s)
+        out["edm"][name] = {"net": kw_net, "sampler": kw_s, "x": x, "sigma_min": net.sigma_min, "sigma_max": net.sigma_max,
+                            "u_sample": net.u[::100].clone()}
+    out["edm_latents"], out["y"] = lat, y
+    noise = torch.randn(3, 3, 8, 8, generator=torch.Generator().manual_seed(9))
+    for path in ("linear", "cosine"):
+        for mt in ("EPSILON", "START_X", "VELOCITY", "VECTOR"):
+            for solver in ("euler", "heun"):
+                fm = gd.FlowMatching(args=base_args(path_type=path, sampler_type="sde"), model_mean_type=gd.ModelMeanType[mt], device="cpu")
+                torch.manual_seed(77)
+                out["flow_sde"][f"{path}/{mt}/{solver}"] = fm.sde_sample(sampling_model, noise, "cpu", num_steps=9, solver=solver, y=y)
+    out["flow_noise"] = noise
+    torch.save(out, os.path.join(HERE, "samplers.pt"))
+
+
 def gen_misc():
     from tools.utils import warmup_cosine_lr
     from tools import resample as R
@@ -569,7 +602,7 @@ def main():
     from tools import gaussian_diffusion as gd
     jobs = {"tables": lambda: gen_tables(gd), "weights": lambda: gen_loss_weights(gd),
             "objective": lambda: gen_objective(gd), "dit": gen_dit_tiny, "unet": gen_unet_tiny, "unet_dropout": gen_unet_dropout, "misc": gen_misc,
-            "trainer": gen_trainer, "bigcfg": gen_bigcfg, "vb": lambda: gen_vb(gd), "trainer_vb": gen_trainer_vb, "sampling": lambda: gen_sampling(gd)}
+            "trainer": gen_trainer, "bigcfg": gen_bigcfg, "vb": lambda: gen_vb(gd), "trainer_vb": gen_trainer_vb, "sampling": lambda: gen_sampling(gd), "samplers": lambda: gen_samplers(gd)}
     for name in (sys.argv[1:] or list(jobs)):
         jobs[name]()
         print("wrote", name)

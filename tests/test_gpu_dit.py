@@ -410,3 +410,27 @@ def test_checkpoint_resume_hip_dit_fused_adamw_is_bitwise(tmp_path, wrapped):
     finally:
         if started:
             vaw_amd.dist_util.cleanup_dist()
+
+
+def test_edm_heun_sampling_hip_dit_vs_oracle_dit():
+    """EDM Heun sampler (vaw_amd.edm_sample over vaw_amd.EDMDenoiser) with the HIP DiT in eval mode under IntervalCFG vs the same
+    sampler code over the oracle DiT on the CPU: same weights, same CPU RNG stream, f32 kernels; 2 x 7 - 1 chained model calls."""
+    from oracle import dit as odit, sampler as osam
+    kw = dict(image_size=8, patch_size=2, in_channels=4, hidden_size=64, depth=2, num_heads=2, class_dropout_prob=0.1,
+              num_classes=10, learn_sigma=False)
+    torch.manual_seed(3)
+    om = odit.DiT(**kw)
+    perturb_(om, 17)
+    hm = vaw_amd.DiT(compute_dtype="fp32", **kw)
+    hm.load_state_dict(om.state_dict())
+    hm, om = hm.to(DEV).eval(), om.eval()
+    lat = torch.randn(4, 4, 8, 8, generator=torch.Generator().manual_seed(2))
+    y = torch.tensor([0, 3, 7, 9])
+    outs = []
+    for model, cfgc, dev in ((om, osam.IntervalCFG, "cpu"), (hm, vaw_amd.IntervalCFG, DEV)):
+        net = vaw_amd.EDMDenoiser(cfgc(model, 10, 1.7, (-1.0, -1.0), True).eval(), img_resolution=8, img_channels=4, label_dim=10,
+                                  pred_type="EPSILON", noise_schedule="cosine").to(dev)
+        torch.manual_seed(11)
+        rl = lambda t: torch.randn(t.shape, dtype=t.dtype).to(t.device)          # CPU stream for both
+        outs.append(vaw_amd.edm_sample(net, lat.to(dev), class_labels=y.to(dev), num_steps=7, solver="heun", S_churn=2.0, randn_like=rl).cpu())
+    torch.testing.assert_close(outs[1], outs[0], rtol=1e-4, atol=1e-4)
