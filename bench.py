@@ -198,7 +198,9 @@ def spawn_ranks(n):
     rc = procs[0].returncode
     for p in procs[1:]:
         rc = rc or p.wait()
-    sys.stdout.write(out)
+    # rank 0's stdout may carry backend chatter (e.g. gloo's connection notice): relay the result line alone on stdout
+    for line in out.splitlines():
+        (sys.stdout if line.startswith('{"metric"') else sys.stderr).write(line + "\n")
     sys.stdout.flush()
     raise SystemExit(rc)
 

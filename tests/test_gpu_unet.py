@@ -151,8 +151,12 @@ def _implicit_conv_case(B, H, W, Ci, Co):
     assert ops.conv3x3(BF16, 2, ptr(dyd), ptr(xd), None, ptr(dw2), B, H, W, Ci, Co, rowsum_a_out=ptr(db), rowsum_a_beta=0.5)
     assert torch.equal(dw2.cpu().double().permute(0, 3, 1, 2), wr.grad)
     assert torch.equal(db.cpu().double(), 1.0 + dy.double().sum((0, 2, 3)))
-    # unsupported shapes decline without launching
+    # unsupported shapes decline without launching -- visibly: a one-time warning and a counter
+    ops.fallbacks.clear()
+    with pytest.warns(RuntimeWarning, match="falling back to im2col"):
+        assert not ops.conv3x3(BF16, 0, ptr(xd), None, ptr(wd), ptr(y), B, H, W, 24, Co)
     assert not ops.conv3x3(BF16, 0, ptr(xd), None, ptr(wd), ptr(y), B, H, W, 24, Co)
+    assert ops.fallbacks == {("conv3x3", "fwd", B, H, W, 24, Co): 2}
     assert not ops.conv3x3(F32, 0, ptr(xd), None, ptr(wd), ptr(y), B, H, W, Ci, Co)
 
 

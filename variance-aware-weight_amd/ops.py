@@ -211,6 +211,14 @@ def conv3x3(dt, mode, act, act2, w, out, B, H, W, Ci, Co, *, bias=None, resid=No
         e0.record()
     rc = L.lib().vaw_conv3x3(dt, mode, act, act2 or None, w, out, B, H, W, Ci, Co, C.byref(e), ws.data_ptr(), ws.numel(), stream_ptr())
     if rc == -3:
+        if dt == L.BF16:       # the f32 parity mode always takes the explicit path; in bf16 it is a performance cliff worth a word
+            key = ("conv3x3", ("fwd", "dgrad", "wgrad")[mode], B, H, W, Ci, Co)
+            fallbacks[key] = fallbacks.get(key, 0) + 1
+            if fallbacks[key] == 1:
+                import warnings
+                warnings.warn(f"vaw_amd: conv3x3 {key[1]} [B={B}, {H}x{W}, Ci={Ci}, Co={Co}] is not covered by the implicit-GEMM kernels "
+                              "(channel counts off the 64 / 8 grid?): falling back to im2col + GEMM; counts in vaw_amd.ops.fallbacks",
+                              RuntimeWarning, stacklevel=3)
         return False
     check(rc, "vaw_conv3x3")
     if tr is not None:
@@ -218,6 +226,9 @@ def conv3x3(dt, mode, act, act2, w, out, B, H, W, Ci, Co, *, bias=None, resid=No
         M = B * H * W
         tr.add(1, mode != 2, mode == 0, *((M, Co, 9 * Ci) if mode == 0 else (M, Ci, 9 * Co) if mode == 1 else (Co, 9 * Ci, M)), e0, e1)
     return True
+
+
+fallbacks = {}       # (op, variant, shape...) -> times a bf16 launch left the fast kernels for the explicit path
 
 
 class GemmTrace:
