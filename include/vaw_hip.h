@@ -27,7 +27,8 @@ extern "C" {
 #endif
 
 typedef enum { VAW_OK = 0, VAW_ERR_INVALID = -1, VAW_ERR_LAUNCH = -2, VAW_ERR_UNSUPPORTED = -3 } vaw_status;
-typedef enum { VAW_F32 = 0, VAW_BF16 = 1 } vaw_dtype;
+typedef enum { VAW_F32 = 0, VAW_BF16 = 1,
+               VAW_FP8 = 2, VAW_BF8 = 3 /* OCP e4m3fn / e5m2: GEMM operand formats of vaw_gemm_fp8 and vaw_wgrad_grouped only */ } vaw_dtype;
 typedef void* vaw_stream;
 
 int vaw_version(void);
@@ -136,10 +137,36 @@ typedef struct {
     const void* x;         /* act dtype (bf16) [K][N], row stride ld_x */
     float* dw;             /* f32 [M][N], row stride ld_dw */
     int64_t M, N, ld_dy, ld_x, ld_dw;
+    float alpha;           /* scales dy^T x before it is added (0 = 1) */
+    int pad_;
+    const float* scale_dy; /* dt = VAW_FP8 / VAW_BF8 only: dy and x are the TRANSPOSED e4m3 copies dy^T [M][K] and x^T [N][K] (k-major), ld_*  */
+    const float* scale_x;  /* their row strides, and these DEVICE scalars their per-tensor dequantisation scales (vaw_fp8_quantize) */
 } vaw_wgrad_problem;
 int64_t vaw_wgrad_grouped_desc_bytes(int n_problems);
 int vaw_wgrad_grouped(vaw_dtype dt, int n_problems, const vaw_wgrad_problem* problems, int64_t K, float beta, void* desc_dev,
                       int upload, float* workspace, int64_t workspace_floats, vaw_stream stream);
+
+/* fp8 operands (OCP e4m3fn, per-tensor scaling) for the Linear GEMMs: BASELINE.json config 5 "DiT-XL/2, fp8 MFMA GEMMs + bf16
+ * accum" (model: models/dit.py:373, recipe run.sh:20-26; the reference itself trains that model in bf16 autocast).
+ *
+ * vaw_fp8_quantize: q[r,c] = fp8(src[r,c] * FMAX / amax|src|) (round to nearest even), qt[c,r] = q[r,c] (optional transposed
+ * copy: every fp8 GEMM takes both operands k-major, so dgrad reads W^T and wgrad reads dy^T and x^T), and *scale_out =
+ * amax / FMAX (1 for an all-zero tensor), a DEVICE scalar: nothing syncs with the host.  dst_format: VAW_FP8 (e4m3fn, FMAX 448:
+ * weights and activations) or VAW_BF8 (e5m2, FMAX 57344: gradients).  src: f32 or bf16 [R][C], row stride ld; q: [R][C] bytes,
+ * stride ldq; qt: [C][R] bytes, stride ldt.  C, ld, ldq, ldt multiples of 4.
+ * workspace: vaw_fp8_quantize_workspace_floats() floats (amax partials, folded in a fixed order). */
+int64_t vaw_fp8_quantize_workspace_floats(void);
+int vaw_fp8_quantize(vaw_dtype src_dt, vaw_dtype dst_format, const void* src, int64_t R, int64_t C, int64_t ld, void* q, int64_t ldq,
+                     void* qt, int64_t ldt, float* scale_out, float* workspace, int64_t workspace_floats, vaw_stream stream);
+/* C[M,N] = epilogue(alpha * *scale_a * *scale_b * A[M,K] . B[N,K]^T): A bytes of a_format (VAW_FP8 | VAW_BF8), B e4m3 bytes,
+ * both k-major (K % 128 == 0, row strides multiples of 16), f32 accumulation on v_mfma_scale_f32_16x16x128_f8f6f4 with unit
+ * block scales; C and the epilogue operands as for vaw_gemm with dt = VAW_BF16 (bf16 C / aux, or f32 C with out_f32).
+ * Epilogues offered: bias (+ colsum_out), either A format; GELU' (+ colsum_out), either; bias + aux_out + GELU and bias +
+ * aux_out + gate + f32 residual, e4m3 A.  Others return VAW_ERR_UNSUPPORTED.
+ * Weight gradients: vaw_wgrad_grouped with dt = VAW_FP8 (dy^T, x^T e4m3) or VAW_BF8 (dy^T e5m2, x^T e4m3). */
+int vaw_gemm_fp8(vaw_dtype a_format, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const float* scale_a,
+                 const void* B, int64_t ldb, const float* scale_b, void* C, int64_t ldc, const vaw_epilogue* epi_host,
+                 float* workspace, int64_t workspace_floats, vaw_stream stream);
 
 /* 1 when vaw_gemm would run these operands on the bf16 MFMA kernel (M%128==0, N%128==0, K%64==0, 16-byte
  * aligned rows), 0 when it takes the exact-f32 generic kernel.  For measurement and tests. */

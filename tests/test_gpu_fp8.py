@@ -1,0 +1,167 @@
+"""fp8 (OCP e4m3fn / e5m2) GEMM path of BASELINE.json config 5 through the C ABI: vaw_fp8_quantize, vaw_gemm_fp8 and
+vaw_wgrad_grouped(dt = VAW_FP8).
+
+  * the quantiser is byte-exact against torch's float8_e4m3fn cast of the same scaled values (round to nearest even) and its
+    transposed copy is the transpose;
+  * the GEMMs are checked with small integers (exact in e4m3, exact in the f32 accumulator) and power-of-two scales, so operand
+    layout, block-scale encoding, tile edges, grouping, K split and fixup must all be right bit for bit;
+  * the fused epilogues are checked against float64 arithmetic on the dequantised operands.
+There is no reference fp8 code to pin against (the reference trains this model under bf16 autocast); the end-to-end drift of the fp8
+training step against the reference's f32 fixture is asserted in test_gpu_bigcfg.py."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import vaw_amd
+from vaw_amd import ops
+from vaw_amd._lib import BF8, FP8, ptr
+
+DEV = "cuda"
+E4M3, E5M2 = torch.float8_e4m3fn, torch.float8_e5m2
+FMT = {"e4m3": (FP8, E4M3, 448.0), "e5m2": (BF8, E5M2, 57344.0)}
+
+
+def _bytes(t, tdt=E4M3):
+    """exactly representable float values -> fp8 bytes on the GPU"""
+    assert torch.equal(t.to(tdt).float(), t)
+    return t.to(tdt).view(torch.uint8).to(DEV)
+
+
+@pytest.mark.parametrize("fmt", ["e4m3", "e5m2"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("R,C", [(256, 128), (200, 264), (1000, 68), (4, 4), (64, 2048)])
+def test_quantize_bytes_and_transpose(dtype, R, C, fmt):
+    code, E, FMAX = FMT[fmt]
+    g = torch.Generator().manual_seed(R + C)
+    x = (torch.randn(R, C, generator=g) * torch.logspace(-3, 1, C)[None, :]).to(dtype)     # wide dynamic range: subnormals, zeros
+    x[0, 0] = 0.0
+    f = ops.Fp8(R, C, torch.device(DEV), fmt=code).quantize(x.to(DEV))
+    amax = x.float().abs().max()
+    scale = amax / torch.tensor(FMAX)
+    inv = torch.tensor(1.0) / scale
+    ref = (x.float() * inv).to(E).view(torch.uint8)
+    assert float(f.scale.cpu()) == float(scale)
+    assert torch.equal(f.q.cpu(), ref)
+    assert torch.equal(f.qt.cpu(), ref.t())
+    # transposed copy only
+    f2 = ops.Fp8(R, C, torch.device(DEV), plain=False, fmt=code).quantize(x.to(DEV))
+    assert torch.equal(f2.qt.cpu(), ref.t())
+    z = ops.Fp8(R, C, torch.device(DEV), fmt=code).quantize(torch.zeros(R, C, device=DEV, dtype=dtype))
+    assert float(z.scale.cpu()) == 1.0 and int(z.q.max()) == 0
+    # a row count off the 4-grid: no transposed copy (its row stride would not be a multiple of 4), plain copy still exact
+    f3 = ops.Fp8(R - 1, C, torch.device(DEV), transposed=False, fmt=code).quantize(x[1:].contiguous().to(DEV))
+    x3 = x[1:].float()
+    s3 = x3.abs().max() / torch.tensor(FMAX)
+    assert torch.equal(f3.q.cpu(), (x3 * (torch.tensor(1.0) / s3)).to(E).view(torch.uint8))
+
+
+def _int_operands(M, N, K, seed):
+    g = torch.Generator().manual_seed(seed)
+    A = torch.randint(-4, 5, (M, K), generator=g).float()
+    B = torch.randint(-4, 5, (N, K), generator=g).float()
+    # make the k positions distinguishable (a k permutation applied to one operand only would change the result)
+    A[:, ::7] *= 2
+    B[:, 1::5] *= 0.5
+    return A, B
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 1152), (1000, 264, 384), (4096, 1152, 1152), (272, 192, 256),
+                                   (256, 2304, 256)])
+@pytest.mark.parametrize("afmt", ["e4m3", "e5m2"])
+def test_gemm_fp8_exact_integers(M, N, K, afmt):
+    acode, AE, _ = FMT[afmt]
+    A, B = _int_operands(M, N, K, M + N + K)
+    sa = torch.tensor([0.5], device=DEV)
+    sb = torch.tensor([4.0], device=DEV)
+    bias = torch.randint(-3, 4, (N,)).float()
+    ref = 2.0 * (A.double() @ B.double().t()) + bias.double()
+    Ad, Bd, bd = _bytes(A, AE), _bytes(B), bias.to(DEV)
+    out = torch.empty(M, N, device=DEV, dtype=torch.float32)
+    ops.gemm_fp8(M, N, K, ptr(Ad), K, ptr(sa), ptr(Bd), K, ptr(sb), ptr(out), N, a_format=acode, bias=ptr(bd), out_f32=True)
+    assert torch.equal(out.cpu().double(), ref), (out.cpu().double() - ref).abs().max()
+    # bf16 output + column sums of what was stored
+    outb = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    cs = torch.zeros(N, device=DEV)
+    ops.gemm_fp8(M, N, K, ptr(Ad), K, ptr(sa), ptr(Bd), K, ptr(sb), ptr(outb), N, a_format=acode, colsum_out=ptr(cs))
+    refb = (2.0 * (A.double() @ B.double().t())).float().bfloat16()
+    assert torch.equal(outb.cpu(), refb)
+    torch.testing.assert_close(cs.cpu().double(), refb.double().sum(0), rtol=1e-6, atol=1e-3)
+
+
+def test_gemm_fp8_epilogues():
+    M, N, K, T = 1024, 768, 512, 256
+    g = torch.Generator().manual_seed(5)
+    dev = torch.device(DEV)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * 0.05
+    fx, fw = ops.Fp8(M, K, dev).quantize(x.to(DEV)), ops.Fp8(N, K, dev).quantize(w.to(DEV))
+    xd, wd = fx.dequant().cpu().double(), fw.dequant().cpu().double()
+    bias = torch.randn(N, generator=g)
+    bias_d = bias.to(DEV)          # (device operands live in named tensors: a temporary's memory is reused by the next .to())
+    lin = xd @ wd.t() + bias.double()
+    args = (M, N, K, ptr(fx.q), K, ptr(fx.scale), ptr(fw.q), K, ptr(fw.scale))
+    # bias + aux_out + GELU(tanh)
+    out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    aux = torch.empty_like(out)
+    ops.gemm_fp8(*args, ptr(out), N, bias=ptr(bias_d), act=1, aux_out=ptr(aux))
+    torch.testing.assert_close(aux.cpu().double(), lin, rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(out.cpu().double(), torch.nn.functional.gelu(aux.cpu().double(), approximate="tanh"), rtol=1e-2, atol=1e-2)
+    # GELU'(aux_in) + column sums
+    pre = torch.randn(M, N, generator=g).bfloat16()
+    cs = torch.zeros(N, device=DEV)
+    pre_d = pre.to(DEV)
+    ops.gemm_fp8(*args, ptr(out), N, act=2, aux_in=ptr(pre_d), colsum_out=ptr(cs))
+    p = pre.double().requires_grad_(True)
+    torch.nn.functional.gelu(p, approximate="tanh").sum().backward()
+    torch.testing.assert_close(out.cpu().double(), (xd @ wd.t()) * p.grad, rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(cs.cpu().double(), out.cpu().double().sum(0), rtol=1e-5, atol=1e-2)
+    # bias + aux_out + gate + f32 residual
+    gate = torch.randn(M // T, N, generator=g)
+    resid = torch.randn(M, N, generator=g)
+    outf = torch.empty(M, N, device=DEV, dtype=torch.float32)
+    gate_d, resid_d = gate.to(DEV), resid.to(DEV)
+    ops.gemm_fp8(*args, ptr(outf), N, bias=ptr(bias_d), aux_out=ptr(aux), gate=ptr(gate_d), gate_ld=N,
+                 resid=ptr(resid_d), rows_per_batch=T, out_f32=True)
+    want = aux.cpu().double() * gate.double().repeat_interleave(T, 0) + resid.double()
+    torch.testing.assert_close(aux.cpu().double(), lin, rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(outf.cpu().double(), want, rtol=1e-5, atol=1e-5)
+    # an epilogue without an fp8 kernel is refused, not approximated
+    with pytest.raises(vaw_amd.VawError):
+        ops.gemm_fp8(*args, ptr(outf), N, act=1, out_f32=True)
+
+
+@pytest.mark.parametrize("dyfmt", ["e5m2", "e4m3"])
+@pytest.mark.parametrize("case", ["few_tiles_split", "full_rounds_plus_split", "n192", "edges_accumulate"])
+def test_wgrad_grouped_fp8_exact_integers(case, dyfmt):
+    """dW_p (+)= alpha_p * s_dy * s_x * dy_p^T x_p from the transposed e4m3 copies dy^T [M][K], x^T [N][K]."""
+    code, DE, _ = FMT[dyfmt]
+    g = torch.Generator().manual_seed(13)
+    shapes, K, beta = {
+        "few_tiles_split": ([(768, 768), (2304, 768), (256, 512)], 1024, 0.0),
+        "full_rounds_plus_split": ([(512, 512)] * 70, 2560, 0.0),
+        "n192": ([(384, 1152), (1152, 384), (256, 192)], 512, 0.0),
+        "edges_accumulate": ([(200, 264), (520, 72), (136, 1000)], 384, 1.0),
+    }[case]
+    probs, keep, refs = [], [], []
+    for i, (M, N) in enumerate(shapes):
+        dyT = torch.randint(-3, 4, (M, K), generator=g).float()
+        xT = torch.randint(-3, 4, (N, K), generator=g).float()
+        dyT[:, ::3] *= 2
+        dw0 = torch.randint(-5, 6, (M, N), generator=g).float()
+        s_dy = torch.tensor([2.0 if i % 2 else 0.25], device=DEV)
+        s_x = torch.tensor([0.5], device=DEV)
+        alpha = 2.0 if i == 1 else 0.0          # 0 = 1
+        dyd, xd, dwd = _bytes(dyT, DE), _bytes(xT), dw0.to(DEV).clone()
+        keep += [dyd, xd, dwd, s_dy, s_x]
+        probs.append((ptr(dyd), ptr(xd), ptr(dwd), M, N, K, K, N, alpha, 0, ptr(s_dy), ptr(s_x)))
+        f = (alpha or 1.0) * float(s_dy) * float(s_x)
+        refs.append((dwd, beta * dw0.double() + f * (dyT.double() @ xT.double().t())))
+    grp = ops.WgradGroup(probs, K, torch.device(DEV))
+    grp.launch(code, beta)
+    for i, (got, ref) in enumerate(refs):
+        assert torch.equal(got.cpu().double(), ref), (case, i, shapes[i], (got.cpu().double() - ref).abs().max())
+    if beta == 0.0:
+        grp.launch(code, 0.0)
+        for got, ref in refs:
+            assert torch.equal(got.cpu().double(), ref)

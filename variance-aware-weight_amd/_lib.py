@@ -8,7 +8,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvaw_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, FP8, BF8 = 0, 1, 2, 3
 TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16}
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -75,6 +75,8 @@ _PROTOS = {
     "vaw_cast_bf16": [_p, _p, _l, _p],
     "vaw_uncast_bf16": [_p, _p, _l, _f, _p],
     "vaw_wgrad_grouped": [_i, _i, _p, _l, _f, _p, _i, _p, _l, _p],
+    "vaw_fp8_quantize": [_i, _i, _p, _l, _l, _l, _p, _l, _p, _l, _p, _p, _l, _p],
+    "vaw_gemm_fp8": [_i, _l, _l, _l, _p, _l, _p, _p, _l, _p, _p, _l, C.POINTER(Epilogue), _p, _l, _p],
 }
 
 _lib = None
@@ -108,6 +110,8 @@ def lib():
         L.vaw_groupnorm_workspace_floats.restype = _l
         L.vaw_wgrad_grouped_desc_bytes.argtypes = [_i]
         L.vaw_wgrad_grouped_desc_bytes.restype = _l
+        L.vaw_fp8_quantize_workspace_floats.argtypes = []
+        L.vaw_fp8_quantize_workspace_floats.restype = _l
         L.vaw_sumsq_workspace_floats.argtypes = []
         L.vaw_sumsq_workspace_floats.restype = _l
         L.vaw_debug_force_rowwise_attention.argtypes = [_i]
@@ -123,7 +127,8 @@ def lib():
 def exported_symbols():
     return sorted(list(_PROTOS) + ["vaw_version", "vaw_last_error_string", "vaw_colsum_workspace_floats",
                                    "vaw_sumsq_workspace_floats", "vaw_groupnorm_workspace_floats", "vaw_wgrad_grouped_desc_bytes",
-                                   "vaw_conv3x3_wgrad_small_workspace_floats", "vaw_row_bwd_workspace_floats"])
+                                   "vaw_conv3x3_wgrad_small_workspace_floats", "vaw_row_bwd_workspace_floats",
+                                   "vaw_fp8_quantize_workspace_floats"])
 
 
 def check(rc, what):

@@ -18,6 +18,8 @@ struct EpiDev {
     int64_t M, N, ldc;
     void* C;
     float* slab;   // split-K partial sums [n_split][M][N] f32 (workspace), or NULL
+    const float* scale_a;   // fp8 operands: device scalars (per-tensor dequantisation scales) multiplied into alpha, or NULL
+    const float* scale_b;
     int nt_off;       // 1 (default): gemm_p8 epilogue stores use the default cache policy; 0 (VAW_P8_NT=1): non-temporal
     int debug;        // measurement only (VAW_GEMM_DEBUG): 1 = skip the epilogue, 2 = skip the K loop (ablations 3-5 of DESIGN.md §5 lived here)
     int direct_epi;   // 1: register-direct epilogue (default), 0: LDS-staged (VAW_GEMM_EPI=0; always for fused column sums)

@@ -111,18 +111,24 @@ void vaw_p8_launch(const P8Plan& pl, int a_kmajor, int b_kmajor, int64_t M, int6
 // ---- grouped weight gradients -----------------------------------------------------------------------------------
 #include <vector>
 
+void vaw_p8_group_fp8(int ntw, bool a_e5m2, int nk, int grid, const EpiDev& e, const P8Prob* probs_dev, const P8Group& grp, hipStream_t s);   // gemm_p8_fp8.hip
+
 extern "C" int64_t vaw_wgrad_grouped_desc_bytes(int n_problems) { return (int64_t)n_problems * (int64_t)sizeof(P8Prob); }
 
 extern "C" int vaw_wgrad_grouped(vaw_dtype dt, int n_problems, const vaw_wgrad_problem* problems, int64_t K, float beta,
                                  void* desc_dev, int upload, float* workspace, int64_t workspace_floats, vaw_stream stream) {
-    VAW_CHECK_ARG(dt == VAW_BF16, "wgrad_grouped: bf16 activations only (the f32 parity mode runs vaw_gemm per layer)");
-    VAW_CHECK_ARG(n_problems > 0 && problems && desc_dev && K > 0 && K % 64 == 0, "wgrad_grouped: bad arguments (K %% 64)");
+    VAW_CHECK_ARG(dt == VAW_BF16 || dt == VAW_FP8 || dt == VAW_BF8, "wgrad_grouped: bf16 or fp8 operands (the f32 parity mode runs vaw_gemm per layer)");
+    const bool f8 = dt == VAW_FP8 || dt == VAW_BF8;
+    const int kt = f8 ? 128 : 64;
+    VAW_CHECK_ARG(n_problems > 0 && problems && desc_dev && K > 0 && K % kt == 0, "wgrad_grouped: bad arguments (K %% %d)", kt);
     bool all192 = true, any_not256 = false;
     for (int i = 0; i < n_problems; ++i) {
         const vaw_wgrad_problem& q = problems[i];
         VAW_CHECK_ARG(q.dy && q.x && q.dw && q.M >= 16 && q.N >= 16 && q.M % 8 == 0 && q.N % 8 == 0, "wgrad_grouped: problem %d: M, N", i);
-        VAW_CHECK_ARG(q.ld_dy >= q.M && q.ld_x >= q.N && q.ld_dw >= q.N && q.ld_dy % 8 == 0 && q.ld_x % 8 == 0 && q.ld_dw % 4 == 0,
-                      "wgrad_grouped: problem %d: leading dimensions", i);
+        if (f8) VAW_CHECK_ARG(q.ld_dy >= K && q.ld_x >= K && q.ld_dw >= q.N && q.ld_dy % 16 == 0 && q.ld_x % 16 == 0 && q.ld_dw % 4 == 0,
+                              "wgrad_grouped: problem %d: leading dimensions (fp8: dy^T [M][K], x^T [N][K])", i);
+        else VAW_CHECK_ARG(q.ld_dy >= q.M && q.ld_x >= q.N && q.ld_dw >= q.N && q.ld_dy % 8 == 0 && q.ld_x % 8 == 0 && q.ld_dw % 4 == 0,
+                           "wgrad_grouped: problem %d: leading dimensions", i);
         VAW_CHECK_ARG((((uintptr_t)q.dy | (uintptr_t)q.x | (uintptr_t)q.dw) & 15) == 0, "wgrad_grouped: problem %d: alignment", i);
         VAW_CHECK_ARG(q.M < (1 << 30) && q.N < (1 << 30), "wgrad_grouped: problem %d too large", i);
         all192 = all192 && q.N % 192 == 0;
@@ -138,6 +144,10 @@ extern "C" int vaw_wgrad_grouped(vaw_dtype dt, int n_problems, const vaw_wgrad_p
         h.a = (const bf16_t*)q.dy; h.b = (const bf16_t*)q.x; h.c = q.dw;
         h.lda = q.ld_dy; h.ldb = q.ld_x; h.ldc = q.ld_dw;
         h.M = (int)q.M; h.N = (int)q.N;
+        h.alpha = q.alpha != 0.f ? q.alpha : 1.f;
+        h.pad_ = 0;
+        h.scale_a = f8 ? q.scale_dy : nullptr;
+        h.scale_b = f8 ? q.scale_x : nullptr;
         h.tiles_n = (int)((q.N + bn - 1) / bn);
         h.tile0 = (int)t_total;
         t_total += ((q.M + 255) / 256) * h.tiles_n;
@@ -148,7 +158,7 @@ extern "C" int vaw_wgrad_grouped(vaw_dtype dt, int n_problems, const vaw_wgrad_p
         const hipError_t rc = hipMemcpyAsync(desc_dev, host.data(), sizeof(P8Prob) * n_problems, hipMemcpyHostToDevice, s);
         VAW_CHECK_ARG(rc == hipSuccess, "wgrad_grouped: descriptor upload failed: %s", hipGetErrorString(rc));
     }
-    const int cus = p8_num_cus(), nk = (int)(K / 64);
+    const int cus = p8_num_cus(), nk = (int)(K / kt);
     P8Group grp{};
     grp.n_prob = n_problems;
     grp.t_full = (int)(t_total / cus) * cus;
@@ -182,7 +192,8 @@ extern "C" int vaw_wgrad_grouped(vaw_dtype dt, int n_problems, const vaw_wgrad_p
         if (dbg < 0) { const char* v = getenv("VAW_GEMM_DEBUG"); dbg = v ? atoi(v) : 0; }
         e.debug = dbg;
     }
-    if (ntw == 4) p8_launch_group<4>(nk, grid, e, (const P8Prob*)desc_dev, grp, s);
+    if (f8) vaw_p8_group_fp8(ntw, dt == VAW_BF8, nk, grid, e, (const P8Prob*)desc_dev, grp, s);
+    else if (ntw == 4) p8_launch_group<4>(nk, grid, e, (const P8Prob*)desc_dev, grp, s);
     else p8_launch_group<3>(nk, grid, e, (const P8Prob*)desc_dev, grp, s);
     if (grp.t_rem > 0) {
         if (ntw == 4) p8_group_fixup_kernel<256><<<grp.t_rem * 8, 256, 0, s>>>((const P8Prob*)desc_dev, grp, beta);

@@ -1,0 +1,189 @@
+// fp8 (OCP e4m3fn) operands for the Linear GEMMs of DiT -- BASELINE.json config 5 ("DiT-XL/2, fp8 MFMA GEMMs + bf16 accum";
+// reference recipe run.sh:20-26, model models/dit.py:373).
+//
+//   vaw_fp8_quantize   per-tensor scaling: q = e4m3(x * 448 / amax(|x|)), written row-major AND (optionally) transposed, with the
+//                      dequantisation scale amax / 448 left in device memory (nothing syncs with the host).  The transposed copy is
+//                      what lets every GEMM of the step run k-major x k-major: dgrad reads W^T, wgrad reads dy^T and x^T.
+//   vaw_gemm_fp8       C = epilogue(alpha * scale_a * scale_b * A[M,K] . B[N,K]^T) on the persistent kernel of gemm_p8_kernel.h with
+//                      v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales): twice the bf16 MFMA rate, half the staged bytes.  Same
+//                      epilogues (bias / GELU / GELU' / gated residual / column sums), f32 accumulation, bf16 or f32 output.
+//   (vaw_wgrad_grouped with dt = VAW_FP8 runs the deferred weight gradients on the transposed copies.)
+#include "gemm_p8_kernel.h"
+
+struct P8Plan {
+    bool use;
+    int ntw, split, grid;
+};
+P8Plan vaw_p8_plan(int64_t M, int64_t N, int64_t K, bool plain_f32, bool want_colsum, int64_t ws_floats, int force);
+extern "C" int vaw_reduce_rows(const float* partial, int64_t R, int64_t N, float* out, float beta, vaw_stream stream);
+
+// a_e5m2: the dy operand is e5m2 (vaw_wgrad_grouped with dt = VAW_BF8); x is e4m3 either way
+void vaw_p8_group_fp8(int ntw, bool a_e5m2, int nk, int grid, const EpiDev& e, const P8Prob* probs_dev, const P8Group& grp, hipStream_t s) {
+    if (a_e5m2) {
+        if (ntw == 4) p8_launch_group<4, 2>(nk, grid, e, probs_dev, grp, s);
+        else p8_launch_group<3, 2>(nk, grid, e, probs_dev, grp, s);
+    } else {
+        if (ntw == 4) p8_launch_group<4, 1>(nk, grid, e, probs_dev, grp, s);
+        else p8_launch_group<3, 1>(nk, grid, e, probs_dev, grp, s);
+    }
+}
+
+// ---- quantisation ---------------------------------------------------------------------------------------------------
+// |x| maxima: max is exact and order-independent, so per-workgroup partials folded by a second launch are deterministic.
+template <typename T>
+__global__ void fp8_amax_partial_kernel(const T* __restrict__ x, int64_t R, int64_t C, int64_t ld, float* __restrict__ part) {
+    float m = 0.f;
+    const int64_t n4 = R * (C / 4), c4n = C / 4;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 v = load4(x + (i / c4n) * ld + (i % c4n) * 4);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    __shared__ float sh[4];
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+__global__ void fp8_amax_final_kernel(const float* __restrict__ part, int n, float* __restrict__ scale, float fmt_max) {
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += 64) m = fmaxf(m, part[i]);
+    m = wave_max(m);
+    if (threadIdx.x == 0) scale[0] = m > 0.f ? m / fmt_max : 1.f;    // dequantisation scale; fmt_max = largest finite value of the format
+}
+
+template <bool E5M2>
+__device__ __forceinline__ unsigned fp8_pack4(f32x4 v) {
+    unsigned r = 0;
+    if (E5M2) {
+        r = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], r, false);   // v_cvt_pk_bf8_f32: OCP e5m2 on gfx950, round to nearest even
+        r = __builtin_amdgcn_cvt_pk_bf8_f32(v[2], v[3], r, true);
+    } else {
+        r = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], r, false);   // v_cvt_pk_fp8_f32: OCP e4m3fn
+        r = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], r, true);
+    }
+    return r;
+}
+
+// One 64 x 64 tile per workgroup: q rows straight out (coalesced 4-byte stores), the transposed copy through LDS.
+template <typename T, bool E5M2>
+__global__ void fp8_quantize_kernel(const T* __restrict__ x, int64_t R, int64_t C, int64_t ld, unsigned char* __restrict__ q, int64_t ldq,
+                                    unsigned char* __restrict__ qt, int64_t ldt, const float* __restrict__ scale) {
+    __shared__ unsigned char tile[64][68];
+    const float inv = 1.f / scale[0];
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+    const int tr = threadIdx.x >> 4, tc = (threadIdx.x & 15) * 4;              // 16 rows x 16 groups of 4 columns per pass
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int r = pass * 16 + tr;
+        unsigned w = 0;
+        if (r0 + r < R && c0 + tc < C) {                                       // C % 4 == 0: a group of 4 is in or out as a whole
+            w = fp8_pack4<E5M2>(load4(x + (r0 + r) * ld + c0 + tc) * inv);
+            *reinterpret_cast<unsigned*>(q + (r0 + r) * ldq + c0 + tc) = w;
+        }
+        if (qt) *reinterpret_cast<unsigned*>(&tile[r][tc]) = w;
+    }
+    if (!qt) return;
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {                                     // out row = input column
+        const int c = pass * 16 + tr;
+        if (c0 + c < C && r0 + tc < R) {
+            const unsigned w = (unsigned)tile[tc][c] | ((unsigned)tile[tc + 1][c] << 8) | ((unsigned)tile[tc + 2][c] << 16) |
+                               ((unsigned)tile[tc + 3][c] << 24);
+            if (r0 + tc + 3 < R) *reinterpret_cast<unsigned*>(qt + (c0 + c) * ldt + r0 + tc) = w;
+            else
+                for (int j = 0; j < 4 && r0 + tc + j < R; ++j) qt[(c0 + c) * ldt + r0 + tc + j] = tile[tc + j][c];
+        }
+    }
+}
+
+extern "C" int64_t vaw_fp8_quantize_workspace_floats(void) { return 1024; }
+
+extern "C" int vaw_fp8_quantize(vaw_dtype src_dt, vaw_dtype dst_format, const void* src, int64_t R, int64_t C, int64_t ld, void* q,
+                                int64_t ldq, void* qt, int64_t ldt, float* scale_out, float* workspace, int64_t workspace_floats,
+                                vaw_stream stream) {
+    VAW_CHECK_ARG(src && q && scale_out && R > 0 && C > 0 && C % 4 == 0 && ld >= C && ld % 4 == 0 && ldq >= C && ldq % 4 == 0,
+                  "fp8_quantize: sizes (C, ld, ldq multiples of 4)");
+    VAW_CHECK_ARG(!qt || (ldt >= R && ldt % 4 == 0), "fp8_quantize: transposed copy needs ldt >= R, ldt %% 4 == 0");
+    VAW_CHECK_ARG(src_dt == VAW_F32 || src_dt == VAW_BF16, "fp8_quantize: source must be f32 or bf16");
+    VAW_CHECK_ARG(dst_format == VAW_FP8 || dst_format == VAW_BF8, "fp8_quantize: destination format VAW_FP8 (e4m3) or VAW_BF8 (e5m2)");
+    VAW_CHECK_ARG(workspace && workspace_floats >= 1024, "fp8_quantize: workspace of vaw_fp8_quantize_workspace_floats() floats");
+    VAW_CHECK_ARG(((uintptr_t)src & (src_dt == VAW_F32 ? 15 : 7)) == 0 && (((uintptr_t)q | (uintptr_t)qt) & 3) == 0, "fp8_quantize: alignment");
+    hipStream_t s = (hipStream_t)stream;
+    int64_t nb = (R * (C / 4) + 1023) / 1024;
+    if (nb > 1024) nb = 1024;
+    dim3 grid((unsigned)((C + 63) / 64), (unsigned)((R + 63) / 64));
+    const bool e5 = dst_format == VAW_BF8;
+    const float fmt_max = e5 ? 57344.f : 448.f;
+    unsigned char *qp = (unsigned char*)q, *qtp = (unsigned char*)qt;
+#define QUANT_GO(T, E5)                                                                                          \
+    do {                                                                                                         \
+        fp8_amax_partial_kernel<T><<<(int)nb, 256, 0, s>>>((const T*)src, R, C, ld, workspace);                  \
+        fp8_amax_final_kernel<<<1, 64, 0, s>>>(workspace, (int)nb, scale_out, fmt_max);                          \
+        fp8_quantize_kernel<T, E5><<<grid, 256, 0, s>>>((const T*)src, R, C, ld, qp, ldq, qtp, ldt, scale_out);  \
+    } while (0)
+    if (src_dt == VAW_F32) { if (e5) QUANT_GO(float, true); else QUANT_GO(float, false); }
+    else { if (e5) QUANT_GO(bf16_t, true); else QUANT_GO(bf16_t, false); }
+    VAW_CHECK_LAUNCH("fp8_quantize");
+    return VAW_OK;
+}
+
+// ---- GEMM ---------------------------------------------------------------------------------------------------------------
+extern "C" int vaw_gemm_fp8(vaw_dtype a_format, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const float* scale_a, const void* B, int64_t ldb,
+                            const float* scale_b, void* C, int64_t ldc, const vaw_epilogue* ep, float* workspace, int64_t workspace_floats,
+                            vaw_stream stream) {
+    VAW_CHECK_ARG(a_format == VAW_FP8 || a_format == VAW_BF8, "gemm_fp8: a_format VAW_FP8 (e4m3) or VAW_BF8 (e5m2)");
+    VAW_CHECK_ARG(M >= 16 && N >= 16 && K > 0 && K % 128 == 0 && A && B && C, "gemm_fp8: sizes (K %% 128 == 0)");
+    VAW_CHECK_ARG(lda >= K && ldb >= K && ldc >= N && lda % 16 == 0 && ldb % 16 == 0 && N % 8 == 0 && ldc % 8 == 0, "gemm_fp8: leading dimensions");
+    VAW_CHECK_ARG((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) == 0, "gemm_fp8: 16-byte alignment");
+    EpiDev e{};
+    e.alpha = 1.f;
+    if (ep) {
+        e.bias = ep->bias; e.act = ep->act; e.aux_in = ep->aux_in; e.aux_out = ep->aux_out; e.gate = ep->gate;
+        e.gate_ld = ep->gate_ld; e.resid = ep->resid; e.rowadd = ep->rowadd; e.rpb = ep->rows_per_batch;
+        e.alpha = ep->alpha; e.beta = ep->beta; e.out_f32 = ep->out_f32; e.resid_act = ep->resid_is_act;
+    }
+    VAW_CHECK_ARG(!(ep && ep->rowsum_a_out), "gemm_fp8: rowsum_a_out is not offered (take bias gradients from the bf16 tensors)");
+    VAW_CHECK_ARG(e.act >= 0 && e.act <= 2 && (e.act != 2 || e.aux_in), "gemm_fp8: act");
+    VAW_CHECK_ARG(!(e.gate || e.rowadd) || e.rpb > 0, "gemm_fp8: gate/rowadd need rows_per_batch");
+    VAW_CHECK_ARG(!(e.act == 2 && e.gate) && !(e.resid && e.rowadd), "gemm_fp8: epilogue combination not offered");
+    if (e.rpb <= 0) e.rpb = 1;
+    float* colsum_out = ep ? ep->colsum_out : nullptr;
+    VAW_CHECK_ARG(!colsum_out || (workspace && workspace_floats >= ((M + 127) / 128) * N), "gemm_fp8: colsum_out needs a workspace");
+    e.M = M; e.N = N; e.ldc = ldc; e.C = C; e.slab = workspace; e.nt_off = 1;
+    e.scale_a = scale_a; e.scale_b = scale_b;
+    e.colpart = colsum_out ? workspace : nullptr;
+    // plan in units of the kernel's K tiles: 128 fp8 elements = one K tile = what 64 bf16 elements are to vaw_p8_plan
+    // (plain_f32 = false: no K split -- the long-K launches of the step are the weight gradients, served by vaw_wgrad_grouped)
+    const P8Plan pl = vaw_p8_plan(M, N, K / 2, false, colsum_out != nullptr, workspace_floats, 1);
+    hipStream_t s = (hipStream_t)stream;
+    const int bn = 64 * pl.ntw, tiles_m = (int)((M + 255) / 256), tiles_n = (int)((N + bn - 1) / bn), nk = (int)(K / 128);
+    int epi;
+    const bool bf16_out = !e.out_f32;
+    if (e.act == 1 && e.aux_out && !e.gate && !e.resid && !e.rowadd && bf16_out && !e.colpart) epi = P8_GELU;
+    else if (e.act == 2 && !e.bias && !e.aux_out && !e.gate && !e.resid && !e.rowadd && bf16_out) epi = P8_DGELU;
+    else if (e.act == 0 && e.gate && e.resid && !e.resid_act && e.aux_out && !e.rowadd && e.out_f32 && e.beta == 0.f && !e.colpart) epi = P8_GATE;
+    else if (e.act == 0 && !e.aux_out && !e.gate && !e.resid && !e.rowadd && e.beta == 0.f) epi = P8_STORE;
+    else {
+        vaw_set_error("gemm_fp8: this epilogue combination has no fp8 kernel");
+        return VAW_ERR_UNSUPPORTED;
+    }
+    // instantiated: what the training step launches -- forward kinds with e4m3 activations, input-gradient kinds with e5m2 or
+    // e4m3 gradients
+#define F8_GO(EPIv, FMT)                                                                                                         \
+    do {                                                                                                                         \
+        if (pl.ntw == 4) p8_launch_fp8_one<4, EPIv, FMT>(A, lda, B, ldb, nk, tiles_m, tiles_n, pl.split, pl.grid, e, s);          \
+        else p8_launch_fp8_one<3, EPIv, FMT>(A, lda, B, ldb, nk, tiles_m, tiles_n, pl.split, pl.grid, e, s);                      \
+    } while (0)
+    const bool e5 = a_format == VAW_BF8;
+    if (epi == P8_STORE) { if (e5) F8_GO(P8_STORE, 2); else F8_GO(P8_STORE, 1); }
+    else if (epi == P8_DGELU) { if (e5) F8_GO(P8_DGELU, 2); else F8_GO(P8_DGELU, 1); }
+    else if (e5) {
+        vaw_set_error("gemm_fp8: the forward epilogues (GELU, gated residual) take e4m3 activations");
+        return VAW_ERR_UNSUPPORTED;
+    } else if (epi == P8_GELU) F8_GO(P8_GELU, 1);
+    else F8_GO(P8_GATE, 1);
+    VAW_CHECK_LAUNCH("gemm_fp8");
+    if (colsum_out) return vaw_reduce_rows(workspace, (M + 127) / 128, N, colsum_out, ep->colsum_beta, stream);
+    return VAW_OK;
+}

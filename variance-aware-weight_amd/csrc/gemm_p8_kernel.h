@@ -63,6 +63,14 @@ __device__ __forceinline__ void p8_dma16(__amdgpu_buffer_rsrc_t rs, char* lds_ds
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)lds_dst, 16, voff, soff, 0, 0);
 }
 
+typedef int i32x8_t __attribute__((ext_vector_type(8)));
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+// two 16-byte fragment reads -> the 32-byte operand of the fp8 MFMA (k = 32 (l >> 4) + 0..31 of row l & 15)
+__device__ __forceinline__ i32x8_t p8_cat(bf16x8 lo, bf16x8 hi) {
+    const i32x4_t a = __builtin_bit_cast(i32x4_t, lo), b = __builtin_bit_cast(i32x4_t, hi);
+    return i32x8_t{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+
 template <int NTW> struct P8Cfg {
     static constexpr int BN = 64 * NTW;              // 4 waves x NTW MFMA tiles of 16 columns
     static constexpr int WN = 16 * NTW;
@@ -73,21 +81,26 @@ template <int NTW> struct P8Cfg {
 
 __device__ __forceinline__ int p8_mn_swz(int k) { return (((k >> 1) & 1) | (((k >> 3) & 1) << 1)) << 1; }
 
-// Per-lane element offset (from the tile's first element at the current K position) of the 16 bytes this lane's
-// LDS-DMA piece `wid` of part `p` fetches.  is_a: the A-part row set (two 32-row runs 128 apart), else 64 p + row.
-template <bool KMAJOR>
-__device__ __forceinline__ int p8_src_off(bool is_a, int p, int wid, int lane, int64_t ld, int valid) {
+// Per-lane BYTE offset (from the tile's first element at the current K position) of the 16 bytes this lane's LDS-DMA piece
+// `wid` of part `p` fetches.  is_a: the A-part row set (two 32-row runs 128 apart), else 64 p + row.  ES = bytes per element.
+// F8 (1-byte elements, a K tile = 128 of them = the same 128-byte rows): the scaled fp8 MFMA 16x16x128 wants 32 consecutive k
+// per lane, k = 32 (l >> 4) + j, where the bf16 one wants two 16-byte pieces k = 16 (l >> 4) .. and 64 + 16 (l >> 4) ..; with the
+// row's 16-byte chunks laid down in the order 0,2,4,6,1,3,5,7 the two fragment reads of the bf16 kernel (chunks g and 4 + g)
+// return exactly bytes [32 g, 32 g + 16) and [32 g + 16, 32 g + 32): same LDS image, same reads, same swizzle.
+template <bool KMAJOR, int ES = 2, bool F8 = false>
+__device__ __forceinline__ unsigned p8_src_off(bool is_a, int p, int wid, int lane, int64_t ld, int valid) {
     const int r = 8 * wid + (lane >> 3);          // row (k-major) or k (mn-major) within the part
     if (KMAJOR) {
-        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+        int chunk = (lane & 7) ^ ((r >> 1) & 7);  // position of the chunk in the LDS row
+        if (F8) chunk = chunk < 4 ? 2 * chunk : 2 * (chunk - 4) + 1;     // ... and the 16 source bytes that belong there
         int R = is_a ? (r < 32 ? 32 * p + r : 96 + 32 * p + r) : 64 * p + r;
         R = R < valid ? R : valid - 1;            // LDS-DMA cannot zero-fill: rows beyond the edge mirror a valid row
-        return (int)(R * ld) + chunk * 8;
+        return (unsigned)(R * ld * ES) + chunk * 16;
     } else {
         const int chunk = (lane & 7) ^ p8_mn_swz(r);
         int col = is_a ? (chunk < 4 ? 32 * p + 8 * chunk : 96 + 32 * p + 8 * chunk) : 64 * p + 8 * chunk;
         col = col < valid ? col : 0;
-        return (int)(r * ld) + col;
+        return (unsigned)((r * ld + col) * ES);
     }
 }
 
@@ -127,6 +140,9 @@ struct P8Prob {
     float* c;               // dW  [M][N] f32
     int64_t lda, ldb, ldc;
     int M, N, tiles_n, tile0;   // tile0: index of this problem's first tile in the launch's tile list
+    float alpha;                // scales the accumulator
+    int pad_;
+    const float *scale_a, *scale_b;   // fp8 operands: device scalars (per-tensor dequantisation scales) multiplied into alpha, or NULL
 };
 struct P8Group {
     int n_prob, t_full, t_rem, n_split;   // items: tiles [0, t_full) whole; tiles [t_full, t_full + t_rem) in n_split K ranges
@@ -139,12 +155,15 @@ struct P8Item {
     int M, N, kt0, nk, split, prob, tm, rem;   // split < 0: whole tile (GRP); rem: index among the K-split tiles (GRP)
 };
 
-template <bool AK, bool BKM, int NTW, int EPI, bool GRP = false, int CONV = 0>
+template <bool AK, bool BKM, int NTW, int EPI, bool GRP = false, int CONV = 0, int F8 = 0>   // F8: 0 bf16 | 1 e4m3 x e4m3 | 2 A e5m2, B e4m3
 __global__ void __launch_bounds__(512, 2)
 gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb, int nk_total,
                int tiles_m, int tiles_n, int n_split, EpiDev e, int team_delay, const P8Prob* __restrict__ probs = nullptr,
                P8Group grp = P8Group{}, P8Conv cg = P8Conv{}) {
     static_assert(CONV == 0 || !GRP, "grouped launches are plain GEMMs");
+    static_assert(!F8 || (AK && BKM && CONV == 0), "fp8 operands: both k-major (the callers keep transposed fp8 copies)");
+    constexpr int ES = F8 ? 1 : 2;                 // bytes per operand element
+    constexpr int KT = F8 ? 128 : 64;              // operand elements per K tile (128 bytes of a k-major row either way)
     static_assert(CONV == 0 || (CONV == 1 && AK && BKM) || (CONV == 2 && AK && !BKM) || (CONV == 3 && !AK && !BKM), "conv layouts");
     using Cfg = P8Cfg<NTW>;
     constexpr int LS = 4 + NTW;                                  // DMA pieces per wave and K tile
@@ -223,15 +242,15 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
         iss_kt = 0;
         const int mvalid = t.M - t.m0 < P8_BM ? (int)(t.M - t.m0) : P8_BM;
         const int nvalid = t.N - t.n0 < Cfg::BN ? (int)(t.N - t.n0) : Cfg::BN;
-        const int64_t a_el = AK ? 64 : 64 * t.lda, b_el = BKM ? 64 : 64 * t.ldb;      // elements per K tile
-        step_a = (unsigned)(a_el * 2);
-        step_b = (unsigned)(b_el * 2);
+        const int64_t a_el = AK ? KT : KT * t.lda, b_el = BKM ? KT : KT * t.ldb;      // elements per K tile
+        step_a = (unsigned)(a_el * ES);
+        step_b = (unsigned)(b_el * ES);
         so_a = so_b = 0;
         if (CONV == 0) {
-            rs_a = epi_rsrc((AK ? t.a + t.m0 * t.lda : t.a + t.m0) + t.kt0 * a_el);
-            rs_b = epi_rsrc((BKM ? t.b + t.n0 * t.ldb : t.b + t.n0) + t.kt0 * b_el);
+            rs_a = epi_rsrc((const char*)t.a + ((AK ? t.m0 * t.lda : t.m0) + t.kt0 * a_el) * ES);
+            rs_b = epi_rsrc((const char*)t.b + ((BKM ? t.n0 * t.ldb : t.n0) + t.kt0 * b_el) * ES);
 #pragma unroll
-            for (int p = 0; p < 4; ++p) off_a[p] = 2u * (unsigned)p8_src_off<AK>(true, p, wid, lane, t.lda, mvalid);
+            for (int p = 0; p < 4; ++p) off_a[p] = p8_src_off<AK, ES, F8 != 0>(true, p, wid, lane, t.lda, mvalid);
         } else if (CONV == 1 || CONV == 2) {
             const int r = 8 * wid + (lane >> 3), chunk = (lane & 7) ^ ((r >> 1) & 7);
 #pragma unroll
@@ -273,7 +292,7 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
             step_a = (unsigned)(64 * cg.Ci * 2);
         }
 #pragma unroll
-        for (int p = 0; p < NTW; ++p) off_b[p] = 2u * (unsigned)p8_src_off<BKM>(false, p, wid, lane, t.ldb, nvalid);
+        for (int p = 0; p < NTW; ++p) off_b[p] = p8_src_off<BKM, ES, F8 != 0>(false, p, wid, lane, t.ldb, nvalid);
     };
     if (!iss_done) iss_open();
     // piece c of the stream order [B parts 0..NTW-1, A parts 0..3]
@@ -359,9 +378,15 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
         const int64_t m0 = item.m0, n0 = item.n0;
         // per-item view of the epilogue descriptor: in grouped mode the output tensor changes from item to item
         EpiDev ei = e;
+        if (F8) { /* scales folded in below, once the item's descriptor is final */ }
         if (GRP) {
             const P8Prob& pr = probs[item.prob];
-            ei.C = pr.c; ei.ldc = pr.ldc; ei.M = pr.M; ei.N = pr.N;
+            ei.C = pr.c; ei.ldc = pr.ldc; ei.M = pr.M; ei.N = pr.N; ei.alpha = pr.alpha;
+            ei.scale_a = pr.scale_a; ei.scale_b = pr.scale_b;
+        }
+        if (F8) {
+            if (ei.scale_a) ei.alpha *= *ei.scale_a;
+            if (ei.scale_b) ei.alpha *= *ei.scale_b;
         }
         f32x4 acc[8][NTW];
 #pragma unroll
@@ -396,11 +421,26 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
             __builtin_amdgcn_sched_barrier(0);                                                                        \
         }                                                                                                             \
         __builtin_amdgcn_s_setprio(1);                                                                                \
-        _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                                 \
+        if (F8) {   /* one scaled fp8 MFMA (K = 128, unit block scales) where the bf16 kernel issues two of K = 32 */   \
             _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                             \
                 _Pragma("unroll") for (int u = 0; u < NTW; ++u)                                                       \
-                    acc[2 * (j) + t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[s][u], af[s][t], acc[2 * (j) + t][u], 0, 0, 0); \
+                    /* the MFMA's first matrix is our B tile (cbsz: e4m3), its second our A tile (blgp: 0 e4m3 | 1 e5m2) */ \
+                    acc[2 * (j) + t][u] = F8 == 2 ? __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                  \
+                        p8_cat(bfr[0][u], bfr[1][u]), p8_cat(af[0][t], af[1][t]), acc[2 * (j) + t][u], 0, 1, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F) \
+                                                  : __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                  \
+                        p8_cat(bfr[0][u], bfr[1][u]), p8_cat(af[0][t], af[1][t]), acc[2 * (j) + t][u], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F); \
+        } else {                                                                                                      \
+            _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                             \
+                _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                         \
+                    _Pragma("unroll") for (int u = 0; u < NTW; ++u)                                                   \
+                        acc[2 * (j) + t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[s][u], af[s][t], acc[2 * (j) + t][u], 0, 0, 0); \
+        }                                                                                                             \
         __builtin_amdgcn_s_setprio(0);                                                                                \
+        if (F8) {   /* pin the results here: the accumulators are only read after the loop, and LLVM's code sinking   \
+                       otherwise moves all four phases' MFMAs (pure register ops) into the loop's last block */       \
+            _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                             \
+                _Pragma("unroll") for (int u = 0; u < NTW; ++u) asm volatile("" : "+v"(acc[2 * (j) + t][u]));        \
+        }                                                                                                             \
     } while (0)
             // ---- phase 1: B fragments of the whole K tile + A quarter 0
 #pragma unroll
@@ -602,6 +642,19 @@ static void p8_launch_conv(const bf16_t* a, int64_t lda, const bf16_t* b, int64_
     gemm_p8_kernel<AK, BKM, NTW, EPI, false, CONV><<<grid, 512, lds, s>>>(a, lda, b, ldb, nk, tiles_m, tiles_n, split, e, 0, nullptr, P8Group{}, cg);
 }
 
+template <int NTW, int EPI, int F8>
+static void p8_launch_fp8_one(const void* a, int64_t lda, const void* b, int64_t ldb, int nk, int tiles_m, int tiles_n, int split, int grid,
+                              const EpiDev& e, hipStream_t s) {
+    static bool attr_done = false;
+    const int lds = P8Cfg<NTW>::lds_bytes;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)gemm_p8_kernel<true, true, NTW, EPI, false, 0, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_done = true;
+    }
+    gemm_p8_kernel<true, true, NTW, EPI, false, 0, F8><<<grid, 512, lds, s>>>((const bf16_t*)a, lda, (const bf16_t*)b, ldb, nk, tiles_m, tiles_n,
+                                                                               split, e, 0, nullptr, P8Group{}, P8Conv{});
+}
+
 template <bool AK, bool BKM, int NTW, int EPI>
 static void p8_launch_one(const bf16_t* a, int64_t lda, const bf16_t* b, int64_t ldb, int nk, int tiles_m, int tiles_n, int split,
                           int grid, const EpiDev& e, hipStream_t s, int team_delay) {
@@ -614,15 +667,16 @@ static void p8_launch_one(const bf16_t* a, int64_t lda, const bf16_t* b, int64_t
     gemm_p8_kernel<AK, BKM, NTW, EPI, false, 0><<<grid, 512, lds, s>>>(a, lda, b, ldb, nk, tiles_m, tiles_n, split, e, team_delay);
 }
 
-template <int NTW>
+template <int NTW, int F8 = 0>
 static void p8_launch_group(int nk, int grid, const EpiDev& e, const P8Prob* probs_dev, const P8Group& grp, hipStream_t s) {
+    // bf16: dy and x as stored ([K][M], [K][N]: both mn-major); fp8: the callers' transposed copies ([M][K], [N][K]: both k-major)
     static bool attr_done = false;
     const int lds = P8Cfg<NTW>::lds_bytes;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gemm_p8_kernel<false, false, NTW, P8_WGRAD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm_p8_kernel<F8 != 0, F8 != 0, NTW, P8_WGRAD, true, 0, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
-    gemm_p8_kernel<false, false, NTW, P8_WGRAD, true><<<grid, 512, lds, s>>>(nullptr, 0, nullptr, 0, nk, 0, 0, 1, e, 0, probs_dev, grp);
+    gemm_p8_kernel<F8 != 0, F8 != 0, NTW, P8_WGRAD, true, 0, F8><<<grid, 512, lds, s>>>(nullptr, 0, nullptr, 0, nk, 0, 0, 1, e, 0, probs_dev, grp, P8Conv{});
 }
 
 // C_tile = beta * C_tile + sum_s slab[s][r] (fixed order) for the K-split tiles r of a grouped launch: one workgroup per
@@ -644,6 +698,7 @@ __global__ void p8_group_fixup_kernel(const P8Prob* __restrict__ probs, P8Group 
         for (int sp = 0; sp < grp.n_split; ++sp)
             acc += load4(grp.slab + ((int64_t)sp * grp.t_rem + r) * (P8_BM * BN) + (int64_t)(32 * band + row) * BN + c4);
         float* c = pr.c + m * pr.ldc + n;
+        acc *= pr.alpha * (pr.scale_a ? *pr.scale_a : 1.f) * (pr.scale_b ? *pr.scale_b : 1.f);
         if (beta != 0.f) acc += beta * load4(c);
         store4(c, acc);
     }

@@ -161,10 +161,75 @@ def gemm(dt, a_kmajor, b_kmajor, M, N, K, A, lda, B, ldb, Cp, ldc, *, bias=None,
         tr.add(L.lib().vaw_gemm_uses_bf16_mfma(dt, M, N, K, A, lda, B, ldb), bool(a_kmajor), bool(b_kmajor), M, N, K, e0, e1)
 
 
+# ---- fp8 operands ------------------------------------------------------------------------------------
+def fp8_quantize(src_dt, src, R, C_, ld, q, qt, scale, fmt=L.FP8, device=None):
+    """Raw-pointer vaw_fp8_quantize: src [R][C] (row stride ld) -> q [R][C] bytes, qt [C][R] bytes (0 = not wanted), scale."""
+    ws = scratch_f32(device or torch.device("cuda", torch.cuda.current_device()), 0)
+    check(L.lib().vaw_fp8_quantize(src_dt, fmt, src, R, C_, ld, q, C_, qt or None, R, scale, ws.data_ptr(), ws.numel(), stream_ptr()),
+          "vaw_fp8_quantize")
+
+
+class Fp8:
+    """An fp8 copy of a 2-D operand: q [R][C] bytes, optionally qt [C][R] (the transposed copy the k-major-only fp8 GEMMs read
+    for the other contraction), and the device scalar `scale` that turns the bytes back into values.  fmt: FP8 (e4m3) | BF8 (e5m2).
+    plain=False keeps only the transposed copy (the row-major bytes go to the buffer `q_scratch` hands out)."""
+
+    def __init__(self, R, C_, device, transposed=True, plain=True, fmt=L.FP8):
+        self.R, self.C, self.fmt, self.device = int(R), int(C_), fmt, device
+        self.q = torch.empty(R, C_, device=device, dtype=torch.uint8) if plain else None
+        self.qt = torch.empty(C_, R, device=device, dtype=torch.uint8) if transposed else None
+        self.scale = torch.ones(1, device=device, dtype=torch.float32)
+
+    def quantize(self, src, ld=None, src_dt=None):
+        """src: f32 / bf16 tensor holding R x C values with row stride ld (default C), or a device address with src_dt."""
+        if isinstance(src, torch.Tensor):
+            need_cuda(src)
+            src_dt, src = dt_of(src), src.data_ptr()
+        q = self.q if self.q is not None else q_scratch(self.R * self.C, self.device)
+        fp8_quantize(src_dt, src, self.R, self.C, ld or self.C, q.data_ptr(), ptr(self.qt), self.scale.data_ptr(), self.fmt, self.device)
+        self.last_q = q.data_ptr()
+        return self
+
+    def dequant(self):
+        return self.q.view(torch.float8_e5m2 if self.fmt == L.BF8 else torch.float8_e4m3fn).float() * self.scale
+
+
+_q_scratch = {}
+
+
+def q_scratch(n, device):
+    """Grow-only byte scratch for row-major fp8 copies that only the very next GEMM reads."""
+    t = _q_scratch.get(device)
+    if t is None or t.numel() < n:
+        t = _q_scratch[device] = torch.empty(n, device=device, dtype=torch.uint8)
+    return t
+
+
+def gemm_fp8(M, N, K, A, lda, scale_a, B, ldb, scale_b, Cp, ldc, *, a_format=L.FP8, bias=None, act=0, aux_in=None, aux_out=None,
+             gate=None, gate_ld=0, resid=None, rows_per_batch=0, alpha=1.0, out_f32=False, colsum_out=None, colsum_beta=0.0):
+    """Raw-pointer fp8 GEMM (vaw_gemm_fp8): A [M][K] bytes of a_format, B [N][K] e4m3 bytes; scale_a / scale_b device scalars."""
+    e = Epilogue(bias or None, act, aux_in or None, aux_out or None, gate or None, gate_ld, resid or None, None, rows_per_batch,
+                 alpha, 0.0, 1 if out_f32 else 0, colsum_out or None, colsum_beta, 0, None, 0.0)
+    tr = gemm_trace
+    if tr is not None:
+        e0, e1 = tr.events()
+        e0.record()
+    ws_ptr, ws_n = 0, 0
+    if colsum_out:
+        ws = scratch_f32(torch.device("cuda", torch.cuda.current_device()), 0)
+        ws_ptr, ws_n = ws.data_ptr(), ws.numel()
+    check(L.lib().vaw_gemm_fp8(a_format, M, N, K, A, lda, scale_a, B, ldb, scale_b, Cp, ldc, C.byref(e), ws_ptr, ws_n, stream_ptr()),
+          "vaw_gemm_fp8")
+    if tr is not None:
+        e1.record()
+        tr.add(2, True, a_format == L.FP8, M, N, K, e0, e1)
+
+
 class WgradProblem(C.Structure):
     """vaw_wgrad_problem of include/vaw_hip.h."""
     _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("M", C.c_int64), ("N", C.c_int64),
-                ("ld_dy", C.c_int64), ("ld_x", C.c_int64), ("ld_dw", C.c_int64)]
+                ("ld_dy", C.c_int64), ("ld_x", C.c_int64), ("ld_dw", C.c_int64), ("alpha", C.c_float), ("pad_", C.c_int),
+                ("scale_dy", C.c_void_p), ("scale_x", C.c_void_p)]
 
 
 class WgradGroup:
@@ -190,7 +255,7 @@ class WgradGroup:
         self.uploaded = True
         if tr is not None:
             e1.record()
-            tr.add_flop(1, False, False, self.flop, e0, e1)
+            tr.add_flop(2 if dt in (L.FP8, L.BF8) else 1, False, False, self.flop, e0, e1)
 
 
 def beta_or_plain(bias, act, aux_out, gate, resid, rowadd):
@@ -250,7 +315,7 @@ class GemmTrace:
         """-> {variant: {launches, flop, ms}} after a device synchronize."""
         out = {}
         for mfma, ak, bk, flop, e0, e1 in self.rows:
-            name = ("bf16_mfma" if mfma else "generic_f32mfma") + ("/fwd" if ak and bk else "/dgrad" if ak else "/wgrad")
+            name = ("fp8_mfma" if mfma == 2 else "bf16_mfma" if mfma else "generic_f32mfma") + ("/fwd" if ak and bk else "/dgrad" if ak else "/wgrad")
             d = out.setdefault(name, {"launches": 0, "flop": 0.0, "ms": 0.0})
             d["launches"] += 1
             d["flop"] += flop
