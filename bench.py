@@ -38,6 +38,10 @@ WORKLOADS = {
     "dit_b2": dict(kind="dit", model="DiT-B", patch=2, batch=256, gflop_per_img=138.0, desc="DiT-B/2, 4x32x32 latents, 1000 classes"),
     "dit_xl2": dict(kind="dit", model="DiT-XL", patch=2, batch=128, gflop_per_img=711.7,
                     desc="DiT-XL/2, 4x32x32 latents, 1000 classes (BASELINE config 5 at its per-GPU batch 1024/8; bf16, not fp8)"),
+    "dit_xl2_fp8": dict(kind="dit", model="DiT-XL", patch=2, batch=128, gflop_per_img=711.7, fp8=True,
+                        desc="DiT-XL/2, 4x32x32 latents, 1000 classes (BASELINE config 5 at its per-GPU batch 1024/8): the blocks' Linear "
+                             "layers on the scaled fp8 MFMA (e4m3 weights/activations, e5m2 gradients, per-tensor scales, f32 accumulate), "
+                             "attention / norms / embedders in bf16"),
     "dit_s4": dict(kind="dit", model="DiT-S", patch=4, batch=256, gflop_per_img=None, desc="DiT-S/4 (smoke)"),
     "unet32": dict(kind="unet", size=32, classes=0, batch=16, gflop_per_img=9.91,
                    desc="CIFAR-10-shaped UNet (32x32, base 64 ch, mult 1,2,2,2, 10.4 M params), BASELINE config 1"),
@@ -47,6 +51,7 @@ WORKLOADS = {
                   desc="ADM_64 (ImageNet-64, 192 ch, mult 1,2,3,4, attention at 32/16/8, 296 M params), BASELINE config 3"),
 }
 BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md
+FP8_MFMA_PEAK_TFLOPS = 5000.0    # dense fp8 (v_mfma_scale_f32_16x16x128_f8f6f4), same guide
 
 
 def pmc_traffic(workload, batch):
@@ -56,7 +61,7 @@ def pmc_traffic(workload, batch):
     file for the workload / batch being run is used and named in the line ("traffic_source"); (None, None) without one."""
     import glob
     import re
-    pat = os.path.join(REPO, "profiles", f"r*_{workload}_bs{batch}_bf16_hbm_traffic.json")
+    pat = os.path.join(REPO, "profiles", f"r*_{workload}_bs{batch}_*hbm_traffic.json")
     best = None
     for path in glob.glob(pat):
         m = re.match(r"r(\d+)_", os.path.basename(path))
@@ -274,6 +279,8 @@ def main():
     model, ema_model = build(vaw_amd, wl, args, device, rank)
     if a.fp32:
         model.set_compute_dtype("fp32")
+    elif wl.get("fp8"):
+        model.set_compute_dtype("fp8")
     net = vaw_amd.DistributedDataParallel(model, bucket_dtype=a.bucket_dtype) if parallel else model
     opt = vaw_amd.FusedAdamW(model, lr=args.lr, betas=(0.9, 0.95), weight_decay=0.0, eps=1e-8)
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=vaw_amd.get_lr_lambda(args))
@@ -334,7 +341,7 @@ def main():
         ips, ms = main_res["value"], main_res["ms_per_step"]
         rec = {"metric": "training images/sec", "value": ips, "unit": "images/sec", "n_gpus": world,
                "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "median_ms_per_step": main_res["median_ms_per_step"],
-               "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32" if a.fp32 else "bf16",
+               "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32" if a.fp32 else "fp8" if wl.get("fp8") else "bf16",
                "data": "synthetic",
                "config": {"workload": f"{wl['desc']}; Trainer.train_step: q_sample + fwd + lambda-weighted MSE + bwd + "
                                       f"AdamW + EMA; global batch {main_res['global_batch']} = {main_res['per_gpu_batch']} per GPU",
@@ -347,20 +354,25 @@ def main():
             rec["config"]["step_mfma_util_vs_2.5PF"] = round(ips / world * wl["gflop_per_img"] / 1e3 / BF16_MFMA_PEAK_TFLOPS, 4)
         if trace is not None:
             summ = trace.summarize()
-            fast = {k: v for k, v in summ.items() if k.startswith("bf16_mfma")}
+            f8 = bool(wl.get("fp8")) and not a.fp32
+            fast = {k: v for k, v in summ.items() if k.startswith("fp8_mfma" if f8 else "bf16_mfma")}
             if fast:
                 flop = sum(v["flop"] for v in fast.values())
                 t_ms = sum(v["ms"] for v in fast.values())
                 n_l = sum(v["launches"] for v in fast.values())
                 ach = flop / (t_ms * 1e-3) / 1e12
+                peak = FP8_MFMA_PEAK_TFLOPS if f8 else BF16_MFMA_PEAK_TFLOPS
                 traffic, src = (None, None) if a.fp32 else pmc_traffic(a.workload, main_res["per_gpu_batch"])
                 rec["roofline"] = {
-                    "kernel": "bf16 MFMA GEMM family (v_mfma_f32_16x16x32_bf16): gemm_p8_kernel (persistent 256 x 256|192 tiles, "
+                    "kernel": ("fp8 MFMA GEMM family (v_mfma_scale_f32_16x16x128_f8f6f4): gemm_p8_kernel<F8> (persistent 256 x 256|192 "
+                               "tiles, LDS-DMA ring) for the blocks' Linear fwd / dgrad and the grouped weight gradients; the bf16 "
+                               "launches of the step are listed in by_variant") if f8 else
+                              "bf16 MFMA GEMM family (v_mfma_f32_16x16x32_bf16): gemm_p8_kernel (persistent 256 x 256|192 tiles, "
                               "LDS-DMA ring, counted vmcnt) for the large Linear launches, gemm_bf16_kernel (128 x 128) for the rest; "
                               "fwd/dgrad/wgrad variants",
-                    "bound": "mfma", "achieved": round(ach, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
                     "traffic_unit": "HBM bytes per launch (PMC, separate passes)",
-                    "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
+                    "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": src,
                     "launches_per_step": n_l / traced_steps, "avg_launch_us": round(1e3 * t_ms / n_l, 2),
                     "traced_steps": traced_steps, "traced_where": "extra steps after the timed region",
                     "gemm_share_of_step": round(t_ms / traced_steps / ms, 4),

@@ -10,6 +10,11 @@ Data layout in HBM (B images, T tokens, D hidden, M = B*T rows):
   GEMM operands     act dtype [M, *]      bf16 in throughput mode, f32 in parity mode
   adaLN modulation  f32 [B, (6L+2) D]     ONE GEMM for all blocks + final layer; kernels take (ptr, row stride)
   weights           flat f32 master + flat bf16 shadow; all adaLN weights contiguous so that GEMM sees one matrix
+  fp8 mode          (compute_dtype="fp8", BASELINE.json config 5) the four Linear layers of every block run on the scaled fp8
+                    MFMA: activations / weights e4m3, gradients e5m2 (or e4m3), per-tensor scales taken on the device just before
+                    use; every operand is kept k-major, so each tensor that feeds two contractions also has a transposed fp8
+                    copy (W^T for dgrad; x^T, dy^T [*, M] per block for the deferred grouped weight gradients).  Everything else
+                    -- attention, LayerNorm, embedders, final layer, adaLN, optimizer -- is the bf16 mode's.
 """
 import math
 
@@ -127,8 +132,17 @@ class _Workspace:
         self.dDm, self.dqkv, self.dao = e(M, m.Dm), e(M, 3 * D), e(M, D)
         # deferred weight gradients (bf16 mode): every block keeps the four dy operands of its Linear layers until ONE grouped
         # launch at the end of backward consumes them (226 MB per DiT-B/4 block at batch 256; sized for 288 GB of HBM)
-        self.defer = bool(m.defer_wgrad) and adt == torch.bfloat16 and M % 64 == 0
-        if self.defer:
+        self.fp8 = bool(m._fp8)
+        self.defer = (bool(m.defer_wgrad) or self.fp8) and adt == torch.bfloat16 and M % 64 == 0
+        if self.fp8:
+            # per block: the transposed fp8 copies the grouped weight gradients read (x^T and dy^T, [features][M]); the row-major
+            # copies live in a shared scratch just long enough for the GEMM that follows the quantiser
+            gf = L.BF8 if m.fp8_grad_format == "e5m2" else L.FP8
+            F = lambda cols, fmt=L.FP8: ops.Fp8(M, cols, dev, transposed=True, plain=False, fmt=fmt)
+            for b in self.blk:
+                b.update(f_xm=F(D), f_ao=F(D), f_xm2=F(D), f_a=F(m.Dm), f_dy2=F(D, gf), f_dhid=F(m.Dm, gf), f_dy1=F(D, gf),
+                         f_dqkv=F(3 * D, gf))
+        elif self.defer:
             for b in self.blk:
                 b.update(dy2=e(M, D), dDm=e(M, m.Dm), dy1=e(M, D), dqkv=e(M, 3 * D))
         self.wgrad_groups = {}
@@ -186,6 +200,8 @@ class DiT(FlatModule):
         self.Kp = in_channels * patch_size * patch_size
         self.No = patch_size * patch_size * self.out_channels
         self.mod_cols = (6 * depth + 2) * hidden_size
+        self.fp8_grad_format = "e5m2"      # fp8 mode: gradients in e5m2 (range) or "e4m3" (precision); weights / activations e4m3
+        self._fp8_w, self._fp8_epoch = {}, None
         self.set_compute_dtype(compute_dtype)
         self._anchor = torch.zeros(1, requires_grad=True)
         self._ws, self._ws_cur = {}, None
@@ -221,12 +237,17 @@ class DiT(FlatModule):
         nn.init.constant_(self.final_layer.linear.bias, 0)
 
     def set_compute_dtype(self, name):
-        """'bf16' (throughput: bf16 MFMA, f32 accumulate) or 'fp32' (parity with the CPU reference)."""
-        name = {"float32": "fp32", "f32": "fp32", "bfloat16": "bf16"}.get(name, name)
-        if name not in ("bf16", "fp32"):
-            raise ValueError(f"compute_dtype must be 'bf16' or 'fp32', got {name}")
+        """'bf16' (throughput: bf16 MFMA, f32 accumulate), 'fp32' (parity with the CPU reference) or 'fp8' (the blocks' Linear
+        layers on the scaled fp8 MFMA with f32 accumulate, everything else as in 'bf16')."""
+        name = {"float32": "fp32", "f32": "fp32", "bfloat16": "bf16", "float8": "fp8"}.get(name, name)
+        if name not in ("bf16", "fp32", "fp8"):
+            raise ValueError(f"compute_dtype must be 'bf16', 'fp32' or 'fp8', got {name}")
+        if name == "fp8" and (self.D % 128 or self.Dm % 128):
+            raise ValueError("compute_dtype='fp8' needs hidden and MLP widths that are multiples of 128 (one fp8 MFMA K tile)")
         self.compute_dtype = name
-        self._dt = BF16 if name == "bf16" else F32
+        self._dt = F32 if name == "fp32" else BF16
+        self._fp8 = name == "fp8"
+        self._fp8_w, self._fp8_epoch = {}, None
         self._ws = {}
 
     def _flat_groups(self):
@@ -306,11 +327,34 @@ class DiT(FlatModule):
         else:
             self._wbase, self._wsize = self._flat.data_ptr(), 4
         adt = L.TORCH_DTYPE[self._dt]
-        key = (B, adt)
+        if self._fp8:
+            if (B * self.T) % 128:
+                raise L.VawError("compute_dtype='fp8': batch * tokens must be a multiple of 128 (K tile of the weight gradients)")
+            self._refresh_fp8_weights()
+        key = (B, adt, self._fp8)
         if key not in self._ws:
             self._ws[key] = _Workspace(self, B, adt)
         self._ws_cur = self._ws[key]
         return self._ws_cur
+
+    _FP8_LINEARS = (("attn.qkv.", 3, 1), ("attn.proj.", 1, 1), ("mlp.fc1.", 0, 1), ("mlp.fc2.", 1, 0))   # (name, N / D or 0 = Dm, K / D or 0 = Dm)
+
+    def _refresh_fp8_weights(self):
+        """e4m3 copies W [N][K] and W^T [K][N] of the blocks' Linear weights, re-quantised from the f32 masters whenever the
+        weights changed (optimizer step, load_state_dict, broadcast)."""
+        epoch = (self._weights_epoch, self._flat.data_ptr())
+        if self._fp8_epoch == epoch:
+            return
+        dev = self._flat.device
+        for l in range(self.depth):
+            for nm, nf, kf in self._FP8_LINEARS:
+                name = f"blocks.{l}.{nm}weight"
+                N, K = (nf * self.D or self.Dm), (kf * self.D or self.Dm)
+                f = self._fp8_w.get(name)
+                if f is None or f.device != dev:
+                    f = self._fp8_w[name] = ops.Fp8(N, K, dev)
+                f.quantize(self._p32(name), src_dt=F32)
+        self._fp8_epoch = epoch
 
     def _forward_impl(self, x, t, y):
         B, C, H, W = x.shape
@@ -349,20 +393,16 @@ class DiT(FlatModule):
             mo = mod + 4 * (6 * l * D)
             xin, xmid, xout = ptr(ws.xres[2 * l]), ptr(ws.xres[2 * l + 1]), ptr(ws.xres[2 * l + 2])
             ops.ln_modulate_fwd(dt, xin, mo, mo + 4 * D, ld, ptr(b["xm"]), ptr(b["mean1"]), ptr(b["rstd1"]), B, T, D)
-            ops.gemm(dt, 1, 1, M, 3 * D, D, ptr(b["xm"]), D, self._w(pre + "attn.qkv.weight"), D, ptr(b["qkv"]), 3 * D,
-                     bias=self._p32(pre + "attn.qkv.bias"))
+            self._linear_fwd(ws, b, "f_xm", b["xm"], pre + "attn.qkv.", M, 3 * D, D, ptr(b["qkv"]), 3 * D)
             q = ptr(b["qkv"])
             es = self._wsize
             ops.attn_fwd(dt, self._attn_desc(B), q, q + es * D, q + 2 * es * D, ptr(b["ao"]), ptr(b["lse"]))
-            ops.gemm(dt, 1, 1, M, D, D, ptr(b["ao"]), D, self._w(pre + "attn.proj.weight"), D, xmid, D,
-                     bias=self._p32(pre + "attn.proj.bias"), aux_out=ptr(b["y1"]), gate=mo + 4 * 2 * D, gate_ld=ld,
-                     resid=xin, rows_per_batch=T, out_f32=True)
+            self._linear_fwd(ws, b, "f_ao", b["ao"], pre + "attn.proj.", M, D, D, xmid, D, aux_out=ptr(b["y1"]), gate=mo + 4 * 2 * D,
+                             gate_ld=ld, resid=xin, rows_per_batch=T, out_f32=True)
             ops.ln_modulate_fwd(dt, xmid, mo + 4 * 3 * D, mo + 4 * 4 * D, ld, ptr(b["xm2"]), ptr(b["mean2"]), ptr(b["rstd2"]), B, T, D)
-            ops.gemm(dt, 1, 1, M, Dm, D, ptr(b["xm2"]), D, self._w(pre + "mlp.fc1.weight"), D, ptr(b["a"]), Dm,
-                     bias=self._p32(pre + "mlp.fc1.bias"), act=1, aux_out=ptr(b["hpre"]))
-            ops.gemm(dt, 1, 1, M, D, Dm, ptr(b["a"]), Dm, self._w(pre + "mlp.fc2.weight"), Dm, xout, D,
-                     bias=self._p32(pre + "mlp.fc2.bias"), aux_out=ptr(b["y2"]), gate=mo + 4 * 5 * D, gate_ld=ld,
-                     resid=xmid, rows_per_batch=T, out_f32=True)
+            self._linear_fwd(ws, b, "f_xm2", b["xm2"], pre + "mlp.fc1.", M, Dm, D, ptr(b["a"]), Dm, act=1, aux_out=ptr(b["hpre"]))
+            self._linear_fwd(ws, b, "f_a", b["a"], pre + "mlp.fc2.", M, D, Dm, xout, D, aux_out=ptr(b["y2"]), gate=mo + 4 * 5 * D,
+                             gate_ld=ld, resid=xmid, rows_per_batch=T, out_f32=True)
         mo = mod + 4 * (6 * Lyr * D)
         ops.ln_modulate_fwd(dt, ptr(ws.xres[2 * Lyr]), mo, mo + 4 * D, ld, ptr(ws.xf), ptr(ws.meanf), ptr(ws.rstdf), B, T, D)
         ops.gemm(dt, 1, 1, M, self.No, D, ptr(ws.xf), D, self._w("final_layer.linear.weight"), D, ptr(ws.otok), self.No,
@@ -370,6 +410,23 @@ class DiT(FlatModule):
         out = torch.empty(B, self.out_channels, H, W, device=x.device, dtype=torch.float32)
         L.check(lib.vaw_unpatchify(dt, ptr(ws.otok), ptr(out), B, self.out_channels, H, W, self.patch_size, st), "unpatchify")
         return out
+
+    def _linear_fwd(self, ws, b, fkey, x, name, M, N, K, out, ldc, **epi):
+        """y = x W^T + bias with the block's epilogue: bf16 / f32 MFMA GEMM, or (fp8 mode) quantise x (keeping x^T for the weight
+        gradient) and run the e4m3 x e4m3 GEMM."""
+        if not ws.fp8:
+            ops.gemm(self._dt, 1, 1, M, N, K, ptr(x), K, self._w(name + "weight"), K, out, ldc, bias=self._p32(name + "bias"), **epi)
+            return
+        f, w = b[fkey].quantize(x), self._fp8_w[name + "weight"]
+        ops.gemm_fp8(M, N, K, f.last_q, K, ptr(f.scale), ptr(w.q), K, ptr(w.scale), out, ldc, bias=self._p32(name + "bias"), **epi)
+
+    def _linear_dgrad(self, ws, b, fkey, dy, name, M, N, K, out, **epi):
+        """dx[M,K] = dy[M,N] W[N,K] (+ epilogue).  fp8 mode: quantise dy (keeping dy^T for the weight gradient), contract with W^T."""
+        if not ws.fp8:
+            ops.gemm(self._dt, 1, 0, M, K, N, ptr(dy) if isinstance(dy, torch.Tensor) else dy, N, self._w(name + "weight"), K, out, K, **epi)
+            return
+        f, w = b[fkey].quantize(dy, src_dt=BF16), self._fp8_w[name + "weight"]
+        ops.gemm_fp8(M, K, N, f.last_q, N, ptr(f.scale), ptr(w.qt), N, ptr(w.scale), out, K, a_format=f.fmt, **epi)
 
     def _attn_desc(self, B):
         d = getattr(self, "_adesc", None)
@@ -420,6 +477,7 @@ class DiT(FlatModule):
             hook(Lyr + 1)
         es = self._wsize
         defer = ws.defer and dt == BF16
+        fp8 = ws.fp8
         pending = []                      # blocks whose weight gradients wait for the next grouped launch
         group_cut = Lyr // 2 if (hook and Lyr >= 4) else 0      # with a listener: flush once half-way, once at the end
 
@@ -433,11 +491,16 @@ class DiT(FlatModule):
                 probs = []
                 for l in pending:
                     b, pre = ws.blk[l], f"blocks.{l}."
+                    if fp8:     # dy^T [Nw][M] and x^T [Kw][M], with their device scales
+                        for name, fdy, fx, Nw, Kw in ((pre + "mlp.fc2.", b["f_dy2"], b["f_a"], D, Dm), (pre + "mlp.fc1.", b["f_dhid"], b["f_xm2"], Dm, D),
+                                                      (pre + "attn.proj.", b["f_dy1"], b["f_ao"], D, D), (pre + "attn.qkv.", b["f_dqkv"], b["f_xm"], 3 * D, D)):
+                            probs.append((ptr(fdy.qt), ptr(fx.qt), self._g(name + "weight"), Nw, Kw, M, M, Kw, 0.0, 0, ptr(fdy.scale), ptr(fx.scale)))
+                        continue
                     for name, dy, x, Nw, Kw in ((pre + "mlp.fc2.", b["dy2"], b["a"], D, Dm), (pre + "mlp.fc1.", b["dDm"], b["xm2"], Dm, D),
                                                 (pre + "attn.proj.", b["dy1"], b["ao"], D, D), (pre + "attn.qkv.", b["dqkv"], b["xm"], 3 * D, D)):
                         probs.append((ptr(dy), ptr(x), self._g(name + "weight"), Nw, Kw, Nw, Kw, Kw))
                 grp = ws.wgrad_groups[key] = ops.WgradGroup(probs, M, dout.device)
-            grp.launch(dt, beta)
+            grp.launch((L.BF8 if self.fp8_grad_format == "e5m2" else L.FP8) if fp8 else dt, beta)
             if hook:
                 for l in pending:
                     hook(l + 1)
@@ -447,7 +510,7 @@ class DiT(FlatModule):
             b, pre = ws.blk[l], f"blocks.{l}."
             mo, dmo = mod + 4 * (6 * l * D), dmod + 4 * (6 * l * D)
             xin, xmid = ptr(ws.xres[2 * l]), ptr(ws.xres[2 * l + 1])
-            dy2, dhid, dy1, dq = ((ptr(b["dy2"]), ptr(b["dDm"]), ptr(b["dy1"]), ptr(b["dqkv"])) if defer
+            dy2, dhid, dy1, dq = ((ptr(b["dy2"]), ptr(b["dDm"]), ptr(b["dy1"]), ptr(b["dqkv"])) if (defer and not fp8)
                                   else (dD, dDm, dD, ptr(ws.dqkv)))
             # MLP branch
             # bias gradients ride on the kernels that produce dy (per-sample partials / GEMM epilogue): no re-read
@@ -455,11 +518,11 @@ class DiT(FlatModule):
             ops.reduce_rows(colpart, B, D, self._g(pre + "mlp.fc2.bias"), beta)
             if not defer:
                 self._wgrad(dt, pre + "mlp.fc2.", dy2, ptr(b["a"]), D, Dm, M, beta, bias=False)
-            ops.gemm(dt, 1, 0, M, Dm, D, dy2, D, self._w(pre + "mlp.fc2.weight"), Dm, dhid, Dm, act=2, aux_in=ptr(b["hpre"]),
-                     colsum_out=self._g(pre + "mlp.fc1.bias"), colsum_beta=beta)
+            self._linear_dgrad(ws, b, "f_dy2", dy2, pre + "mlp.fc2.", M, D, Dm, dhid, act=2, aux_in=ptr(b["hpre"]),
+                               colsum_out=self._g(pre + "mlp.fc1.bias"), colsum_beta=beta)
             if not defer:
                 self._wgrad(dt, pre + "mlp.fc1.", dhid, ptr(b["xm2"]), Dm, D, M, beta, bias=False)
-            ops.gemm(dt, 1, 0, M, D, Dm, dhid, Dm, self._w(pre + "mlp.fc1.weight"), D, dD, D)
+            self._linear_dgrad(ws, b, "f_dhid", dhid, pre + "mlp.fc1.", M, Dm, D, dD)
             ops.ln_modulate_bwd(dt, dD, xmid, ptr(b["mean2"]), ptr(b["rstd2"]), mo + 4 * 4 * D, ld, dres, dres,
                                 dmo + 4 * 3 * D, dmo + 4 * 4 * D, ld, B, T, D)
             # attention branch
@@ -467,7 +530,7 @@ class DiT(FlatModule):
             ops.reduce_rows(colpart, B, D, self._g(pre + "attn.proj.bias"), beta)
             if not defer:
                 self._wgrad(dt, pre + "attn.proj.", dy1, ptr(b["ao"]), D, D, M, beta, bias=False)
-            ops.gemm(dt, 1, 0, M, D, D, dy1, D, self._w(pre + "attn.proj.weight"), D, ptr(ws.dao), D)
+            self._linear_dgrad(ws, b, "f_dy1", dy1, pre + "attn.proj.", M, D, D, ptr(ws.dao))
             q = ptr(b["qkv"])
             ops.attn_bwd(dt, self._attn_desc(B), q, q + es * D, q + 2 * es * D, ptr(b["ao"]), ptr(ws.dao), ptr(b["lse"]),
                          ptr(ws.delta), dq, dq + es * D, dq + 2 * es * D)
@@ -475,7 +538,7 @@ class DiT(FlatModule):
                 ops.colsum(dt, dq, M, 3 * D, 3 * D, self._g(pre + "attn.qkv.bias"), beta, device=dout.device)
             else:
                 self._wgrad(dt, pre + "attn.qkv.", dq, ptr(b["xm"]), 3 * D, D, M, beta)
-            ops.gemm(dt, 1, 0, M, D, 3 * D, dq, 3 * D, self._w(pre + "attn.qkv.weight"), D, dD, D)
+            self._linear_dgrad(ws, b, "f_dqkv", dq, pre + "attn.qkv.", M, 3 * D, D, dD)
             ops.ln_modulate_bwd(dt, dD, xin, ptr(b["mean1"]), ptr(b["rstd1"]), mo + 4 * D, ld, dres, dres, dmo, dmo + 4 * D,
                                 ld, B, T, D)
             if defer:

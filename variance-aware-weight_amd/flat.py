@@ -83,6 +83,7 @@ class FlatModule(nn.Module):
         self._flat_grad = None
         self._flat_shadow = None
         self._shadow_version = None
+        self._weights_epoch = 0
         self._flat_params = [p for _, p, _ in train]
         self._flat_names = [n for n, _, _ in train]
         self._flat_dirty = False
@@ -111,7 +112,7 @@ class FlatModule(nn.Module):
         import copy
         skip = {"_flat", "_flat_grad", "_flat_shadow", "_flat_params"}
         # per-batch workspaces / tapes / descriptors hold activations of the source model: the copy starts with none
-        fresh = {"_ws": dict, "_ws_cur": lambda: None, "_adesc": lambda: None, "_tape": list}
+        fresh = {"_ws": dict, "_ws_cur": lambda: None, "_adesc": lambda: None, "_tape": list, "_fp8_w": dict, "_fp8_epoch": lambda: None}
         for k, v in self.__dict__.items():
             new.__dict__[k] = None if k in skip else fresh[k]() if k in fresh else copy.deepcopy(v, memo)
         new._flat_dirty = True
@@ -164,9 +165,11 @@ class FlatModule(nn.Module):
         if ver != self._shadow_version:
             ops.cast_bf16(self._flat, self._flat_shadow)
             self._shadow_version = ver
+            self._weights_epoch += 1
         return self._flat_shadow
 
     def mark_shadow_fresh(self):
         """Called by the fused optimizer after it rewrote parameters AND shadow in one pass."""
+        self._weights_epoch += 1          # (other derived copies -- the fp8 weights of dit.py -- follow this counter)
         if self._flat_shadow is not None:
             self._shadow_version = sum(p._version for p in self._flat_params)
