@@ -58,7 +58,10 @@ class Trainer:
         self.scaler = None
         inner = getattr(model, "module", model)
         if hasattr(inner, "set_compute_dtype"):
-            want = "bf16" if args.amp else "fp32"
+            # --amp (main.py:104) selects reduced-precision GEMMs: bf16, or fp8 where the model was built / configured for it
+            # (compute_dtype="fp8" or args.amp_dtype = "fp8", an extension: the reference has bf16 autocast only)
+            low = getattr(args, "amp_dtype", None) or (inner.compute_dtype if inner.compute_dtype in ("bf16", "fp8") else "bf16")
+            want = low if args.amp else "fp32"
             if inner.compute_dtype != want:
                 inner.set_compute_dtype(want)
         if hasattr(inner, "host_dropout_rng"):
