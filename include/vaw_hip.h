@@ -158,6 +158,14 @@ int vaw_wgrad_grouped(vaw_dtype dt, int n_problems, const vaw_wgrad_problem* pro
 int64_t vaw_fp8_quantize_workspace_floats(void);
 int vaw_fp8_quantize(vaw_dtype src_dt, vaw_dtype dst_format, const void* src, int64_t R, int64_t C, int64_t ld, void* q, int64_t ldq,
                      void* qt, int64_t ldt, float* scale_out, float* workspace, int64_t workspace_floats, vaw_stream stream);
+/* Delayed scaling (the step after the first): one pass instead of two.  state = 4 floats {scale in use, running max |src|,
+ * FMAX / margin, unused}: vaw_fp8_quantize_delayed quantises with state[0] as it stands (values beyond its range saturate) and
+ * folds this tensor's max |src| into state[1] (integer atomic max on the bits: order-independent); vaw_fp8_scale_update, once
+ * per step over all n states ([n][4] floats), turns every non-zero state[1] into the next scale state[0] = state[1] / state[2]
+ * and clears it.  GEMMs take &state[0] as their scale pointer. */
+int vaw_fp8_quantize_delayed(vaw_dtype src_dt, vaw_dtype dst_format, const void* src, int64_t R, int64_t C, int64_t ld, void* q,
+                             int64_t ldq, void* qt, int64_t ldt, float* state, vaw_stream stream);
+int vaw_fp8_scale_update(float* states, int64_t n, vaw_stream stream);
 /* C[M,N] = epilogue(alpha * *scale_a * *scale_b * A[M,K] . B[N,K]^T): A bytes of a_format (VAW_FP8 | VAW_BF8), B e4m3 bytes,
  * both k-major (K % 128 == 0, row strides multiples of 16), f32 accumulation on v_mfma_scale_f32_16x16x128_f8f6f4 with unit
  * block scales; C and the epilogue operands as for vaw_gemm with dt = VAW_BF16 (bf16 C / aux, or f32 C with out_f32).

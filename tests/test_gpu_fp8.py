@@ -56,6 +56,33 @@ def test_quantize_bytes_and_transpose(dtype, R, C, fmt):
     assert torch.equal(f3.q.cpu(), (x3 * (torch.tensor(1.0) / s3)).to(E).view(torch.uint8))
 
 
+@pytest.mark.parametrize("fmt", ["e4m3", "e5m2"])
+def test_quantize_delayed_scaling_state(fmt):
+    """vaw_fp8_quantize_delayed + vaw_fp8_scale_update: bytes = cast(clamp(x / scale)) with the scale in the state, the state's
+    running max = max |x| exactly (atomic max on the bits), and the update turns it into scale = amax * margin / FMAX."""
+    code, E, FMAX = FMT[fmt]
+    dev = torch.device(DEV)
+    R, C = 520, 328
+    g = torch.Generator().manual_seed(9)
+    st = ops.fp8_states([code, code], dev, margin=2.0)
+    f = ops.Fp8(R, C, dev, fmt=code, state=st[1])
+    x1 = torch.randn(R, C, generator=g).bfloat16()
+    f.quantize(x1.to(DEV))                                   # first step: just-in-time scale
+    s1 = x1.float().abs().max() / torch.tensor(FMAX)
+    assert float(st[1, 0]) == float(s1) and float(st[1, 1]) == 0.0
+    x2 = (torch.randn(R, C, generator=g) * 3).bfloat16()     # larger than the scale covers: saturates
+    f.quantize(x2.to(DEV), delayed=True)
+    ref = (x2.float() * (torch.tensor(1.0) / s1)).clamp(-FMAX, FMAX).to(E).view(torch.uint8)
+    assert torch.equal(f.q.cpu(), ref) and torch.equal(f.qt.cpu(), ref.t())
+    assert float(st[1, 1]) == float(x2.float().abs().max())
+    ops.fp8_scale_update(st)
+    assert float(st[1, 0]) == float(x2.float().abs().max() / torch.tensor(FMAX / 2.0)) and float(st[1, 1]) == 0.0
+    assert float(st[0, 0]) == 1.0                            # a state nobody quantised with keeps its scale
+    f.quantize(x2.to(DEV), delayed=True)
+    s2 = st[1, 0].cpu()
+    assert torch.equal(f.q.cpu(), (x2.float() * (torch.tensor(1.0) / s2)).to(E).view(torch.uint8))
+
+
 def _int_operands(M, N, K, seed):
     g = torch.Generator().manual_seed(seed)
     A = torch.randint(-4, 5, (M, K), generator=g).float()

@@ -65,25 +65,52 @@ __device__ __forceinline__ unsigned fp8_pack4(f32x4 v) {
 }
 
 // One 64 x 64 tile per workgroup: q rows straight out (coalesced 4-byte stores), the transposed copy through LDS.
+// amax_acc != NULL (delayed scaling): `scale` is the one fixed before this step; values beyond its range saturate, and the
+// tensor's max |x| is folded into *amax_acc with an integer atomic max on the float's bits (non-negative floats order like
+// unsigned integers; max is order-independent, so the result does not depend on scheduling).
 template <typename T, bool E5M2>
 __global__ void fp8_quantize_kernel(const T* __restrict__ x, int64_t R, int64_t C, int64_t ld, unsigned char* __restrict__ q, int64_t ldq,
-                                    unsigned char* __restrict__ qt, int64_t ldt, const float* __restrict__ scale) {
+                                    unsigned char* __restrict__ qt, int64_t ldt, const float* __restrict__ scale, float* __restrict__ amax_acc) {
     __shared__ unsigned char tile[64][68];
+    __shared__ float sh[4];
     const float inv = 1.f / scale[0];
+    const float fmax_ = E5M2 ? 57344.f : 448.f;
     const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
     const int tr = threadIdx.x >> 4, tc = (threadIdx.x & 15) * 4;              // 16 rows x 16 groups of 4 columns per pass
+    float am = 0.f;
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
         const int r = pass * 16 + tr;
         unsigned w = 0;
         if (r0 + r < R && c0 + tc < C) {                                       // C % 4 == 0: a group of 4 is in or out as a whole
-            w = fp8_pack4<E5M2>(load4(x + (r0 + r) * ld + c0 + tc) * inv);
+            f32x4 v = load4(x + (r0 + r) * ld + c0 + tc);
+            if (amax_acc) {
+                am = fmaxf(fmaxf(am, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                v = v * inv;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = __builtin_amdgcn_fmed3f(v[j], -fmax_, fmax_);
+            } else {
+                v = v * inv;
+            }
+            w = fp8_pack4<E5M2>(v);
             *reinterpret_cast<unsigned*>(q + (r0 + r) * ldq + c0 + tc) = w;
         }
         if (qt) *reinterpret_cast<unsigned*>(&tile[r][tc]) = w;
     }
-    if (!qt) return;
+    if (amax_acc) {
+        am = wave_max(am);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = am;
+    }
     __syncthreads();
+    if (amax_acc && threadIdx.x == 0) {
+        const float m = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+        // look first: the running max only grows, so after the first few workgroups almost nobody needs the atomic (tens of
+        // thousands of same-address atomics per tensor cost more than the pass they replace); a stale read only costs a spare atomic
+        unsigned* acc = reinterpret_cast<unsigned*>(amax_acc);
+        const unsigned mb = __float_as_uint(m);
+        if (m > 0.f && !(m != m) && mb > __hip_atomic_load(acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(acc, mb);
+    }
+    if (!qt) return;
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {                                     // out row = input column
         const int c = pass * 16 + tr;
@@ -95,6 +122,16 @@ __global__ void fp8_quantize_kernel(const T* __restrict__ x, int64_t R, int64_t 
                 for (int j = 0; j < 4 && r0 + tc + j < R; ++j) qt[(c0 + c) * ldt + r0 + tc + j] = tile[tc + j][c];
         }
     }
+}
+
+// Delayed scaling, once per step for all tensors: state = {scale in use, running max |x|, FMAX / margin, unused}.
+__global__ void fp8_scale_update_kernel(float* __restrict__ states, int64_t n) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float* st = states + 4 * i;
+    const float m = st[1];
+    if (m > 0.f) st[0] = m / st[2];      // an all-zero (or never quantised) tensor keeps its scale
+    st[1] = 0.f;
 }
 
 extern "C" int64_t vaw_fp8_quantize_workspace_floats(void) { return 1024; }
@@ -120,11 +157,38 @@ extern "C" int vaw_fp8_quantize(vaw_dtype src_dt, vaw_dtype dst_format, const vo
     do {                                                                                                         \
         fp8_amax_partial_kernel<T><<<(int)nb, 256, 0, s>>>((const T*)src, R, C, ld, workspace);                  \
         fp8_amax_final_kernel<<<1, 64, 0, s>>>(workspace, (int)nb, scale_out, fmt_max);                          \
-        fp8_quantize_kernel<T, E5><<<grid, 256, 0, s>>>((const T*)src, R, C, ld, qp, ldq, qtp, ldt, scale_out);  \
+        fp8_quantize_kernel<T, E5><<<grid, 256, 0, s>>>((const T*)src, R, C, ld, qp, ldq, qtp, ldt, scale_out, nullptr);  \
     } while (0)
     if (src_dt == VAW_F32) { if (e5) QUANT_GO(float, true); else QUANT_GO(float, false); }
     else { if (e5) QUANT_GO(bf16_t, true); else QUANT_GO(bf16_t, false); }
     VAW_CHECK_LAUNCH("fp8_quantize");
+    return VAW_OK;
+}
+
+extern "C" int vaw_fp8_quantize_delayed(vaw_dtype src_dt, vaw_dtype dst_format, const void* src, int64_t R, int64_t C, int64_t ld, void* q,
+                                        int64_t ldq, void* qt, int64_t ldt, float* state, vaw_stream stream) {
+    VAW_CHECK_ARG(src && q && state && R > 0 && C > 0 && C % 4 == 0 && ld >= C && ld % 4 == 0 && ldq >= C && ldq % 4 == 0,
+                  "fp8_quantize_delayed: sizes (C, ld, ldq multiples of 4)");
+    VAW_CHECK_ARG(!qt || (ldt >= R && ldt % 4 == 0), "fp8_quantize_delayed: transposed copy needs ldt >= R, ldt %% 4 == 0");
+    VAW_CHECK_ARG(src_dt == VAW_F32 || src_dt == VAW_BF16, "fp8_quantize_delayed: source must be f32 or bf16");
+    VAW_CHECK_ARG(dst_format == VAW_FP8 || dst_format == VAW_BF8, "fp8_quantize_delayed: destination format VAW_FP8 (e4m3) or VAW_BF8 (e5m2)");
+    VAW_CHECK_ARG(((uintptr_t)src & (src_dt == VAW_F32 ? 15 : 7)) == 0 && (((uintptr_t)q | (uintptr_t)qt | (uintptr_t)state) & 3) == 0,
+                  "fp8_quantize_delayed: alignment");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)((C + 63) / 64), (unsigned)((R + 63) / 64));
+    const bool e5 = dst_format == VAW_BF8;
+    unsigned char *qp = (unsigned char*)q, *qtp = (unsigned char*)qt;
+#define QUANT_D(T, E5) fp8_quantize_kernel<T, E5><<<grid, 256, 0, s>>>((const T*)src, R, C, ld, qp, ldq, qtp, ldt, state, state + 1)
+    if (src_dt == VAW_F32) { if (e5) QUANT_D(float, true); else QUANT_D(float, false); }
+    else { if (e5) QUANT_D(bf16_t, true); else QUANT_D(bf16_t, false); }
+    VAW_CHECK_LAUNCH("fp8_quantize_delayed");
+    return VAW_OK;
+}
+
+extern "C" int vaw_fp8_scale_update(float* states, int64_t n, vaw_stream stream) {
+    VAW_CHECK_ARG(states && n > 0 && ((uintptr_t)states & 15) == 0, "fp8_scale_update: states [n][4] floats, 16-byte aligned");
+    fp8_scale_update_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(states, n);
+    VAW_CHECK_LAUNCH("fp8_scale_update");
     return VAW_OK;
 }
 

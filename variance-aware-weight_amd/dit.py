@@ -138,10 +138,14 @@ class _Workspace:
             # per block: the transposed fp8 copies the grouped weight gradients read (x^T and dy^T, [features][M]); the row-major
             # copies live in a shared scratch just long enough for the GEMM that follows the quantiser
             gf = L.BF8 if m.fp8_grad_format == "e5m2" else L.FP8
-            F = lambda cols, fmt=L.FP8: ops.Fp8(M, cols, dev, transposed=True, plain=False, fmt=fmt)
-            for b in self.blk:
-                b.update(f_xm=F(D), f_ao=F(D), f_xm2=F(D), f_a=F(m.Dm), f_dy2=F(D, gf), f_dhid=F(m.Dm, gf), f_dy1=F(D, gf),
-                         f_dqkv=F(3 * D, gf))
+            fmts = [L.FP8] * 4 + [gf] * 4
+            self.fp8_states = ops.fp8_states(fmts * Lyr, dev, m.fp8_margin)     # delayed scaling: one update launch per step
+            self.calib_fwd = self.calib_bwd = False                             # first pass: scales taken just in time
+            self.d_fwd = self.d_bwd = False
+            for l, b in enumerate(self.blk):
+                F = lambda i, cols: ops.Fp8(M, cols, dev, transposed=True, plain=False, fmt=fmts[i], state=self.fp8_states[8 * l + i])
+                b.update(f_xm=F(0, D), f_ao=F(1, D), f_xm2=F(2, D), f_a=F(3, m.Dm), f_dy2=F(4, D), f_dhid=F(5, m.Dm), f_dy1=F(6, D),
+                         f_dqkv=F(7, 3 * D))
         elif self.defer:
             for b in self.blk:
                 b.update(dy2=e(M, D), dDm=e(M, m.Dm), dy1=e(M, D), dqkv=e(M, 3 * D))
@@ -201,7 +205,10 @@ class DiT(FlatModule):
         self.No = patch_size * patch_size * self.out_channels
         self.mod_cols = (6 * depth + 2) * hidden_size
         self.fp8_grad_format = "e5m2"      # fp8 mode: gradients in e5m2 (range) or "e4m3" (precision); weights / activations e4m3
-        self._fp8_w, self._fp8_epoch = {}, None
+        # fp8 scales: "delayed" = each tensor's scale comes from its max |x| of the previous step (x margin), taken by the
+        # quantiser itself -- one pass per tensor; the first step, and "jit" always, measure the tensor first (two passes)
+        self.fp8_scaling, self.fp8_margin = "delayed", 2.0
+        self._fp8_w, self._fp8_epoch, self._fp8_wstates = {}, None, None
         self.set_compute_dtype(compute_dtype)
         self._anchor = torch.zeros(1, requires_grad=True)
         self._ws, self._ws_cur = {}, None
@@ -247,7 +254,7 @@ class DiT(FlatModule):
         self.compute_dtype = name
         self._dt = F32 if name == "fp32" else BF16
         self._fp8 = name == "fp8"
-        self._fp8_w, self._fp8_epoch = {}, None
+        self._fp8_w, self._fp8_epoch, self._fp8_wstates = {}, None, None
         self._ws = {}
 
     def _flat_groups(self):
@@ -334,8 +341,13 @@ class DiT(FlatModule):
         key = (B, adt, self._fp8)
         if key not in self._ws:
             self._ws[key] = _Workspace(self, B, adt)
-        self._ws_cur = self._ws[key]
-        return self._ws_cur
+        self._ws_cur = ws = self._ws[key]
+        if ws.fp8:
+            delayed = self.fp8_scaling == "delayed"
+            ws.d_fwd, ws.d_bwd = delayed and ws.calib_fwd, delayed and ws.calib_bwd
+            if ws.d_fwd or ws.d_bwd:
+                ops.fp8_scale_update(ws.fp8_states)
+        return ws
 
     _FP8_LINEARS = (("attn.qkv.", 3, 1), ("attn.proj.", 1, 1), ("mlp.fc1.", 0, 1), ("mlp.fc2.", 1, 0))   # (name, N / D or 0 = Dm, K / D or 0 = Dm)
 
@@ -346,14 +358,21 @@ class DiT(FlatModule):
         if self._fp8_epoch == epoch:
             return
         dev = self._flat.device
+        if self._fp8_wstates is None or self._fp8_wstates.device != dev:
+            self._fp8_wstates, self._fp8_w = ops.fp8_states([L.FP8] * (4 * self.depth), dev, self.fp8_margin), {}
+        delayed = self.fp8_scaling == "delayed" and bool(self._fp8_w)
+        if delayed:
+            ops.fp8_scale_update(self._fp8_wstates)
+        i = 0
         for l in range(self.depth):
             for nm, nf, kf in self._FP8_LINEARS:
                 name = f"blocks.{l}.{nm}weight"
                 N, K = (nf * self.D or self.Dm), (kf * self.D or self.Dm)
                 f = self._fp8_w.get(name)
-                if f is None or f.device != dev:
-                    f = self._fp8_w[name] = ops.Fp8(N, K, dev)
-                f.quantize(self._p32(name), src_dt=F32)
+                if f is None:
+                    f = self._fp8_w[name] = ops.Fp8(N, K, dev, state=self._fp8_wstates[i])
+                f.quantize(self._p32(name), src_dt=F32, delayed=delayed)
+                i += 1
         self._fp8_epoch = epoch
 
     def _forward_impl(self, x, t, y):
@@ -409,6 +428,8 @@ class DiT(FlatModule):
                  bias=self._p32("final_layer.linear.bias"), out_f32=True)
         out = torch.empty(B, self.out_channels, H, W, device=x.device, dtype=torch.float32)
         L.check(lib.vaw_unpatchify(dt, ptr(ws.otok), ptr(out), B, self.out_channels, H, W, self.patch_size, st), "unpatchify")
+        if ws.fp8:
+            ws.calib_fwd = True
         return out
 
     def _linear_fwd(self, ws, b, fkey, x, name, M, N, K, out, ldc, **epi):
@@ -417,7 +438,7 @@ class DiT(FlatModule):
         if not ws.fp8:
             ops.gemm(self._dt, 1, 1, M, N, K, ptr(x), K, self._w(name + "weight"), K, out, ldc, bias=self._p32(name + "bias"), **epi)
             return
-        f, w = b[fkey].quantize(x), self._fp8_w[name + "weight"]
+        f, w = b[fkey].quantize(x, delayed=ws.d_fwd), self._fp8_w[name + "weight"]
         ops.gemm_fp8(M, N, K, f.last_q, K, ptr(f.scale), ptr(w.q), K, ptr(w.scale), out, ldc, bias=self._p32(name + "bias"), **epi)
 
     def _linear_dgrad(self, ws, b, fkey, dy, name, M, N, K, out, **epi):
@@ -425,7 +446,7 @@ class DiT(FlatModule):
         if not ws.fp8:
             ops.gemm(self._dt, 1, 0, M, K, N, ptr(dy) if isinstance(dy, torch.Tensor) else dy, N, self._w(name + "weight"), K, out, K, **epi)
             return
-        f, w = b[fkey].quantize(dy, src_dt=BF16), self._fp8_w[name + "weight"]
+        f, w = b[fkey].quantize(dy, src_dt=BF16, delayed=ws.d_bwd), self._fp8_w[name + "weight"]
         ops.gemm_fp8(M, K, N, f.last_q, N, ptr(f.scale), ptr(w.qt), N, ptr(w.scale), out, K, a_format=f.fmt, **epi)
 
     def _attn_desc(self, B):
@@ -592,6 +613,8 @@ class DiT(FlatModule):
             dh1_a = ptr(ws.dh1)
         self._wgrad(dt, "t_embedder.mlp.0.", dh1_a, ptr(ws.tfreq), D, 256, B, beta)
         self.attach_grads()
+        if fp8:
+            ws.calib_bwd = True
         if hook:
             hook(0)
         return dx

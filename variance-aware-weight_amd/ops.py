@@ -169,24 +169,47 @@ def fp8_quantize(src_dt, src, R, C_, ld, q, qt, scale, fmt=L.FP8, device=None):
           "vaw_fp8_quantize")
 
 
+FP8_MAX = {L.FP8: 448.0, L.BF8: 57344.0}
+
+
+def fp8_states(formats, device, margin=2.0):
+    """[n][4] f32 scaling states {scale, running amax, FMAX / margin, 0} for delayed scaling (vaw_fp8_quantize_delayed /
+    vaw_fp8_scale_update), one row per tensor format in `formats`."""
+    st = torch.zeros(len(formats), 4)
+    st[:, 0] = 1.0
+    st[:, 2] = torch.tensor([FP8_MAX[f] / margin for f in formats])
+    return st.to(device)
+
+
+def fp8_scale_update(states):
+    check(L.lib().vaw_fp8_scale_update(states.data_ptr(), states.shape[0], stream_ptr()), "vaw_fp8_scale_update")
+
+
 class Fp8:
     """An fp8 copy of a 2-D operand: q [R][C] bytes, optionally qt [C][R] (the transposed copy the k-major-only fp8 GEMMs read
     for the other contraction), and the device scalar `scale` that turns the bytes back into values.  fmt: FP8 (e4m3) | BF8 (e5m2).
-    plain=False keeps only the transposed copy (the row-major bytes go to the buffer `q_scratch` hands out)."""
+    plain=False keeps only the transposed copy (the row-major bytes go to the buffer `q_scratch` hands out).  state: a row of
+    fp8_states() shared with the once-per-step scale update (delayed scaling); without one the object owns a private row."""
 
-    def __init__(self, R, C_, device, transposed=True, plain=True, fmt=L.FP8):
+    def __init__(self, R, C_, device, transposed=True, plain=True, fmt=L.FP8, state=None):
         self.R, self.C, self.fmt, self.device = int(R), int(C_), fmt, device
         self.q = torch.empty(R, C_, device=device, dtype=torch.uint8) if plain else None
         self.qt = torch.empty(C_, R, device=device, dtype=torch.uint8) if transposed else None
-        self.scale = torch.ones(1, device=device, dtype=torch.float32)
+        self.state = state if state is not None else fp8_states([fmt], device)[0]
+        self.scale = self.state[0:1]
 
-    def quantize(self, src, ld=None, src_dt=None):
-        """src: f32 / bf16 tensor holding R x C values with row stride ld (default C), or a device address with src_dt."""
+    def quantize(self, src, ld=None, src_dt=None, delayed=False):
+        """src: f32 / bf16 tensor holding R x C values with row stride ld (default C), or a device address with src_dt.
+        delayed=False: scale = amax / FMAX taken from src first (two passes); True: the scale already in the state."""
         if isinstance(src, torch.Tensor):
             need_cuda(src)
             src_dt, src = dt_of(src), src.data_ptr()
         q = self.q if self.q is not None else q_scratch(self.R * self.C, self.device)
-        fp8_quantize(src_dt, src, self.R, self.C, ld or self.C, q.data_ptr(), ptr(self.qt), self.scale.data_ptr(), self.fmt, self.device)
+        if delayed:
+            check(L.lib().vaw_fp8_quantize_delayed(src_dt, self.fmt, src, self.R, self.C, ld or self.C, q.data_ptr(), self.C, ptr(self.qt),
+                                                   self.R, self.state.data_ptr(), stream_ptr()), "vaw_fp8_quantize_delayed")
+        else:
+            fp8_quantize(src_dt, src, self.R, self.C, ld or self.C, q.data_ptr(), ptr(self.qt), self.scale.data_ptr(), self.fmt, self.device)
         self.last_q = q.data_ptr()
         return self
 
