@@ -142,14 +142,35 @@ def build(pkg, wl, args, device, rank):
     return model, ema_model
 
 
+def usable_cores():
+    """Cores this process may really use: the affinity mask, cut by the cgroup CPU quota (a container sees every host core in its
+    mask but is throttled to its share: oversubscribing it with one thread per visible core stalls for minutes)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]                      # cgroup v2
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())                  # cgroup v1
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(wl, batch, budget_s=25.0):
     """The CPU oracle (torch restatement of the reference path, pinned by tests/golden) on this host: the workload's batch
     when one step fits the budget, else the largest batch that does (flagged in "reduced_batch")."""
     from oracle import diffusion as od, dit as odit, trainer as otr, unet as ounet
     torch.manual_seed(42)
-    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    threads = int(os.environ.get("VAW_CPU_THREADS", usable))
+    usable = usable_cores()
+    # default: at most 16 threads, the CPU share of one GPU on the measurement boxes (VAW_CPU_THREADS overrides)
+    threads = int(os.environ.get("VAW_CPU_THREADS", min(usable, 16)))
     torch.set_num_threads(threads)
+    print(f"[bench] cpu_baseline: {threads} threads ({usable} usable, {os.cpu_count()} on the host)", file=sys.stderr, flush=True)
     args = workload_args(wl, amp=False, defer_loss_sync=False)
     opkg = SimpleNamespace(DiT_models=odit.DiT_models, UNetModel=ounet.UNetModel, ADM_64=ounet.ADM_64, UNet_64=ounet.UNet_64)
     model = make_model(opkg, wl)
@@ -174,6 +195,7 @@ def cpu_baseline(wl, batch, budget_s=25.0):
     while n < 2 or (time.perf_counter() - t0 < budget_s and n < 20):
         tr.train_step(n + 2)
         n += 1
+        print(f"[bench] cpu_baseline: step {n} at batch {B}, {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
     dt = time.perf_counter() - t0
     return {"value": round(B * n / dt, 2), "unit": "images/sec", "cores": threads, "host_cpu_count": os.cpu_count(),
             "usable_cores": usable, "kind": "port", "reduced_batch": None if B == batch else B,
