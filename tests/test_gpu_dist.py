@@ -116,4 +116,8 @@ def test_two_rank_step_reproduces_single_rank_step(kind, variant):
         torch.testing.assert_close(res[0][1], flat1, rtol=0, atol=2.1e-3)      # magnitude, so only sign flips of ~0 gradients differ
         assert float((res[0][1] - flat1).abs().gt(1e-5).float().mean()) < 0.02
     else:
-        torch.testing.assert_close(res[0][1], flat1, rtol=1e-4, atol=2e-6)
+        # f32 buckets: equal up to reduction order.  AdamW's first step moves an element by lr * g / (|g| + eps): where the
+        # gradient itself is of the order of eps = 1e-8 (a handful of UNet weights) the order of summation shows, bounded by 2 lr
+        d = (res[0][1] - flat1).abs()
+        off = d > 2e-6 + 1e-4 * flat1.abs()
+        assert float(off.float().mean()) < 1e-4 and float(d.max()) < 2.1e-3, (int(off.sum()), float(d.max()))

@@ -50,11 +50,11 @@ P8Plan vaw_p8_plan(int64_t M, int64_t N, int64_t K, bool plain_f32, bool want_co
         const int64_t tiles = ((M + 255) / 256) * ((N + bn - 1) / bn);
         if (ntw == 3 && force != 3) {
             // 192-column tiles: where they cut the padded width (N = 192 k that is not a multiple of 256: the conv channel
-            // counts 192 / 576 / 960 ...), or save whole rounds of a multi-round launch; never for a single round of
-            // equally padded work (N = 768: measured no faster)
+            // counts 192 / 576 / 960 ...), save whole rounds of a multi-round launch, or (N = 768 at M = 16384: 256 tiles of
+            // 0.85 instead of 192 tiles on 256 CUs -- measured 3-9 % faster on all five DiT-B/4 launches of that width) put
+            // idle CUs to work within one round; the cost model below decides, wider padding is the only veto
             const int64_t pad4 = ((N + 255) / 256) * 256, pad3 = ((N + 191) / 192) * 192;
-            const int64_t tiles4 = ((M + 255) / 256) * ((N + 255) / 256);
-            if (pad3 > pad4 || (pad3 == pad4 && tiles4 <= cus)) continue;
+            if (pad3 > pad4) continue;
         }
         int smax = 1;
         if (plain_f32 && !want_colsum && ws_floats > 0) {

@@ -319,6 +319,40 @@ colsum_final_kernel(const float* __restrict__ part, int64_t RB, int64_t N, float
     }
 }
 
+// bf16, N % 8 == 0, 16-byte aligned rows: 128 rows x 256 columns per workgroup, every lane 16 independent 16-byte loads
+// (the 512-row kernel above walks its rows with one dependent 8-byte load at a time: 1.9 TB/s on [16384][2304])
+__global__ void __launch_bounds__(256)
+colsum_partial_bf16x8_kernel(const bf16_t* __restrict__ X, int64_t M, int64_t N, int64_t ldx, float* __restrict__ part_out) {
+    __shared__ __attribute__((aligned(16))) float part[8][256];
+    const int cg = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int64_t col = (int64_t)blockIdx.x * 256 + cg * 8;
+    const int64_t r0 = (int64_t)blockIdx.y * 128;
+    f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+    if (col < N) {          // N % 8 == 0: a group of 8 columns is in or out as a whole
+        bf16x8 v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int64_t r = r0 + rg + 8 * i;
+            v[i] = r < M ? *reinterpret_cast<const bf16x8*>(X + r * ldx + col) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {        // rows ascending: fixed order
+            a0 += f32x4{(float)v[i][0], (float)v[i][1], (float)v[i][2], (float)v[i][3]};
+            a1 += f32x4{(float)v[i][4], (float)v[i][5], (float)v[i][6], (float)v[i][7]};
+        }
+    }
+    store4(&part[rg][cg * 8], a0);
+    store4(&part[rg][cg * 8 + 4], a1);
+    __syncthreads();
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) t += part[g][threadIdx.x];
+        part_out[(int64_t)blockIdx.y * N + c] = t;
+    }
+}
+
 // any alignment / any N (e.g. the 3-channel output conv): one thread per (row block, column)
 template <typename T>
 __global__ void colsum_partial_scalar_kernel(const T* __restrict__ X, int64_t M, int64_t N, int64_t ldx, float* __restrict__ part_out) {
@@ -330,7 +364,7 @@ __global__ void colsum_partial_scalar_kernel(const T* __restrict__ X, int64_t M,
     part_out[(int64_t)blockIdx.y * N + c] = acc;
 }
 
-extern "C" int64_t vaw_colsum_workspace_floats(int64_t M, int64_t N) { return ((M + 511) / 512) * N; }
+extern "C" int64_t vaw_colsum_workspace_floats(int64_t M, int64_t N) { return ((M + 127) / 128) * N; }
 
 extern "C" int vaw_reduce_rows(const float* partial, int64_t R, int64_t N, float* out, float beta, vaw_stream stream) {
     VAW_CHECK_ARG(R > 0 && N > 0 && partial && out, "reduce_rows: bad arguments");
@@ -343,13 +377,16 @@ extern "C" int vaw_colsum(vaw_dtype dt, const void* X, int64_t M, int64_t N, int
                           float* workspace, int64_t workspace_floats, vaw_stream stream) {
     VAW_CHECK_ARG(M > 0 && N > 0 && ldx >= N, "colsum: bad sizes");
     const bool vec = (ldx % 4 == 0) && (((uintptr_t)X & 15) == 0);
-    const int64_t RB = (M + 511) / 512;
+    const bool wide = dt == VAW_BF16 && N % 8 == 0 && ldx % 8 == 0 && (((uintptr_t)X & 15) == 0) && M >= 1024;
+    const int64_t RB = wide ? (M + 127) / 128 : (M + 511) / 512;
     VAW_CHECK_ARG(workspace && workspace_floats >= RB * N, "colsum: workspace too small (%ld < %ld floats)",
                   (long)workspace_floats, (long)(RB * N));
     VAW_CHECK_ARG(RB < 65536, "colsum: M too large");
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(ceil_div(N, 256), (int)RB);
-    if (vec) {
+    if (wide) {
+        colsum_partial_bf16x8_kernel<<<grid, 256, 0, s>>>((const bf16_t*)X, M, N, ldx, workspace);
+    } else if (vec) {
         if (dt == VAW_F32) colsum_partial_kernel<float><<<grid, 256, 0, s>>>((const float*)X, M, N, ldx, workspace);
         else colsum_partial_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)X, M, N, ldx, workspace);
     } else {
