@@ -6,7 +6,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvaw_hip.so")
+LIB_PATH = os.environ.get("VAW_HIP_LIB") or os.path.join(_HERE, "libvaw_hip.so")   # (override: measurement builds only)
 
 F32, BF16, FP8, BF8 = 0, 1, 2, 3
 TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16}

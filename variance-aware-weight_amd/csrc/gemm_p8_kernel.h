@@ -38,6 +38,18 @@
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
+// -DP8_TIMING (tools/p8_timing.py, never in the product library): wave 0 and wave 4 of workgroup 0 accumulate s_memtime
+// deltas between the five points of a phase and leave them in the first bytes of their output rows.
+#ifdef P8_TIMING
+#define P8_TS(v) const uint64_t v = __builtin_readcyclecounter()
+#define P8_TACC(tA, tB, tC, tD, tE)                                                                       \
+    do { tacc[0] += tB - tA; tacc[1] += tC - tB; tacc[2] += tD - tC; tacc[3] += tE - tD; tacc[5] += 1;     \
+         if (tprev) tacc[4] += tA - tprev; tprev = tE; } while (0)
+#else
+#define P8_TS(v) do { } while (0)
+#define P8_TACC(tA, tB, tC, tD, tE) do { } while (0)
+#endif
+
 #define P8_BM 256
 #define P8_PART 8192
 #define P8_EPI_BYTES 32768
@@ -60,7 +72,11 @@ struct P8Conv {
 };
 
 __device__ __forceinline__ void p8_dma16(__amdgpu_buffer_rsrc_t rs, char* lds_dst, unsigned voff, unsigned soff) {
+#ifdef P8_ABLATE_DMA       // measurement builds only (tools/p8_timing.py): the main loop without its global -> LDS traffic
+    asm volatile("" :: "v"(voff), "s"(soff));
+#else
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)lds_dst, 16, voff, soff, 0, 0);
+#endif
 }
 
 typedef int i32x8_t __attribute__((ext_vector_type(8)));
@@ -110,6 +126,10 @@ __device__ __forceinline__ bf16x8 p8_frag(const char* part, int r16, int s, int 
     if (KMAJOR) {
         const int row = r16 + (lane & 15);
         const int chunk = (4 * s + (lane >> 4)) ^ ((row >> 1) & 7);
+#ifdef P8_ABLATE_FRAG      // measurement builds only: no LDS fragment reads (operands = address bits)
+        const float f = (float)(row + chunk);
+        return bf16x8{(bf16_t)f, (bf16_t)f, (bf16_t)f, (bf16_t)f, (bf16_t)f, (bf16_t)f, (bf16_t)f, (bf16_t)f};
+#endif
         return *reinterpret_cast<const bf16x8*>(part + row * 128 + (chunk << 4));
     } else {
         const int li = lane & 15, q = li >> 2, p = li & 3;
@@ -372,8 +392,14 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
 
     int stage = 0;
     const int wn0 = wc * Cfg::WN;
+#ifdef P8_TIMING
+    uint64_t tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+#endif
     for (; it_cur < n_items; it_cur += G) {
         const P8Item item = decode(it_cur);
+#ifdef P8_TIMING
+        tprev = 0;
+#endif
         const int split = item.split, tm = item.tm, nk = item.nk;
         const int64_t m0 = item.m0, n0 = item.n0;
         // per-item view of the epilogue descriptor: in grouped mode the output tensor changes from item to item
@@ -449,10 +475,14 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
 #pragma unroll
                 for (int s = 0; s < 2; ++s) bfr[s][u] = p8_frag<BKM>(st + Cfg::a_bytes + (n >> 6) * P8_PART, n & 63, s, lane_k);
             }
+            P8_TS(t1a);
             load_a(0);
             issue_ph1();
+            P8_TS(t1b);
             P8_WAIT(8);
+            P8_TS(t1c);
             __builtin_amdgcn_s_barrier();
+            P8_TS(t1d);
             P8_MMA(0);
             if (CONV == 3 && do_colsum_b) {      // column sums of the B tile (dy): B . ones -- every column of the result holds them
 #pragma unroll
@@ -460,27 +490,47 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
 #pragma unroll
                     for (int u = 0; u < NTW; ++u) accb[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[s][u], ones8, accb[u], 0, 0, 0);
             }
+            P8_TS(t1e);
+            P8_TACC(t1a, t1b, t1c, t1d, t1e);
             __builtin_amdgcn_s_barrier();
             // ---- phase 2
+            P8_TS(t2a);
             load_a(1);
             issue_ph2();
+            P8_TS(t2b);
             if (LS == 8) P8_WAIT(9); else P8_WAIT(8);
+            P8_TS(t2c);
             __builtin_amdgcn_s_barrier();
+            P8_TS(t2d);
             P8_MMA(1);
+            P8_TS(t2e);
+            P8_TACC(t2a, t2b, t2c, t2d, t2e);
             __builtin_amdgcn_s_barrier();
             // ---- phase 3
+            P8_TS(t3a);
             load_a(2);
             issue_ph3();
+            P8_TS(t3b);
             if (LS == 8) P8_WAIT(10); else P8_WAIT(9);
+            P8_TS(t3c);
             __builtin_amdgcn_s_barrier();
+            P8_TS(t3d);
             P8_MMA(2);
+            P8_TS(t3e);
+            P8_TACC(t3a, t3b, t3c, t3d, t3e);
             __builtin_amdgcn_s_barrier();
             // ---- phase 4
+            P8_TS(t4a);
             load_a(3);
             issue_ph4();
+            P8_TS(t4b);
             P8_WAIT(7);
+            P8_TS(t4c);
             __builtin_amdgcn_s_barrier();
+            P8_TS(t4d);
             P8_MMA(3);
+            P8_TS(t4e);
+            P8_TACC(t4a, t4b, t4c, t4d, t4e);
             __builtin_amdgcn_s_barrier();
         }
         if (wr == 0) __builtin_amdgcn_s_barrier();       // level the two wave rows: both run their epilogues together
@@ -627,6 +677,13 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
             }
         }
     }
+#ifdef P8_TIMING
+    if (blockIdx.x == 0 && lane == 0 && (wid == 0 || wid == 4)) {
+        __builtin_amdgcn_s_waitcnt(0);
+        uint64_t* out = reinterpret_cast<uint64_t*>((char*)e.C + (int64_t)(wid == 4 ? 128 : 0) * e.ldc * (e.out_f32 ? 4 : 2));
+        for (int i = 0; i < 6; ++i) out[i] = tacc[i];
+    }
+#endif
 }
 
 
