@@ -15,7 +15,10 @@
 //
 // LDS: every operand block is a [64 rows][HD] bf16 image filled by LDS-DMA (global_load_lds_dwordx4) with the
 // 16-byte chunk XOR-swizzled on the SOURCE side so that the ds_read_b128 row reads are conflict-free
-// (HD 32/64/128; the 192-byte rows of HD 96 stay linear: 4-way conflicts, still far ahead of the VALU kernel).
+// (HD 32/64/128).  HD 96 (DiT-XL's 72-wide heads, the UNets' 96): an XOR cannot stay inside a 12-chunk row, so the row pitch is
+// padded to 13 chunks (208 bytes) instead: 52 dwords per row puts 16 consecutive rows on 16 distinct 4-bank groups, which makes
+// both the ds_read_b128 row reads and the transposed column reads conflict-free (the linear 192-byte rows were 4-way conflicted);
+// the pad chunk is filled from the zero page by the same DMA instruction stream (13 wave-instructions per image instead of 12).
 #include "common.h"
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -34,22 +37,28 @@ template <int HD>
 __device__ __forceinline__ int swz(int row) {
     return HD == 32 ? ((-(row >> 2)) & 3) : HD == 64 ? ((row >> 1) & 7) : HD == 128 ? (row & 15) : 0;
 }
+template <int HD> struct Img {
+    static constexpr int PCH = HD == 96 ? 13 : HD / 8;     // 16-byte chunks per image row (pitch)
+    static constexpr int PITCH = 16 * PCH;
+    static constexpr int BYTES = 64 * PITCH;                // one 64-row image
+};
 template <int HD>
-__device__ __forceinline__ int img_off(int row, int chunk) { return row * (2 * HD) + ((chunk ^ swz<HD>(row)) << 4); }
+__device__ __forceinline__ int img_off(int row, int chunk) { return row * Img<HD>::PITCH + ((chunk ^ swz<HD>(row)) << 4); }
 
 // 64 token rows starting at g (row stride stride_t elements) -> LDS image rows [0,64); all 4 waves cooperate
 template <int HD>
 __device__ __forceinline__ void stage_block(const bf16_t* __restrict__ g, int64_t stride_t, char* img, int wid, int lane,
                                             int hd) {
-    constexpr int CPR = HD / 8;      // 16-byte chunks per row; the image is CPR wave-instructions of 1 KiB
+    constexpr int PCH = Img<HD>::PCH;      // 16-byte chunks per row incl. padding; the image is PCH wave-instructions of 1 KiB
 #pragma unroll
-    for (int i = 0; i < CPR / 4; ++i) {
-        const int inst = wid * (CPR / 4) + i;
+    for (int i = 0; i < (PCH + 3) / 4; ++i) {
+        const int inst = wid + 4 * i;
+        if (PCH % 4 != 0 && inst >= PCH) break;              // uniform per wave
         const int idx = inst * 64 + lane;
-        const int row = idx / CPR;
-        const int chunk = (idx % CPR) ^ swz<HD>(row);
+        const int row = idx / PCH;
+        const int chunk = (idx % PCH) ^ swz<HD>(row);
         const bf16_t* src = chunk * 8 < hd ? g + (int64_t)row * stride_t + chunk * 8
-                                           : reinterpret_cast<const bf16_t*>(attn_zero_page);   // padded head dim (72 -> 96)
+                                           : reinterpret_cast<const bf16_t*>(attn_zero_page);   // padded head dim (72 -> 96), pad chunk
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(img + inst * 1024), 16, 0, 0);
     }
 }
@@ -102,7 +111,7 @@ __global__ void __launch_bounds__(256)
 attn_fwd_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
               bf16_t* __restrict__ o, float* __restrict__ lse) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // QG + 2 (+ 2 if DB) images of 64 x HD bf16
-    constexpr int KS = HD / 32, DT = HD / 16, IMG = 64 * 2 * HD;
+    constexpr int KS = HD / 32, DT = HD / 16, IMG = Img<HD>::BYTES;
     char* qimg = smem;
     char* kv = smem + QG * IMG;                                   // [1 or 2 buffers][K image | V image]
     const int lane = threadIdx.x & 63;
@@ -222,9 +231,9 @@ attn_bwd_dq_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __r
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 images of 64 x HD bf16
     constexpr int KS = HD / 32, DT = HD / 16;
     char* qimg = smem;
-    char* gimg = qimg + 64 * 2 * HD;
-    char* kimg = gimg + 64 * 2 * HD;
-    char* vimg = kimg + 64 * 2 * HD;
+    char* gimg = qimg + Img<HD>::BYTES;
+    char* kimg = gimg + Img<HD>::BYTES;
+    char* vimg = kimg + Img<HD>::BYTES;
     const int lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
@@ -300,10 +309,10 @@ attn_bwd_dkv_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 images of 64 x HD bf16 + lse / delta of the query block
     constexpr int KS = HD / 32, DT = HD / 16;
     char* kimg = smem;
-    char* vimg = kimg + 64 * 2 * HD;
-    char* qimg = vimg + 64 * 2 * HD;
-    char* gimg = qimg + 64 * 2 * HD;
-    float* lse_s = reinterpret_cast<float*>(gimg + 64 * 2 * HD);
+    char* vimg = kimg + Img<HD>::BYTES;
+    char* qimg = vimg + Img<HD>::BYTES;
+    char* gimg = qimg + Img<HD>::BYTES;
+    float* lse_s = reinterpret_cast<float*>(gimg + Img<HD>::BYTES);
     float* del_s = lse_s + 64;
     const int lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -383,10 +392,10 @@ attn_bwd_t64_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 images of 64 x HD bf16 + lse / delta
     constexpr int KS = HD / 32, DT = HD / 16;
     char* qimg = smem;
-    char* gimg = qimg + 64 * 2 * HD;
-    char* kimg = gimg + 64 * 2 * HD;
-    char* vimg = kimg + 64 * 2 * HD;
-    float* lse_s = reinterpret_cast<float*>(vimg + 64 * 2 * HD);
+    char* gimg = qimg + Img<HD>::BYTES;
+    char* kimg = gimg + Img<HD>::BYTES;
+    char* vimg = kimg + Img<HD>::BYTES;
+    float* lse_s = reinterpret_cast<float*>(vimg + Img<HD>::BYTES);
     float* del_s = lse_s + 64;
     const int lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -532,10 +541,10 @@ int vaw_attn_fwd_mfma(const vaw_attn_desc* d, const void* q, const void* k, cons
     AttnMfmaArgs a = mk_args(d);
     // two 16-query groups per wave: +10..17 % for head dims <= 64 (tools/attn_bench.py); slower for the padded 96-wide
     // images (DiT-XL's 72, UNet_64's 96: unswizzled LDS rows and twice the accumulators), which keep one group
-    if (d->T % 128 == 0 && d->hd <= 64 && attn_qg2()) {
+    if (d->T % 128 == 0 && d->hd <= 96 && attn_qg2()) {
         dim3 grid(d->T / 128, d->B * d->H);
         DISPATCH_HD(d->hd,
-            const int lds = (HD <= 64 ? 6 : 4) * 64 * 2 * HD;
+            const int lds = (HD <= 64 ? 6 : 4) * Img<HD>::BYTES;
             (void)hipFuncSetAttribute((const void*)attn_fwd_mfma<HD, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             attn_fwd_mfma<HD, 2><<<grid, 256, lds, s>>>(a, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse);
         )
@@ -545,7 +554,7 @@ int vaw_attn_fwd_mfma(const vaw_attn_desc* d, const void* q, const void* k, cons
     dim3 grid(d->T / 64, d->B * d->H);
     if (d->T == 64) {        // a single key block: nothing to double-buffer, keep the LDS footprint (and residency) small
         DISPATCH_HD(d->hd,
-            const int lds = 3 * 64 * 2 * HD;
+            const int lds = 3 * Img<HD>::BYTES;
             (void)hipFuncSetAttribute((const void*)attn_fwd_mfma<HD, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             attn_fwd_mfma<HD, 1, false><<<grid, 256, lds, s>>>(a, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse);
         )
@@ -553,7 +562,7 @@ int vaw_attn_fwd_mfma(const vaw_attn_desc* d, const void* q, const void* k, cons
         return VAW_OK;
     }
     DISPATCH_HD(d->hd,
-        const int lds = (HD <= 64 ? 5 : 3) * 64 * 2 * HD;
+        const int lds = (HD <= 64 ? 5 : 3) * Img<HD>::BYTES;
         (void)hipFuncSetAttribute((const void*)attn_fwd_mfma<HD, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attn_fwd_mfma<HD, 1><<<grid, 256, lds, s>>>(a, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse);
     )
@@ -567,7 +576,7 @@ int vaw_attn_bwd_mfma(const vaw_attn_desc* d, const void* q, const void* k, cons
     dim3 grid(d->T / 64, d->B * d->H);
     if (d->T == 64) {      // single block of queries and keys: one fused launch
         DISPATCH_HD(d->hd,
-            const int lds = 4 * 64 * 2 * HD + 2 * 64 * 4;
+            const int lds = 4 * Img<HD>::BYTES + 2 * 64 * 4;
             (void)hipFuncSetAttribute((const void*)attn_bwd_t64_mfma<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             attn_bwd_t64_mfma<HD><<<d->B * d->H, 256, lds, s>>>(a, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o,
                                                               (const bf16_t*)d_o, lse, delta, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv);
@@ -576,7 +585,7 @@ int vaw_attn_bwd_mfma(const vaw_attn_desc* d, const void* q, const void* k, cons
         return VAW_OK;
     }
     DISPATCH_HD(d->hd,
-        const int lds = 4 * 64 * 2 * HD + 2 * 64 * 4;
+        const int lds = 4 * Img<HD>::BYTES + 2 * 64 * 4;
         (void)hipFuncSetAttribute((const void*)attn_bwd_dq_mfma<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_mfma<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attn_bwd_dq_mfma<HD><<<grid, 256, lds, s>>>(a, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o,
