@@ -221,46 +221,56 @@ attn_fwd_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward, query-major: grid (T/64, B*H); delta and dQ for 64 queries, keys stream
+// backward, query-major: grid (T/(64 G), B*H); delta and dQ for 64 G queries, keys stream.
+// G = 2 (T % 128 == 0, 96-wide head images): every staged K / V block and every fragment read from it serves two query
+// groups per wave.
 // ------------------------------------------------------------------------------------------------
-template <int HD>
+template <int HD, int G>
 __global__ void __launch_bounds__(256)
 attn_bwd_dq_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                  const bf16_t* __restrict__ o, const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                  float* __restrict__ delta_out, bf16_t* __restrict__ dq) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 images of 64 x HD bf16
-    constexpr int KS = HD / 32, DT = HD / 16;
-    char* qimg = smem;
-    char* gimg = qimg + Img<HD>::BYTES;
-    char* kimg = gimg + Img<HD>::BYTES;
-    char* vimg = kimg + Img<HD>::BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 G + 2 images of 64 x HD bf16
+    constexpr int KS = HD / 32, DT = HD / 16, IMG = Img<HD>::BYTES;
+    char* qimg = smem;                       // G images
+    char* gimg = qimg + G * IMG;             // G images
+    char* kimg = gimg + G * IMG;
+    char* vimg = kimg + IMG;
     const int lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
-    const int qb = blockIdx.x * 64;
+    const int qb = blockIdx.x * 64 * G;
     const int64_t base = b * a.q_sb + h * a.q_sh, obase = b * a.o_sb + h * a.o_sh;
-    stage_block<HD>(q + base + (int64_t)qb * a.q_st, a.q_st, qimg, wid, lane, a.hd);
-    stage_block<HD>(d_o + obase + (int64_t)qb * a.o_st, a.o_st, gimg, wid, lane, a.hd);
-    const int qi = qb + 16 * wid + li;
-    // delta_i = sum_d dO[i,d] * O[i,d]: lane (li, g) takes a quarter of the row
-    float dl = 0.f;
-    {
-        const bf16_t* gp = d_o + obase + (int64_t)qi * a.o_st + g * (HD / 4);
-        const bf16_t* op = o + obase + (int64_t)qi * a.o_st + g * (HD / 4);
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+        stage_block<HD>(q + base + (int64_t)(qb + 64 * u) * a.q_st, a.q_st, qimg + u * IMG, wid, lane, a.hd);
+        stage_block<HD>(d_o + obase + (int64_t)(qb + 64 * u) * a.o_st, a.o_st, gimg + u * IMG, wid, lane, a.hd);
+    }
+    int qi[G];
+    float dl[G], li_lse[G];
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+        qi[u] = qb + 64 * u + 16 * wid + li;
+        // delta_i = sum_d dO[i,d] * O[i,d]: lane (li, g) takes a quarter of the row
+        float t = 0.f;
+        const bf16_t* gp = d_o + obase + (int64_t)qi[u] * a.o_st + g * (HD / 4);
+        const bf16_t* op = o + obase + (int64_t)qi[u] * a.o_st + g * (HD / 4);
 #pragma unroll
         for (int d = 0; d < HD / 4; d += 4) {
             if (g * (HD / 4) + d >= a.hd) continue;
             const f32x4 x = load4(gp + d), y = load4(op + d);
-            dl += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+            t += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
         }
-        dl = group_sum(dl);
+        dl[u] = group_sum(t);
+        li_lse[u] = lse[(int64_t)bh * a.T + qi[u]];
+        if (g == 0) delta_out[(int64_t)bh * a.T + qi[u]] = dl[u];
     }
-    const float li_lse = lse[(int64_t)bh * a.T + qi];
-    if (g == 0) delta_out[(int64_t)bh * a.T + qi] = dl;
-    bf16x8 qf[KS], gf[KS];
-    f32x4 acc[DT];
+    bf16x8 qf[G][KS], gf[G][KS];
+    f32x4 acc[G][DT];
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) acc[dt] = f32x4{0, 0, 0, 0};
+    for (int u = 0; u < G; ++u)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) acc[u][dt] = f32x4{0, 0, 0, 0};
     for (int kb = 0; kb < a.T; kb += 64) {
         __syncthreads();
         stage_block<HD>(k + base + (int64_t)kb * a.q_st, a.q_st, kimg, wid, lane, a.hd);
@@ -268,63 +278,87 @@ attn_bwd_dq_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __r
         DMA_WAIT_SYNC();
         if (kb == 0) {
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                qf[s] = frag_rows<HD>(qimg, 16 * wid, s, lane);
-                gf[s] = frag_rows<HD>(gimg, 16 * wid, s, lane);
-            }
+            for (int u = 0; u < G; ++u)
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    qf[u][s] = frag_rows<HD>(qimg + u * IMG, 16 * wid, s, lane);
+                    gf[u][s] = frag_rows<HD>(gimg + u * IMG, 16 * wid, s, lane);
+                }
         }
-        f32x4 ds[4];
+        f32x4 ds[G][4];
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) {
-            f32x4 c = {0, 0, 0, 0}, d = {0, 0, 0, 0};
+            f32x4 c[G], d[G];
+#pragma unroll
+            for (int u = 0; u < G; ++u) c[u] = d[u] = f32x4{0, 0, 0, 0};
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                c = MFMA(frag_rows<HD>(kimg, 16 * jt, s, lane), qf[s], c);
-                d = MFMA(frag_rows<HD>(vimg, 16 * jt, s, lane), gf[s], d);
+                const bf16x8 kfr = frag_rows<HD>(kimg, 16 * jt, s, lane), vfr = frag_rows<HD>(vimg, 16 * jt, s, lane);
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    c[u] = MFMA(kfr, qf[u][s], c[u]);
+                    d[u] = MFMA(vfr, gf[u][s], d[u]);
+                }
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ds[jt][r] = a.scale * __expf(c[r] * a.scale - li_lse) * (d[r] - dl);
+            for (int u = 0; u < G; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ds[u][jt][r] = a.scale * __expf(c[u][r] * a.scale - li_lse[u]) * (d[u][r] - dl[u]);
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-            const bf16x8 sf = pack_acc(ds[2 * s2], ds[2 * s2 + 1]);
+            bf16x8 sf[G];
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) acc[dt] = MFMA(frag_cols_perm<HD>(kimg, 16 * dt, 32 * s2, lane), sf, acc[dt]);
+            for (int u = 0; u < G; ++u) sf[u] = pack_acc(ds[u][2 * s2], ds[u][2 * s2 + 1]);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const bf16x8 kc = frag_cols_perm<HD>(kimg, 16 * dt, 32 * s2, lane);
+#pragma unroll
+                for (int u = 0; u < G; ++u) acc[u][dt] = MFMA(kc, sf[u], acc[u][dt]);
+            }
         }
     }
-    bf16_t* row = dq + base + (int64_t)qi * a.q_st + 4 * g;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-        if (16 * dt + 4 * g < a.hd) store4(row + 16 * dt, acc[dt]);
+    for (int u = 0; u < G; ++u) {
+        bf16_t* row = dq + base + (int64_t)qi[u] * a.q_st + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+            if (16 * dt + 4 * g < a.hd) store4(row + 16 * dt, acc[u][dt]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward, key-major: grid (T/64, B*H); dK and dV for 64 keys, queries stream
+// backward, key-major: grid (T/(64 G), B*H); dK and dV for 64 G keys, queries stream (G as above)
 // ------------------------------------------------------------------------------------------------
-template <int HD>
+template <int HD, int G>
 __global__ void __launch_bounds__(256)
 attn_bwd_dkv_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                   const bf16_t* __restrict__ d_o, const float* __restrict__ lse, const float* __restrict__ delta,
                   bf16_t* __restrict__ dk, bf16_t* __restrict__ dv) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 images of 64 x HD bf16 + lse / delta of the query block
-    constexpr int KS = HD / 32, DT = HD / 16;
-    char* kimg = smem;
-    char* vimg = kimg + Img<HD>::BYTES;
-    char* qimg = vimg + Img<HD>::BYTES;
-    char* gimg = qimg + Img<HD>::BYTES;
-    float* lse_s = reinterpret_cast<float*>(gimg + Img<HD>::BYTES);
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 G + 2 images of 64 x HD bf16 + lse / delta of the query block
+    constexpr int KS = HD / 32, DT = HD / 16, IMG = Img<HD>::BYTES;
+    char* kimg = smem;                       // G images
+    char* vimg = kimg + G * IMG;             // G images
+    char* qimg = vimg + G * IMG;
+    char* gimg = qimg + IMG;
+    float* lse_s = reinterpret_cast<float*>(gimg + IMG);
     float* del_s = lse_s + 64;
     const int lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
-    const int jb = blockIdx.x * 64;
+    const int jb = blockIdx.x * 64 * G;
     const int64_t base = b * a.q_sb + h * a.q_sh, obase = b * a.o_sb + h * a.o_sh;
-    stage_block<HD>(k + base + (int64_t)jb * a.q_st, a.q_st, kimg, wid, lane, a.hd);
-    stage_block<HD>(v + base + (int64_t)jb * a.q_st, a.q_st, vimg, wid, lane, a.hd);
-    bf16x8 kf[KS], vf[KS];
-    f32x4 av[DT], ak[DT];
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) av[dt] = ak[dt] = f32x4{0, 0, 0, 0};
+    for (int u = 0; u < G; ++u) {
+        stage_block<HD>(k + base + (int64_t)(jb + 64 * u) * a.q_st, a.q_st, kimg + u * IMG, wid, lane, a.hd);
+        stage_block<HD>(v + base + (int64_t)(jb + 64 * u) * a.q_st, a.q_st, vimg + u * IMG, wid, lane, a.hd);
+    }
+    bf16x8 kf[G][KS], vf[G][KS];
+    f32x4 av[G][DT], ak[G][DT];
+#pragma unroll
+    for (int u = 0; u < G; ++u)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) av[u][dt] = ak[u][dt] = f32x4{0, 0, 0, 0};
     for (int ib = 0; ib < a.T; ib += 64) {
         __syncthreads();
         stage_block<HD>(q + base + (int64_t)ib * a.q_st, a.q_st, qimg, wid, lane, a.hd);
@@ -336,45 +370,68 @@ attn_bwd_dkv_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __
         DMA_WAIT_SYNC();
         if (ib == 0) {
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                kf[s] = frag_rows<HD>(kimg, 16 * wid, s, lane);
-                vf[s] = frag_rows<HD>(vimg, 16 * wid, s, lane);
-            }
+            for (int u = 0; u < G; ++u)
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    kf[u][s] = frag_rows<HD>(kimg + u * IMG, 16 * wid, s, lane);
+                    vf[u][s] = frag_rows<HD>(vimg + u * IMG, 16 * wid, s, lane);
+                }
         }
-        f32x4 p[4], ds[4];
+        f32x4 p[G][4], ds[G][4];
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            f32x4 c = {0, 0, 0, 0}, d = {0, 0, 0, 0};
+            f32x4 c[G], d[G];
+#pragma unroll
+            for (int u = 0; u < G; ++u) c[u] = d[u] = f32x4{0, 0, 0, 0};
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                c = MFMA(frag_rows<HD>(qimg, 16 * it, s, lane), kf[s], c);
-                d = MFMA(frag_rows<HD>(gimg, 16 * it, s, lane), vf[s], d);
+                const bf16x8 qfr = frag_rows<HD>(qimg, 16 * it, s, lane), gfr = frag_rows<HD>(gimg, 16 * it, s, lane);
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    c[u] = MFMA(qfr, kf[u][s], c[u]);
+                    d[u] = MFMA(gfr, vf[u][s], d[u]);
+                }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = 16 * it + 4 * g + r;
-                const float pr = __expf(c[r] * a.scale - lse_s[i]);
-                p[it][r] = pr;
-                ds[it][r] = a.scale * pr * (d[r] - del_s[i]);
+                const float ls = lse_s[i], de = del_s[i];
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const float pr = __expf(c[u][r] * a.scale - ls);
+                    p[u][it][r] = pr;
+                    ds[u][it][r] = a.scale * pr * (d[u][r] - de);
+                }
             }
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-            const bf16x8 pf = pack_acc(p[2 * s2], p[2 * s2 + 1]);
-            const bf16x8 sf = pack_acc(ds[2 * s2], ds[2 * s2 + 1]);
+            bf16x8 pf[G], sf[G];
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                pf[u] = pack_acc(p[u][2 * s2], p[u][2 * s2 + 1]);
+                sf[u] = pack_acc(ds[u][2 * s2], ds[u][2 * s2 + 1]);
+            }
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                av[dt] = MFMA(frag_cols_perm<HD>(gimg, 16 * dt, 32 * s2, lane), pf, av[dt]);
-                ak[dt] = MFMA(frag_cols_perm<HD>(qimg, 16 * dt, 32 * s2, lane), sf, ak[dt]);
+                const bf16x8 gc = frag_cols_perm<HD>(gimg, 16 * dt, 32 * s2, lane), qc = frag_cols_perm<HD>(qimg, 16 * dt, 32 * s2, lane);
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    av[u][dt] = MFMA(gc, pf[u], av[u][dt]);
+                    ak[u][dt] = MFMA(qc, sf[u], ak[u][dt]);
+                }
             }
         }
     }
-    const int64_t off = base + (int64_t)(jb + 16 * wid + li) * a.q_st + 4 * g;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-        if (16 * dt + 4 * g >= a.hd) continue;
-        store4(dv + off + 16 * dt, av[dt]);
-        store4(dk + off + 16 * dt, ak[dt]);
+    for (int u = 0; u < G; ++u) {
+        const int64_t off = base + (int64_t)(jb + 64 * u + 16 * wid + li) * a.q_st + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            if (16 * dt + 4 * g >= a.hd) continue;
+            store4(dv + off + 16 * dt, av[u][dt]);
+            store4(dk + off + 16 * dt, ak[u][dt]);
+        }
     }
 }
 
@@ -539,8 +596,8 @@ static bool attn_qg2() {
 int vaw_attn_fwd_mfma(const vaw_attn_desc* d, const void* q, const void* k, const void* v, void* o, float* lse,
                       hipStream_t s) {
     AttnMfmaArgs a = mk_args(d);
-    // two 16-query groups per wave: +10..17 % for head dims <= 64 (tools/attn_bench.py); slower for the padded 96-wide
-    // images (DiT-XL's 72, UNet_64's 96: unswizzled LDS rows and twice the accumulators), which keep one group
+    // two 16-query groups per wave: +10..17 % for head dims <= 64 (tools/attn_bench.py), +30 % for the padded 96-wide images
+    // (DiT-XL's 72, UNet_64's 96) now that their rows are conflict-free; 128-wide images keep one group (accumulators)
     if (d->T % 128 == 0 && d->hd <= 96 && attn_qg2()) {
         dim3 grid(d->T / 128, d->B * d->H);
         DISPATCH_HD(d->hd,
@@ -584,15 +641,27 @@ int vaw_attn_bwd_mfma(const vaw_attn_desc* d, const void* q, const void* k, cons
         VAW_CHECK_LAUNCH("attn_bwd_t64_mfma");
         return VAW_OK;
     }
-    DISPATCH_HD(d->hd,
-        const int lds = 4 * Img<HD>::BYTES + 2 * 64 * 4;
-        (void)hipFuncSetAttribute((const void*)attn_bwd_dq_mfma<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_mfma<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attn_bwd_dq_mfma<HD><<<grid, 256, lds, s>>>(a, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o,
-                                                   (const bf16_t*)d_o, lse, delta, (bf16_t*)dq);
-        attn_bwd_dkv_mfma<HD><<<grid, 256, lds, s>>>(a, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)d_o,
-                                                    lse, delta, (bf16_t*)dk, (bf16_t*)dv);
-    )
+    static int g2 = -1;
+    if (g2 < 0) { const char* e = getenv("VAW_ATTN_BWD_G2"); g2 = e ? atoi(e) : 1; }
+#define ATTN_BWD_GO(Gv)                                                                                                          \
+    do {                                                                                                                         \
+        dim3 gridg(d->T / (64 * Gv), d->B * d->H);                                                                               \
+        const int lds = (2 * Gv + 2) * Img<HD>::BYTES + 2 * 64 * 4;                                                              \
+        (void)hipFuncSetAttribute((const void*)attn_bwd_dq_mfma<HD, Gv>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);       \
+        (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_mfma<HD, Gv>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);      \
+        attn_bwd_dq_mfma<HD, Gv><<<gridg, 256, lds, s>>>(a, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o, \
+                                                        (const bf16_t*)d_o, lse, delta, (bf16_t*)dq);                            \
+        attn_bwd_dkv_mfma<HD, Gv><<<gridg, 256, lds, s>>>(a, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)d_o, \
+                                                         lse, delta, (bf16_t*)dk, (bf16_t*)dv);                                  \
+    } while (0)
+    // measured (tools/attn_bench.py, T = 256 / 1024): two groups are +10 % on the 96-wide images with 96 real channels
+    // (UNet_64), neutral on DiT-XL's 72-in-96, and 10-20 % SLOWER on 64-wide images, where the third resident workgroup is
+    // worth more than the shared fragments: these kernels are occupancy-, not DMA-latency-bound
+    if (d->T % 128 == 0 && d->hd > 64 && d->hd <= 96 && g2) {
+        DISPATCH_HD(d->hd, if constexpr (HD == 96) ATTN_BWD_GO(2); else ATTN_BWD_GO(1);)
+    } else {
+        DISPATCH_HD(d->hd, ATTN_BWD_GO(1);)
+    }
     VAW_CHECK_LAUNCH("attn_bwd_mfma");
     return VAW_OK;
 }
