@@ -56,13 +56,13 @@ def test_quantize_bytes_and_transpose(dtype, R, C, fmt):
     assert torch.equal(f3.q.cpu(), (x3 * (torch.tensor(1.0) / s3)).to(E).view(torch.uint8))
 
 
+@pytest.mark.parametrize("R,C", [(520, 328), (576, 384)])        # generic kernel | the 64 x 128 tiled kernel of the training shapes
 @pytest.mark.parametrize("fmt", ["e4m3", "e5m2"])
-def test_quantize_delayed_scaling_state(fmt):
+def test_quantize_delayed_scaling_state(fmt, R, C):
     """vaw_fp8_quantize_delayed + vaw_fp8_scale_update: bytes = cast(clamp(x / scale)) with the scale in the state, the state's
     running max = max |x| exactly (atomic max on the bits), and the update turns it into scale = amax * margin / FMAX."""
     code, E, FMAX = FMT[fmt]
     dev = torch.device(DEV)
-    R, C = 520, 328
     g = torch.Generator().manual_seed(9)
     st = ops.fp8_states([code, code], dev, margin=2.0)
     f = ops.Fp8(R, C, dev, fmt=code, state=st[1])

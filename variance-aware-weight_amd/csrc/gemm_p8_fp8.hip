@@ -124,6 +124,70 @@ __global__ void fp8_quantize_kernel(const T* __restrict__ x, int64_t R, int64_t 
     }
 }
 
+// The training step's shapes (bf16 source, R % 64 == 0, C % 128 == 0, both copies wanted, 16-byte aligned rows): 64 x 128
+// tile per workgroup, 16-byte loads, 8-byte q stores (128-byte row segments), and the transposed copy by WORDS: the tile goes
+// to LDS as 4-byte groups, each lane reads a 4 x 4 byte block (four words of four consecutive rows), transposes it in
+// registers with v_perm_b32 and stores four 4-byte groups of qt (16 lanes = one 64-byte row segment).  A quarter of the LDS
+// operations of the byte-gathering kernel above.
+template <bool E5M2>
+__global__ void __launch_bounds__(256)
+fp8_quantize_bf16_tile_kernel(const bf16_t* __restrict__ x, int64_t ld, unsigned char* __restrict__ q, int64_t ldq,
+                              unsigned char* __restrict__ qt, int64_t ldt, const float* __restrict__ scale, float* __restrict__ amax_acc) {
+    __shared__ unsigned tile[64][33];                      // [row][word of 4 columns], +1 word of padding
+    __shared__ float sh[4];
+    const float inv = 1.f / scale[0];
+    const float fmax_ = E5M2 ? 57344.f : 448.f;
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 128;
+    const int tr = threadIdx.x >> 4, c8 = threadIdx.x & 15;
+    float am = 0.f;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int r = pass * 16 + tr;
+        const bf16x8 h = *reinterpret_cast<const bf16x8*>(x + (r0 + r) * ld + c0 + 8 * c8);
+        f32x4 v0 = {(float)h[0], (float)h[1], (float)h[2], (float)h[3]}, v1 = {(float)h[4], (float)h[5], (float)h[6], (float)h[7]};
+        if (amax_acc) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) am = fmaxf(am, fmaxf(fabsf(v0[j]), fabsf(v1[j])));
+            v0 = v0 * inv; v1 = v1 * inv;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v0[j] = __builtin_amdgcn_fmed3f(v0[j], -fmax_, fmax_); v1[j] = __builtin_amdgcn_fmed3f(v1[j], -fmax_, fmax_); }
+        } else {
+            v0 = v0 * inv; v1 = v1 * inv;
+        }
+        const unsigned w0 = fp8_pack4<E5M2>(v0), w1 = fp8_pack4<E5M2>(v1);
+        *reinterpret_cast<uint2*>(q + (r0 + r) * ldq + c0 + 8 * c8) = uint2{w0, w1};
+        tile[r][2 * c8] = w0;
+        tile[r][2 * c8 + 1] = w1;
+    }
+    if (amax_acc) {
+        am = wave_max(am);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = am;
+    }
+    __syncthreads();
+    if (amax_acc && threadIdx.x == 0) {
+        const float m = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+        unsigned* acc = reinterpret_cast<unsigned*>(amax_acc);
+        const unsigned mb = __float_as_uint(m);
+        if (m > 0.f && !(m != m) && mb > __hip_atomic_load(acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(acc, mb);
+    }
+    const int rg = threadIdx.x & 15, cq0 = threadIdx.x >> 4;      // rows 4 rg .. 4 rg + 3; column quads cq0, cq0 + 16
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int cq = cq0 + 16 * pass;
+        const unsigned a = tile[4 * rg][cq], b = tile[4 * rg + 1][cq], c = tile[4 * rg + 2][cq], d = tile[4 * rg + 3][cq];
+        // v_perm_b32(hi, lo, sel): result byte i = byte sel[i] of the 8-byte value {hi, lo} (lo = bytes 0-3)
+        const unsigned ab_lo = __builtin_amdgcn_perm(b, a, 0x05010400), ab_hi = __builtin_amdgcn_perm(b, a, 0x07030602);   // a0 b0 a1 b1 | a2 b2 a3 b3
+        const unsigned cd_lo = __builtin_amdgcn_perm(d, c, 0x05010400), cd_hi = __builtin_amdgcn_perm(d, c, 0x07030602);
+        const unsigned o0 = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x05040100), o1 = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x07060302);
+        const unsigned o2 = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x05040100), o3 = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x07060302);
+        unsigned char* dst = qt + (c0 + 4 * cq) * ldt + r0 + 4 * rg;
+        *reinterpret_cast<unsigned*>(dst) = o0;
+        *reinterpret_cast<unsigned*>(dst + ldt) = o1;
+        *reinterpret_cast<unsigned*>(dst + 2 * ldt) = o2;
+        *reinterpret_cast<unsigned*>(dst + 3 * ldt) = o3;
+    }
+}
+
 // Delayed scaling, once per step for all tensors: state = {scale in use, running max |x|, FMAX / margin, unused}.
 __global__ void fp8_scale_update_kernel(float* __restrict__ states, int64_t n) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -153,6 +217,17 @@ extern "C" int vaw_fp8_quantize(vaw_dtype src_dt, vaw_dtype dst_format, const vo
     const bool e5 = dst_format == VAW_BF8;
     const float fmt_max = e5 ? 57344.f : 448.f;
     unsigned char *qp = (unsigned char*)q, *qtp = (unsigned char*)qt;
+    const bool tiled = src_dt == VAW_BF16 && qt && R % 64 == 0 && C % 128 == 0 && ld % 8 == 0 && ldq % 8 == 0 &&
+                       ((((uintptr_t)src) & 15) == 0) && ((((uintptr_t)q) & 7) == 0);
+    if (tiled) {
+        fp8_amax_partial_kernel<bf16_t><<<(int)nb, 256, 0, s>>>((const bf16_t*)src, R, C, ld, workspace);
+        fp8_amax_final_kernel<<<1, 64, 0, s>>>(workspace, (int)nb, scale_out, fmt_max);
+        dim3 gt((unsigned)(C / 128), (unsigned)(R / 64));
+        if (e5) fp8_quantize_bf16_tile_kernel<true><<<gt, 256, 0, s>>>((const bf16_t*)src, ld, qp, ldq, qtp, ldt, scale_out, nullptr);
+        else fp8_quantize_bf16_tile_kernel<false><<<gt, 256, 0, s>>>((const bf16_t*)src, ld, qp, ldq, qtp, ldt, scale_out, nullptr);
+        VAW_CHECK_LAUNCH("fp8_quantize");
+        return VAW_OK;
+    }
 #define QUANT_GO(T, E5)                                                                                          \
     do {                                                                                                         \
         fp8_amax_partial_kernel<T><<<(int)nb, 256, 0, s>>>((const T*)src, R, C, ld, workspace);                  \
@@ -178,6 +253,15 @@ extern "C" int vaw_fp8_quantize_delayed(vaw_dtype src_dt, vaw_dtype dst_format, 
     dim3 grid((unsigned)((C + 63) / 64), (unsigned)((R + 63) / 64));
     const bool e5 = dst_format == VAW_BF8;
     unsigned char *qp = (unsigned char*)q, *qtp = (unsigned char*)qt;
+    const bool tiled = src_dt == VAW_BF16 && qt && R % 64 == 0 && C % 128 == 0 && ld % 8 == 0 && ldq % 8 == 0 &&
+                       ((((uintptr_t)src) & 15) == 0) && ((((uintptr_t)q) & 7) == 0);
+    if (tiled) {
+        dim3 gt((unsigned)(C / 128), (unsigned)(R / 64));
+        if (e5) fp8_quantize_bf16_tile_kernel<true><<<gt, 256, 0, s>>>((const bf16_t*)src, ld, qp, ldq, qtp, ldt, state, state + 1);
+        else fp8_quantize_bf16_tile_kernel<false><<<gt, 256, 0, s>>>((const bf16_t*)src, ld, qp, ldq, qtp, ldt, state, state + 1);
+        VAW_CHECK_LAUNCH("fp8_quantize_delayed");
+        return VAW_OK;
+    }
 #define QUANT_D(T, E5) fp8_quantize_kernel<T, E5><<<grid, 256, 0, s>>>((const T*)src, R, C, ld, qp, ldq, qtp, ldt, state, state + 1)
     if (src_dt == VAW_F32) { if (e5) QUANT_D(float, true); else QUANT_D(float, false); }
     else { if (e5) QUANT_D(bf16_t, true); else QUANT_D(bf16_t, false); }
