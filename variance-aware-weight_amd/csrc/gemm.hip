@@ -829,8 +829,11 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
         static int bk_env = -1;
         if (bk_env < 0) { const char* v = getenv("VAW_GEMM_BK"); bk_env = v ? atoi(v) : 0; }
         // measured on MI355X (tools/gemm_bench.py, DiT-B/4 shapes): the 32-deep stage (3 workgroups per CU) wins for
-        // the input-gradient layout (k-major x mn-major, 768 output tiles = exactly 3 per CU), the 64-deep one elsewhere
-        const int bkt = bk_env == 32 || bk_env == 64 ? bk_env : ((a_kmajor && !b_kmajor && K <= 4096) ? 32 : 64);
+        // the input-gradient layout (k-major x mn-major) when there are at least ~3 tiles per CU to overlap its K steps
+        // (768 output tiles at batch 256); with fewer tiles (per-GPU batches of 32 / 64 under strong scaling: 96 / 192 tiles)
+        // every K step is exposed latency and the 64-deep stage halves their number (step 7.05 -> 6.46 ms at batch 32)
+        const bool many_tiles = n_wg >= 3 * 256;
+        const int bkt = bk_env == 32 || bk_env == 64 ? bk_env : ((a_kmajor && !b_kmajor && K <= 4096 && many_tiles) ? 32 : 64);
         const int nk_total = (int)(K / bkt);
         const bool fused_rowsum = rowsum_out && !a_kmajor && !colsum_out;     // row sums of A ride on the MFMA kernel
         int split = colsum_out ? 1 : pick_split(n_wg, K, M * N, workspace_floats - (fused_rowsum ? 64 * M : 0), plain_f32);
