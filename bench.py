@@ -394,7 +394,8 @@ def main():
                               "fwd/dgrad/wgrad variants",
                     "bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
                     "traffic_unit": "HBM bytes per launch (PMC, separate passes)",
-                    "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": src,
+                    "frac": round(ach / peak, 4), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": round(sum(v["bytes"] for v in fast.values()) / n_l), "traffic_source": src,
                     "launches_per_step": n_l / traced_steps, "avg_launch_us": round(1e3 * t_ms / n_l, 2),
                     "traced_steps": traced_steps, "traced_where": "extra steps after the timed region",
                     "gemm_share_of_step": round(t_ms / traced_steps / ms, 4),

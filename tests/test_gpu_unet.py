@@ -388,3 +388,39 @@ def test_unet_backward_stage_hooks_tile_the_gradient_buffer():
     for st, snap in snaps:
         assert torch.equal(snap, final[bounds[st][0]:bounds[st][1]]), st
         assert float(snap.abs().max()) > 0
+
+
+@pytest.mark.parametrize("name,size,chans", [("LDM", 32, 4), ("ADM-32", 32, 3), ("UNet-32", 32, 3)])
+def test_other_unet_factories_fp32_vs_oracle(name, size, chans):
+    """The factories no BASELINE config trains (LDM: 4-channel latents, 32-channel heads, mult 1,2,4; ADM-32; UNet-32) on the
+    HIP engine in f32 against the CPU oracle of the same architecture: output and gradients at batch 2."""
+    from oracle import unet as ounet
+    kw = dict(num_classes=10, class_cond=True)
+    torch.manual_seed(3)
+    ref = getattr(ounet, name.replace("-", "_"))(**kw)
+    torch.manual_seed(3)
+    m = getattr(vaw_amd.unet, name.replace("-", "_"))(compute_dtype="fp32", **kw)
+    perturb_(ref, 77, std=0.02)
+    perturb_(m, 77, std=0.02)
+    m = m.to(DEV).train()
+    ref.train()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, chans, size, size, generator=g)
+    t = torch.tensor([17.0, 803.0])
+    y = torch.tensor([3, 7])
+    gout = torch.randn(2, chans, size, size, generator=g)
+    out_r = ref(x, t, y=y)
+    out_r = out_r[0] if isinstance(out_r, tuple) else out_r
+    (out_r * gout).sum().backward()
+    out = m(x.to(DEV), t.to(DEV), y=y.to(DEV))
+    out = out[0] if isinstance(out, tuple) else out
+    (out * gout.to(DEV)).sum().backward()
+    torch.testing.assert_close(out.detach().cpu(), out_r.detach(), rtol=1e-4, atol=1e-5)
+    gr = dict(ref.named_parameters())
+    worst = 0.0
+    for k, p in m.named_parameters():
+        r = gr[k].grad
+        if r is None or float(r.norm()) < 1e-8:
+            continue
+        worst = max(worst, float((p.grad.detach().cpu() - r).norm() / r.norm()))
+    assert worst < 1e-3, worst

@@ -326,3 +326,23 @@ def test_sharded_sampler_equals_torch_distributed_sampler(n, world, shuffle, dro
             seen += list(mine)
         if not drop_last:
             assert set(seen) == set(data)
+
+
+@pytest.mark.parametrize("name", ["UNet-32", "ADM-32", "UNet-64", "LDM"])
+def test_unet_factories_have_the_reference_structure(name):
+    """Every UNet factory of models/unet.py:921-1032 builds (no GPU needed to construct) with the state_dict keys, shapes and
+    parameter count of the oracle's factory (itself pinned to the reference by unet_tiny.pt / bigcfg.pt and the nparams goldens).
+    Conv weights are kept channels-last inside the flat buffer, but the state_dict speaks the reference's [Co][Ci][3][3]."""
+    import vaw_amd
+    from oracle import unet as ounet
+    kw = dict(num_classes=10, class_cond=True)
+    torch.manual_seed(3)
+    ref = getattr(ounet, name.replace("-", "_"))(**kw)
+    torch.manual_seed(3)
+    got = getattr(vaw_amd.unet, name.replace("-", "_"))(compute_dtype="fp32", **kw)
+    sd_r, sd_g = ref.state_dict(), got.state_dict()
+    assert list(sd_r) == list(sd_g)
+    assert all(sd_r[k].shape == sd_g[k].shape for k in sd_r)
+    assert sum(p.numel() for p in ref.parameters()) == sum(p.numel() for p in got.parameters())
+    for k in list(sd_r)[:8] + list(sd_r)[-8:]:       # same seed, same construction order => same initial weights
+        torch.testing.assert_close(sd_g[k], sd_r[k], rtol=0, atol=0)

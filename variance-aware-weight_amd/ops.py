@@ -158,7 +158,10 @@ def gemm(dt, a_kmajor, b_kmajor, M, N, K, A, lda, B, ldb, Cp, ldc, *, bias=None,
                            C.byref(e), ws_ptr, ws_n, stream_ptr()), "vaw_gemm")
     if tr is not None:
         e1.record()
-        tr.add(L.lib().vaw_gemm_uses_bf16_mfma(dt, M, N, K, A, lda, B, ldb), bool(a_kmajor), bool(b_kmajor), M, N, K, e0, e1)
+        es = 2 if dt == BF16 else 4
+        nb = es * (M * K + N * K) + M * N * ((4 if (out_f32 or dt == F32) else 2) + (es if aux_out else 0) + (es if aux_in else 0) +
+                                             ((es if resid_is_act else 4) if resid else 0) + (4 if (beta and out_f32) else 0))
+        tr.add(L.lib().vaw_gemm_uses_bf16_mfma(dt, M, N, K, A, lda, B, ldb), bool(a_kmajor), bool(b_kmajor), M, N, K, e0, e1, float(nb))
 
 
 # ---- fp8 operands ------------------------------------------------------------------------------------
@@ -245,7 +248,8 @@ def gemm_fp8(M, N, K, A, lda, scale_a, B, ldb, scale_b, Cp, ldc, *, a_format=L.F
           "vaw_gemm_fp8")
     if tr is not None:
         e1.record()
-        tr.add(2, True, a_format == L.FP8, M, N, K, e0, e1)
+        nb = M * K + N * K + M * N * ((4 if out_f32 else 2) + (2 if aux_out else 0) + (2 if aux_in else 0) + (4 if resid else 0))
+        tr.add(2, True, a_format == L.FP8, M, N, K, e0, e1, float(nb))
 
 
 class WgradProblem(C.Structure):
@@ -278,7 +282,9 @@ class WgradGroup:
         self.uploaded = True
         if tr is not None:
             e1.record()
-            tr.add_flop(2 if dt in (L.FP8, L.BF8) else 1, False, False, self.flop, e0, e1)
+            es = 1 if dt in (L.FP8, L.BF8) else 2
+            tr.add_flop(2 if dt in (L.FP8, L.BF8) else 1, False, False, self.flop, e0, e1,
+                        float(sum(es * (p.M + p.N) * self.K + 4 * p.M * p.N * (2 if beta else 1) for p in self.table)))
 
 
 def beta_or_plain(bias, act, aux_out, gate, resid, rowadd):
@@ -312,7 +318,8 @@ def conv3x3(dt, mode, act, act2, w, out, B, H, W, Ci, Co, *, bias=None, resid=No
     if tr is not None:
         e1.record()
         M = B * H * W
-        tr.add(1, mode != 2, mode == 0, *((M, Co, 9 * Ci) if mode == 0 else (M, Ci, 9 * Co) if mode == 1 else (Co, 9 * Ci, M)), e0, e1)
+        nb = 2 * M * (Ci + Co) + (2 if mode != 2 else 4 * (2 if beta else 1)) * 9 * Ci * Co + ((2 * M * Co) if (mode == 0 and resid) else 0)
+        tr.add(1, mode != 2, mode == 0, *((M, Co, 9 * Ci) if mode == 0 else (M, Ci, 9 * Co) if mode == 1 else (Co, 9 * Ci, M)), e0, e1, float(nb))
     return True
 
 
@@ -328,20 +335,21 @@ class GemmTrace:
     def events(self):
         return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
-    def add(self, mfma, ak, bk, M, N, K, e0, e1):
-        self.rows.append((mfma, ak, bk, 2.0 * M * N * K, e0, e1))
+    def add(self, mfma, ak, bk, M, N, K, e0, e1, nbytes=0.0):
+        self.rows.append((mfma, ak, bk, 2.0 * M * N * K, e0, e1, nbytes))
 
-    def add_flop(self, mfma, ak, bk, flop, e0, e1):
-        self.rows.append((mfma, ak, bk, flop, e0, e1))
+    def add_flop(self, mfma, ak, bk, flop, e0, e1, nbytes=0.0):
+        self.rows.append((mfma, ak, bk, flop, e0, e1, nbytes))
 
     def summarize(self):
         """-> {variant: {launches, flop, ms}} after a device synchronize."""
         out = {}
-        for mfma, ak, bk, flop, e0, e1 in self.rows:
+        for mfma, ak, bk, flop, e0, e1, nbytes in self.rows:
             name = ("fp8_mfma" if mfma == 2 else "bf16_mfma" if mfma else "generic_f32mfma") + ("/fwd" if ak and bk else "/dgrad" if ak else "/wgrad")
-            d = out.setdefault(name, {"launches": 0, "flop": 0.0, "ms": 0.0})
+            d = out.setdefault(name, {"launches": 0, "flop": 0.0, "ms": 0.0, "bytes": 0.0})
             d["launches"] += 1
             d["flop"] += flop
+            d["bytes"] += nbytes          # algorithmic: every operand and result once
             d["ms"] += e0.elapsed_time(e1)
         return out
 
