@@ -837,6 +837,18 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
         const int nk_total = (int)(K / bkt);
         const bool fused_rowsum = rowsum_out && !a_kmajor && !colsum_out;     // row sums of A ride on the MFMA kernel
         int split = colsum_out ? 1 : pick_split(n_wg, K, M * N, workspace_floats - (fused_rowsum ? 64 * M : 0), plain_f32);
+        // small-M input gradients (per-GPU batches of 32 / 64 under strong scaling: 96-192 tiles, K up to 3072): with one
+        // workgroup per CU every K step is exposed DMA latency, so a plain bf16 result is K-split as well (f32 slabs, fixed-order
+        // reduce that writes bf16) when K is long enough to pay for the slab round trip
+        const bool plain_bf16 = !e.out_f32 && !e.bias && !e.act && !e.aux_out && !e.gate && !e.resid && !e.rowadd && e.beta == 0.f &&
+                                N % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)C & 7) == 0;
+        if (split == 1 && plain_bf16 && !colsum_out && !rowsum_out && workspace && K >= 2048 && n_wg <= 256) {
+            int64_t sp = 512 / n_wg;
+            if (sp > K / 512) sp = K / 512;
+            if (sp > workspace_floats / (M * N)) sp = workspace_floats / (M * N);
+            if (sp > 8) sp = 8;
+            if (sp >= 2) split = (int)sp;
+        }
         if (colsum_out) e.colpart = workspace;
         if (split > 1) {   // no empty splits
             const int per = (nk_total + split - 1) / split;
@@ -935,7 +947,10 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
         }
         if (bkt == 32) LAUNCH_FAST_BK(32);
         else LAUNCH_FAST_BK(64);
-        if (split > 1)
+        if (split > 1 && !e.out_f32)
+            splitk_reduce_kernel<bf16_t><<<ceil_div(M * N / 4, 256) > 2048 ? 2048 : ceil_div(M * N / 4, 256), 256, 0, s>>>(
+                workspace, split, M, N, ldc, C, e.alpha, 0.f, 0);
+        else if (split > 1)
             splitk_reduce_kernel<float><<<ceil_div(M * N / 4, 256) > 2048 ? 2048 : ceil_div(M * N / 4, 256), 256, 0, s>>>(
                 workspace, split, M, N, ldc, C, e.alpha, e.beta, 1, rowpart, rowsum_out, rowsum_beta);
         VAW_CHECK_LAUNCH("gemm_bf16");

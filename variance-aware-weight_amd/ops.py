@@ -151,7 +151,7 @@ def gemm(dt, a_kmajor, b_kmajor, M, N, K, A, lda, B, ldb, Cp, ldc, *, bias=None,
         e0, e1 = tr.events()
         e0.record()
     ws_ptr, ws_n = 0, 0
-    if colsum_out or rowsum_a_out or (out_f32 and beta_or_plain(bias, act, aux_out, gate, resid, rowadd) and K >= 2048):
+    if colsum_out or rowsum_a_out or (beta_or_plain(bias, act, aux_out, gate, resid, rowadd) and K >= 2048):     # may run split-K
         ws = scratch_f32(torch.device("cuda", torch.cuda.current_device()), 0)
         ws_ptr, ws_n = ws.data_ptr(), ws.numel()
     check(L.lib().vaw_gemm(dt, 1 if a_kmajor else 0, 1 if b_kmajor else 0, M, N, K, A, lda, B, ldb, Cp, ldc,
