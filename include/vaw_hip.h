@@ -171,10 +171,16 @@ int vaw_fp8_scale_update(float* states, int64_t n, vaw_stream stream);
  * block scales; C and the epilogue operands as for vaw_gemm with dt = VAW_BF16 (bf16 C / aux, or f32 C with out_f32).
  * Epilogues offered: bias (+ colsum_out), either A format; GELU' (+ colsum_out), either; bias + aux_out + GELU and bias +
  * aux_out + gate + f32 residual, e4m3 A.  Others return VAW_ERR_UNSUPPORTED.
- * Weight gradients: vaw_wgrad_grouped with dt = VAW_FP8 (dy^T, x^T e4m3) or VAW_BF8 (dy^T e5m2, x^T e4m3). */
+ * Weight gradients: vaw_wgrad_grouped with dt = VAW_FP8 (dy^T, x^T e4m3) or VAW_BF8 (dy^T e5m2, x^T e4m3).
+ * c_fp8_state != NULL (GELU and GELU' epilogues only): C is written as fp8 BYTES of c_fp8_format (row stride ldc bytes) -- the bf16
+ * rounding of each value, divided by the scale in c_fp8_state[0] and saturated, exactly what vaw_fp8_quantize_delayed would make
+ * of the bf16 tensor -- and the tensor's max |x| is folded into c_fp8_state[1]; vaw_fp8_transpose then provides the transposed
+ * copy.  For fp8 mode's fc1 output and fc2 input gradient, whose bf16 forms have no other reader. */
 int vaw_gemm_fp8(vaw_dtype a_format, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const float* scale_a,
                  const void* B, int64_t ldb, const float* scale_b, void* C, int64_t ldc, const vaw_epilogue* epi_host,
-                 float* workspace, int64_t workspace_floats, vaw_stream stream);
+                 float* c_fp8_state, vaw_dtype c_fp8_format, float* workspace, int64_t workspace_floats, vaw_stream stream);
+/* qt[c][r] = q[r][c] for fp8 bytes; R % 64 == 0, C % 128 == 0, ldq % 8 == 0, ldt % 4 == 0. */
+int vaw_fp8_transpose(const void* q, int64_t R, int64_t C, int64_t ldq, void* qt, int64_t ldt, vaw_stream stream);
 
 /* 1 when vaw_gemm would run these operands on the bf16 MFMA kernel (M%128==0, N%128==0, K%64==0, 16-byte
  * aligned rows), 0 when it takes the exact-f32 generic kernel.  For measurement and tests. */

@@ -225,3 +225,32 @@ def test_dit_fp8_training_tracks_bf16():
     assert a[-1] < 0.8 * a[0] and b[-1] < 0.8 * b[0]
     assert max(abs(x - y) / x for x, y in zip(a, b)) < 5e-2
     assert b == b2           # the delayed-scaling state machine (atomic max of |x| bits) is deterministic
+
+
+def test_dit_fp8_fused_epilogue_quantisation_is_bitwise_the_separate_quantiser():
+    """fp8 mode with delayed scaling: writing `a` and d hidden as fp8 from the GELU / GELU' epilogues must reproduce, bit for bit,
+    the run that writes them as bf16 and quantises them in a separate pass (same scales, same bytes, same running maxima)."""
+    def run(fuse):
+        random.seed(3); np.random.seed(3); torch.manual_seed(3)
+        m = vaw_amd.DiT(image_size=32, patch_size=4, in_channels=4, hidden_size=768, depth=3, num_heads=12, class_dropout_prob=0.0,
+                        num_classes=10, compute_dtype="fp8")
+        m.fp8_fuse_epilogue = fuse
+        perturb_(m, 7, std=0.02)
+        m = m.to(DEV).train()
+        opt = vaw_amd.FusedAdamW(m, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.0, eps=1e-8)
+        diff = _diffusion(_args(dict(kind="dit", classes=10, size=32)))
+        g = torch.Generator().manual_seed(1)
+        x0 = (torch.randn(16, 4, 32, 32, generator=g) * 0.5).to(DEV)
+        noise = torch.randn(16, 4, 32, 32, generator=g).to(DEV)
+        t = torch.randint(0, 1000, (16,), generator=g).to(DEV)
+        y = torch.randint(0, 10, (16,), generator=g).to(DEV)
+        losses = []
+        for _ in range(4):                  # step 1 measures the scales just in time; steps 2-4 run delayed (and fused)
+            opt.zero_grad()
+            terms = diff.training_losses(m, x0, None, t=t, model_kwargs={"y": y}, noise=noise)
+            terms["loss"].mean().backward()
+            opt.step()
+            losses.append(terms["mse"].detach().cpu())
+        return torch.stack(losses), m._flat.detach().cpu().clone()
+    (la, pa), (lb, pb) = run(True), run(False)
+    assert torch.equal(la, lb) and torch.equal(pa, pb)

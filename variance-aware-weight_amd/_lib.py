@@ -78,7 +78,8 @@ _PROTOS = {
     "vaw_fp8_quantize": [_i, _i, _p, _l, _l, _l, _p, _l, _p, _l, _p, _p, _l, _p],
     "vaw_fp8_quantize_delayed": [_i, _i, _p, _l, _l, _l, _p, _l, _p, _l, _p, _p],
     "vaw_fp8_scale_update": [_p, _l, _p],
-    "vaw_gemm_fp8": [_i, _l, _l, _l, _p, _l, _p, _p, _l, _p, _p, _l, C.POINTER(Epilogue), _p, _l, _p],
+    "vaw_gemm_fp8": [_i, _l, _l, _l, _p, _l, _p, _p, _l, _p, _p, _l, C.POINTER(Epilogue), _p, _i, _p, _l, _p],
+    "vaw_fp8_transpose": [_p, _l, _l, _l, _p, _l, _p],
 }
 
 _lib = None

@@ -26,6 +26,9 @@ struct EpiDev {
     float* rowpart;   // mn-major A only (CONV 3 / plain weight gradients): [n_split][M] f32 partial row sums of A = dy^T
                       // over this split's K range (the layer's bias gradient)
     float* colpart;   // [M/128][N] f32: per-row-tile column sums of the OUTPUT (bias gradient of the next layer), or NULL
+    float* q_state;   // fp8 OUTPUT (P8_GELU_Q / P8_DGELU_Q): the tensor's delayed-scaling state {scale in use, running max |x|}
+    int q_e5m2;       // its format: 0 e4m3, 1 e5m2
+    float q_inv;      // filled in by the kernel: 1 / q_state[0]
 };
 
 // Streaming (non-temporal) 16-byte stores for the epilogue: the output tile is written once and not re-read by this
@@ -168,20 +171,23 @@ enum { P8_STORE = 0,   // value = acc*alpha (+ bias) -> C (act dtype or f32)    
        P8_SLAB = 4,    // raw f32 partial sums of one K split                                     weight gradients
        P8_ANY = 5,
        P8_WGRAD = 6,   // weight gradients: whole tiles C = beta * C + acc (f32), K-split tiles raw into their slab
-       P8_RESID = 7 }; // (+ bias) + resid (act dtype) -> C (bf16)                                  conv forward with a fused skip add
+       P8_RESID = 7,   // (+ bias) + resid (act dtype) -> C (bf16)                                  conv forward with a fused skip add
+       P8_GELU_Q = 8,  // P8_GELU with C written as fp8 bytes (the bf16 rounding of the value, scaled by 1 / q_state[0], saturated),
+       P8_DGELU_Q = 9 };// P8_DGELU likewise: fp8 mode's `a` and `dhid`, whose bf16 forms nobody else reads; running max |x| -> q_state[1]
 template <int EPI> struct EpiKind {
-    static __device__ __forceinline__ bool act1(const EpiDev& e) { return EPI == P8_GELU || (EPI == P8_ANY && e.act == 1); }
-    static __device__ __forceinline__ bool act2(const EpiDev& e) { return EPI == P8_DGELU || (EPI == P8_ANY && e.act == 2); }
+    static __device__ __forceinline__ bool act1(const EpiDev& e) { return EPI == P8_GELU || EPI == P8_GELU_Q || (EPI == P8_ANY && e.act == 1); }
+    static __device__ __forceinline__ bool act2(const EpiDev& e) { return EPI == P8_DGELU || EPI == P8_DGELU_Q || (EPI == P8_ANY && e.act == 2); }
     static __device__ __forceinline__ bool gate(const EpiDev& e) { return EPI == P8_GATE || (EPI == P8_ANY && e.gate != nullptr); }
     static __device__ __forceinline__ bool resid(const EpiDev& e) { return EPI == P8_GATE || EPI == P8_RESID || (EPI == P8_ANY && e.resid != nullptr); }
     static __device__ __forceinline__ bool resid_act(const EpiDev& e) { return EPI == P8_RESID || (EPI == P8_ANY && e.resid_act); }
     static __device__ __forceinline__ bool rowadd(const EpiDev& e) { return EPI == P8_ANY && e.rowadd != nullptr; }
-    static __device__ __forceinline__ bool aux_out(const EpiDev& e) { return EPI == P8_GELU || EPI == P8_GATE || (EPI == P8_ANY && e.aux_out != nullptr); }
+    static __device__ __forceinline__ bool aux_out(const EpiDev& e) { return EPI == P8_GELU || EPI == P8_GELU_Q || EPI == P8_GATE || (EPI == P8_ANY && e.aux_out != nullptr); }
     static __device__ __forceinline__ bool out_f32(const EpiDev& e) { return EPI == P8_GATE || EPI == P8_WGRAD || ((EPI == P8_ANY || EPI == P8_STORE) && e.out_f32); }
     static __device__ __forceinline__ bool beta(const EpiDev& e) { return (EPI == P8_ANY || EPI == P8_WGRAD) && e.beta != 0.f; }
-    static __device__ __forceinline__ bool colsum(const EpiDev& e) { return (EPI == P8_DGELU || EPI == P8_STORE || EPI == P8_ANY) && e.colpart != nullptr; }
-    static constexpr bool may_colsum = EPI == P8_DGELU || EPI == P8_STORE || EPI == P8_ANY;   // the sums are then always carried
-    static constexpr bool loads = EPI == P8_DGELU || EPI == P8_GATE || EPI == P8_RESID || EPI == P8_ANY;     // epi_load8 has something to fetch
+    static __device__ __forceinline__ bool colsum(const EpiDev& e) { return (EPI == P8_DGELU || EPI == P8_DGELU_Q || EPI == P8_STORE || EPI == P8_ANY) && e.colpart != nullptr; }
+    static constexpr bool may_colsum = EPI == P8_DGELU || EPI == P8_DGELU_Q || EPI == P8_STORE || EPI == P8_ANY;   // the sums are then always carried
+    static constexpr bool out_q = EPI == P8_GELU_Q || EPI == P8_DGELU_Q;                      // C is fp8 bytes
+    static constexpr bool loads = EPI == P8_DGELU || EPI == P8_DGELU_Q || EPI == P8_GATE || EPI == P8_RESID || EPI == P8_ANY;     // epi_load8 has something to fetch
 };
 // Two operand slots: x = GELU'-argument (act == 2) or gate; y = residual or row-add (each pair is mutually exclusive in every
 // launch of the training step; the dispatcher keeps launches that set both members of a pair on the other kernel).
@@ -250,7 +256,7 @@ __device__ __forceinline__ void buf_store16(__amdgpu_buffer_rsrc_t rs, unsigned 
 // The beta read (P8_ANY) uses the plain pointer c_row = address of that row group when valid.
 template <int EPI>
 __device__ __forceinline__ void epi_apply8(const EpiDev& e, __amdgpu_buffer_rsrc_t rs_c, __amdgpu_buffer_rsrc_t rs_aux, int loc,
-                                           const float* c_f32, f32x4& v0, f32x4& v1, f32x4 b0, f32x4 b1, const EpiOps& o) {
+                                           const float* c_f32, f32x4& v0, f32x4& v1, f32x4 b0, f32x4 b1, const EpiOps& o, float& qmax) {
     using K = EpiKind<EPI>;
     const bool ok = loc >= 0;
     v0 = v0 * e.alpha + b0;
@@ -283,10 +289,34 @@ __device__ __forceinline__ void epi_apply8(const EpiDev& e, __amdgpu_buffer_rsrc
         buf_store16(rs_c, ok ? bo + 16u : EPI_OOB, v1, !e.nt_off);
     } else {
         bf16x8 r = {(bf16_t)v0[0], (bf16_t)v0[1], (bf16_t)v0[2], (bf16_t)v0[3], (bf16_t)v1[0], (bf16_t)v1[1], (bf16_t)v1[2], (bf16_t)v1[3]};
-        buf_store16(rs_c, ok ? 2u * (unsigned)loc : EPI_OOB, r, !e.nt_off);
-        if (K::may_colsum) {
-            v0 = f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};   // what a later reader of C sees
+        if (K::out_q) {
+            // exactly what vaw_fp8_quantize_delayed makes of the bf16 tensor this launch would otherwise have written
+            v0 = f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
             v1 = f32x4{(float)r[4], (float)r[5], (float)r[6], (float)r[7]};
+            if (ok) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) qmax = fmaxf(qmax, fmaxf(fabsf(v0[j]), fabsf(v1[j])));
+            }
+            const float fm = e.q_e5m2 ? 57344.f : 448.f;
+            f32x4 q0 = v0 * e.q_inv, q1 = v1 * e.q_inv;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { q0[j] = __builtin_amdgcn_fmed3f(q0[j], -fm, fm); q1[j] = __builtin_amdgcn_fmed3f(q1[j], -fm, fm); }
+            unsigned w0 = 0, w1 = 0;
+            if (e.q_e5m2) {
+                w0 = __builtin_amdgcn_cvt_pk_bf8_f32(q0[0], q0[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_bf8_f32(q0[2], q0[3], w0, true);
+                w1 = __builtin_amdgcn_cvt_pk_bf8_f32(q1[0], q1[1], w1, false); w1 = __builtin_amdgcn_cvt_pk_bf8_f32(q1[2], q1[3], w1, true);
+            } else {
+                w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q0[0], q0[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q0[2], q0[3], w0, true);
+                w1 = __builtin_amdgcn_cvt_pk_fp8_f32(q1[0], q1[1], w1, false); w1 = __builtin_amdgcn_cvt_pk_fp8_f32(q1[2], q1[3], w1, true);
+            }
+            typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{w0, w1}, rs_c, ok ? (unsigned)loc : EPI_OOB, 0, 0);
+        } else {
+            buf_store16(rs_c, ok ? 2u * (unsigned)loc : EPI_OOB, r, !e.nt_off);
+            if (K::may_colsum) {
+                v0 = f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};   // what a later reader of C sees
+                v1 = f32x4{(float)r[4], (float)r[5], (float)r[6], (float)r[7]};
+            }
         }
     }
 }

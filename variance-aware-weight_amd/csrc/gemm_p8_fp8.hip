@@ -188,6 +188,46 @@ fp8_quantize_bf16_tile_kernel(const bf16_t* __restrict__ x, int64_t ld, unsigned
     }
 }
 
+// qt[c][r] = q[r][c] for fp8 bytes (R % 64 == 0, C % 128 == 0): the transposed copy of a tensor that a GEMM epilogue already
+// wrote as fp8 (vaw_gemm_fp8 with c_fp8_state).  Same word-wise LDS transposition as fp8_quantize_bf16_tile_kernel.
+__global__ void __launch_bounds__(256)
+fp8_transpose_kernel(const unsigned char* __restrict__ q, int64_t ldq, unsigned char* __restrict__ qt, int64_t ldt) {
+    __shared__ unsigned tile[64][33];
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 128;
+    const int tr = threadIdx.x >> 4, c8 = threadIdx.x & 15;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int r = pass * 16 + tr;
+        const uint2 w = *reinterpret_cast<const uint2*>(q + (r0 + r) * ldq + c0 + 8 * c8);
+        tile[r][2 * c8] = w.x;
+        tile[r][2 * c8 + 1] = w.y;
+    }
+    __syncthreads();
+    const int rg = threadIdx.x & 15, cq0 = threadIdx.x >> 4;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int cq = cq0 + 16 * pass;
+        const unsigned a = tile[4 * rg][cq], b = tile[4 * rg + 1][cq], c = tile[4 * rg + 2][cq], d = tile[4 * rg + 3][cq];
+        const unsigned ab_lo = __builtin_amdgcn_perm(b, a, 0x05010400), ab_hi = __builtin_amdgcn_perm(b, a, 0x07030602);
+        const unsigned cd_lo = __builtin_amdgcn_perm(d, c, 0x05010400), cd_hi = __builtin_amdgcn_perm(d, c, 0x07030602);
+        unsigned char* dst = qt + (c0 + 4 * cq) * ldt + r0 + 4 * rg;
+        *reinterpret_cast<unsigned*>(dst) = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x05040100);
+        *reinterpret_cast<unsigned*>(dst + ldt) = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x07060302);
+        *reinterpret_cast<unsigned*>(dst + 2 * ldt) = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x05040100);
+        *reinterpret_cast<unsigned*>(dst + 3 * ldt) = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x07060302);
+    }
+}
+
+extern "C" int vaw_fp8_transpose(const void* q, int64_t R, int64_t C, int64_t ldq, void* qt, int64_t ldt, vaw_stream stream) {
+    VAW_CHECK_ARG(q && qt && R > 0 && C > 0 && R % 64 == 0 && C % 128 == 0 && ldq >= C && ldq % 8 == 0 && ldt >= R && ldt % 4 == 0,
+                  "fp8_transpose: R %% 64, C %% 128, ldq %% 8, ldt %% 4");
+    VAW_CHECK_ARG((((uintptr_t)q) & 7) == 0 && (((uintptr_t)qt) & 3) == 0, "fp8_transpose: alignment");
+    dim3 grid((unsigned)(C / 128), (unsigned)(R / 64));
+    fp8_transpose_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const unsigned char*)q, ldq, (unsigned char*)qt, ldt);
+    VAW_CHECK_LAUNCH("fp8_transpose");
+    return VAW_OK;
+}
+
 // Delayed scaling, once per step for all tensors: state = {scale in use, running max |x|, FMAX / margin, unused}.
 __global__ void fp8_scale_update_kernel(float* __restrict__ states, int64_t n) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -278,8 +318,8 @@ extern "C" int vaw_fp8_scale_update(float* states, int64_t n, vaw_stream stream)
 
 // ---- GEMM ---------------------------------------------------------------------------------------------------------------
 extern "C" int vaw_gemm_fp8(vaw_dtype a_format, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const float* scale_a, const void* B, int64_t ldb,
-                            const float* scale_b, void* C, int64_t ldc, const vaw_epilogue* ep, float* workspace, int64_t workspace_floats,
-                            vaw_stream stream) {
+                            const float* scale_b, void* C, int64_t ldc, const vaw_epilogue* ep, float* c_fp8_state, vaw_dtype c_fp8_format,
+                            float* workspace, int64_t workspace_floats, vaw_stream stream) {
     VAW_CHECK_ARG(a_format == VAW_FP8 || a_format == VAW_BF8, "gemm_fp8: a_format VAW_FP8 (e4m3) or VAW_BF8 (e5m2)");
     VAW_CHECK_ARG(M >= 16 && N >= 16 && K > 0 && K % 128 == 0 && A && B && C, "gemm_fp8: sizes (K %% 128 == 0)");
     VAW_CHECK_ARG(lda >= K && ldb >= K && ldc >= N && lda % 16 == 0 && ldb % 16 == 0 && N % 8 == 0 && ldc % 8 == 0, "gemm_fp8: leading dimensions");
@@ -308,8 +348,12 @@ extern "C" int vaw_gemm_fp8(vaw_dtype a_format, int64_t M, int64_t N, int64_t K,
     const int bn = 64 * pl.ntw, tiles_m = (int)((M + 255) / 256), tiles_n = (int)((N + bn - 1) / bn), nk = (int)(K / 128);
     int epi;
     const bool bf16_out = !e.out_f32;
-    if (e.act == 1 && e.aux_out && !e.gate && !e.resid && !e.rowadd && bf16_out && !e.colpart) epi = P8_GELU;
-    else if (e.act == 2 && !e.bias && !e.aux_out && !e.gate && !e.resid && !e.rowadd && bf16_out) epi = P8_DGELU;
+    e.q_state = c_fp8_state;
+    e.q_e5m2 = c_fp8_format == VAW_BF8;
+    VAW_CHECK_ARG(!c_fp8_state || ((c_fp8_format == VAW_FP8 || c_fp8_format == VAW_BF8) && bf16_out && (e.act == 1 || e.act == 2) && ldc % 8 == 0),
+                  "gemm_fp8: fp8 output is offered for the GELU / GELU' epilogues (C then holds bytes, row stride ldc bytes)");
+    if (e.act == 1 && e.aux_out && !e.gate && !e.resid && !e.rowadd && bf16_out && !e.colpart) epi = c_fp8_state ? P8_GELU_Q : P8_GELU;
+    else if (e.act == 2 && !e.bias && !e.aux_out && !e.gate && !e.resid && !e.rowadd && bf16_out) epi = c_fp8_state ? P8_DGELU_Q : P8_DGELU;
     else if (e.act == 0 && e.gate && e.resid && !e.resid_act && e.aux_out && !e.rowadd && e.out_f32 && e.beta == 0.f && !e.colpart) epi = P8_GATE;
     else if (e.act == 0 && !e.aux_out && !e.gate && !e.resid && !e.rowadd && e.beta == 0.f) epi = P8_STORE;
     else {
@@ -326,10 +370,12 @@ extern "C" int vaw_gemm_fp8(vaw_dtype a_format, int64_t M, int64_t N, int64_t K,
     const bool e5 = a_format == VAW_BF8;
     if (epi == P8_STORE) { if (e5) F8_GO(P8_STORE, 2); else F8_GO(P8_STORE, 1); }
     else if (epi == P8_DGELU) { if (e5) F8_GO(P8_DGELU, 2); else F8_GO(P8_DGELU, 1); }
+    else if (epi == P8_DGELU_Q) { if (e5) F8_GO(P8_DGELU_Q, 2); else F8_GO(P8_DGELU_Q, 1); }
     else if (e5) {
         vaw_set_error("gemm_fp8: the forward epilogues (GELU, gated residual) take e4m3 activations");
         return VAW_ERR_UNSUPPORTED;
     } else if (epi == P8_GELU) F8_GO(P8_GELU, 1);
+    else if (epi == P8_GELU_Q) F8_GO(P8_GELU_Q, 1);
     else F8_GO(P8_GATE, 1);
     VAW_CHECK_LAUNCH("gemm_fp8");
     if (colsum_out) return vaw_reduce_rows(workspace, (M + 127) / 128, N, colsum_out, ep->colsum_beta, stream);

@@ -414,6 +414,7 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
             if (ei.scale_a) ei.alpha *= *ei.scale_a;
             if (ei.scale_b) ei.alpha *= *ei.scale_b;
         }
+        if (EPI == P8_GELU_Q || EPI == P8_DGELU_Q) ei.q_inv = 1.f / ei.q_state[0];
         f32x4 acc[8][NTW];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -578,7 +579,7 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
         const int64_t n_ld = col_ok ? n : n0;
         const int64_t m_last = ei.M - 1;
         f32x4 b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
-        if (EPI != P8_SLAB && EPI != P8_DGELU && EPI != P8_WGRAD && ei.bias) {
+        if (EPI != P8_SLAB && EPI != P8_DGELU && EPI != P8_DGELU_Q && EPI != P8_WGRAD && ei.bias) {
             b0 = load4(ei.bias + n_ld);
             b1 = load4(ei.bias + n_ld + 4);
             asm volatile("" ::"v"(b0), "v"(b1));   // the compiler waits for the bias HERE, once (this drains the DMA prefetch of
@@ -586,6 +587,7 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
                                                    // every step, which would drain the stores of the step before
         }
         f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
+        float qmax = 0.f;                     // fp8 output kinds: max |x| of this lane's share of the tile
         // output buffers based at the tile's first element (m0, n0); loc_col = this lane's column offset in the tile
         const int loc_col = wn0 + 8 * rd_c8;
         const bool c_f32 = EK::out_f32(ei);
@@ -597,7 +599,8 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
         const __amdgpu_buffer_rsrc_t rs_c =
             to_slab ? epi_rsrc(GRP ? grp.slab + ((int64_t)split * grp.t_rem + item.rem) * (P8_BM * Cfg::BN)
                                    : ei.slab + (int64_t)split * ei.M * ei.N + m0 * ei.N + n0)
-                    : epi_rsrc(c_f32 ? (const void*)((const float*)ei.C + tile_off) : (const void*)((const bf16_t*)ei.C + tile_off));
+                    : epi_rsrc(EK::out_q ? (const void*)((const unsigned char*)ei.C + tile_off)
+                                         : c_f32 ? (const void*)((const float*)ei.C + tile_off) : (const void*)((const bf16_t*)ei.C + tile_off));
         const __amdgpu_buffer_rsrc_t rs_aux = epi_rsrc(EK::aux_out(ei) ? (const void*)((const bf16_t*)ei.aux_out + tile_off) : (const void*)ei.C);
         // rows of this lane, step k = 2 i + pass: m = mrow0 + 8 k; (sample, row in sample) carried along for gate / rowadd
         const int64_t mrow0 = m0 + wr * 128 + rd_row;
@@ -650,7 +653,7 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
                     buf_store16(rs_c, ok ? bo + 16u : EPI_OOB, v1, false);
                 } else {
                     const int64_t mc = m <= m_last ? m : m_last;
-                    epi_apply8<EPI>(ei, rs_c, rs_aux, loc, (const float*)ei.C + mc * ei.ldc + n_ld, v0, v1, b0, b1, ops[k & 1]);
+                    epi_apply8<EPI>(ei, rs_c, rs_aux, loc, (const float*)ei.C + mc * ei.ldc + n_ld, v0, v1, b0, b1, ops[k & 1], qmax);
                     if (EK::may_colsum) {      // unconditional arithmetic (a run-time condition here makes the compiler keep
                                                // all 16 steps' values alive and sum them at the end: spills)
                         const f32x4 z = {0, 0, 0, 0};
@@ -661,6 +664,14 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);   // keep the 16 unrolled steps apart: hoisting across them spills
+            }
+        }
+        if (EK::out_q) {       // this wave's max |x| -> the tensor's running max (integer atomic max on the bits; look first)
+            qmax = wave_max(qmax);
+            if (lane_e == 0 && qmax > 0.f && !(qmax != qmax)) {
+                unsigned* acc_q = reinterpret_cast<unsigned*>(ei.q_state + 1);
+                const unsigned mb = __float_as_uint(qmax);
+                if (mb > __hip_atomic_load(acc_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(acc_q, mb);
             }
         }
         if (EK::colsum(ei)) {

@@ -208,6 +208,9 @@ class DiT(FlatModule):
         # fp8 scales: "delayed" = each tensor's scale comes from its max |x| of the previous step (x margin), taken by the
         # quantiser itself -- one pass per tensor; the first step, and "jit" always, measure the tensor first (two passes)
         self.fp8_scaling, self.fp8_margin = "delayed", 2.0
+        # with delayed scaling, fc1's GELU epilogue and fc2's GELU' epilogue write their results (`a`, d hidden) as fp8 themselves --
+        # byte-identical to quantising the bf16 tensor, which is then never written or read
+        self.fp8_fuse_epilogue = True
         self._fp8_w, self._fp8_epoch, self._fp8_wstates = {}, None, None
         self.set_compute_dtype(compute_dtype)
         self._anchor = torch.zeros(1, requires_grad=True)
@@ -419,9 +422,11 @@ class DiT(FlatModule):
             self._linear_fwd(ws, b, "f_ao", b["ao"], pre + "attn.proj.", M, D, D, xmid, D, aux_out=ptr(b["y1"]), gate=mo + 4 * 2 * D,
                              gate_ld=ld, resid=xin, rows_per_batch=T, out_f32=True)
             ops.ln_modulate_fwd(dt, xmid, mo + 4 * 3 * D, mo + 4 * 4 * D, ld, ptr(b["xm2"]), ptr(b["mean2"]), ptr(b["rstd2"]), B, T, D)
-            self._linear_fwd(ws, b, "f_xm2", b["xm2"], pre + "mlp.fc1.", M, Dm, D, ptr(b["a"]), Dm, act=1, aux_out=ptr(b["hpre"]))
-            self._linear_fwd(ws, b, "f_a", b["a"], pre + "mlp.fc2.", M, D, Dm, xout, D, aux_out=ptr(b["y2"]), gate=mo + 4 * 5 * D,
-                             gate_ld=ld, resid=xmid, rows_per_batch=T, out_f32=True)
+            fuse_a = ws.fp8 and ws.d_fwd and self.fp8_fuse_epilogue and M % 64 == 0      # fc1's epilogue writes `a` as e4m3 itself
+            self._linear_fwd(ws, b, "f_xm2", b["xm2"], pre + "mlp.fc1.", M, Dm, D, b["f_a"].epilogue_target() if fuse_a else ptr(b["a"]), Dm,
+                             act=1, aux_out=ptr(b["hpre"]), **({"out_fp8": b["f_a"]} if fuse_a else {}))
+            self._linear_fwd(ws, b, "f_a", None if fuse_a else b["a"], pre + "mlp.fc2.", M, D, Dm, xout, D, aux_out=ptr(b["y2"]),
+                             gate=mo + 4 * 5 * D, gate_ld=ld, resid=xmid, rows_per_batch=T, out_f32=True)
         mo = mod + 4 * (6 * Lyr * D)
         ops.ln_modulate_fwd(dt, ptr(ws.xres[2 * Lyr]), mo, mo + 4 * D, ld, ptr(ws.xf), ptr(ws.meanf), ptr(ws.rstdf), B, T, D)
         ops.gemm(dt, 1, 1, M, self.No, D, ptr(ws.xf), D, self._w("final_layer.linear.weight"), D, ptr(ws.otok), self.No,
@@ -438,7 +443,9 @@ class DiT(FlatModule):
         if not ws.fp8:
             ops.gemm(self._dt, 1, 1, M, N, K, ptr(x), K, self._w(name + "weight"), K, out, ldc, bias=self._p32(name + "bias"), **epi)
             return
-        f, w = b[fkey].quantize(x, delayed=ws.d_fwd), self._fp8_w[name + "weight"]
+        # x is None: the producing GEMM's epilogue already left the row-major fp8 bytes (and the running max) in b[fkey]
+        f = b[fkey].quantize(x, delayed=ws.d_fwd) if x is not None else b[fkey].transpose_from_q()
+        w = self._fp8_w[name + "weight"]
         ops.gemm_fp8(M, N, K, f.last_q, K, ptr(f.scale), ptr(w.q), K, ptr(w.scale), out, ldc, bias=self._p32(name + "bias"), **epi)
 
     def _linear_dgrad(self, ws, b, fkey, dy, name, M, N, K, out, **epi):
@@ -446,7 +453,8 @@ class DiT(FlatModule):
         if not ws.fp8:
             ops.gemm(self._dt, 1, 0, M, K, N, ptr(dy) if isinstance(dy, torch.Tensor) else dy, N, self._w(name + "weight"), K, out, K, **epi)
             return
-        f, w = b[fkey].quantize(dy, src_dt=BF16, delayed=ws.d_bwd), self._fp8_w[name + "weight"]
+        f = b[fkey].quantize(dy, src_dt=BF16, delayed=ws.d_bwd) if dy is not None else b[fkey].transpose_from_q()
+        w = self._fp8_w[name + "weight"]
         ops.gemm_fp8(M, K, N, f.last_q, N, ptr(f.scale), ptr(w.qt), N, ptr(w.scale), out, K, a_format=f.fmt, **epi)
 
     def _attn_desc(self, B):
@@ -539,11 +547,13 @@ class DiT(FlatModule):
             ops.reduce_rows(colpart, B, D, self._g(pre + "mlp.fc2.bias"), beta)
             if not defer:
                 self._wgrad(dt, pre + "mlp.fc2.", dy2, ptr(b["a"]), D, Dm, M, beta, bias=False)
-            self._linear_dgrad(ws, b, "f_dy2", dy2, pre + "mlp.fc2.", M, D, Dm, dhid, act=2, aux_in=ptr(b["hpre"]),
-                               colsum_out=self._g(pre + "mlp.fc1.bias"), colsum_beta=beta)
+            fuse_dh = fp8 and ws.d_bwd and self.fp8_fuse_epilogue and M % 64 == 0       # fc2's input-gradient epilogue writes dhid as fp8
+            self._linear_dgrad(ws, b, "f_dy2", dy2, pre + "mlp.fc2.", M, D, Dm, b["f_dhid"].epilogue_target() if fuse_dh else dhid, act=2,
+                               aux_in=ptr(b["hpre"]), colsum_out=self._g(pre + "mlp.fc1.bias"), colsum_beta=beta,
+                               **({"out_fp8": b["f_dhid"]} if fuse_dh else {}))
             if not defer:
                 self._wgrad(dt, pre + "mlp.fc1.", dhid, ptr(b["xm2"]), Dm, D, M, beta, bias=False)
-            self._linear_dgrad(ws, b, "f_dhid", dhid, pre + "mlp.fc1.", M, Dm, D, dD)
+            self._linear_dgrad(ws, b, "f_dhid", None if (fp8 and fuse_dh) else dhid, pre + "mlp.fc1.", M, Dm, D, dD)
             ops.ln_modulate_bwd(dt, dD, xmid, ptr(b["mean2"]), ptr(b["rstd2"]), mo + 4 * 4 * D, ld, dres, dres,
                                 dmo + 4 * 3 * D, dmo + 4 * 4 * D, ld, B, T, D)
             # attention branch

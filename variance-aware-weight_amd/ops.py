@@ -216,6 +216,17 @@ class Fp8:
         self.last_q = q.data_ptr()
         return self
 
+    def epilogue_target(self):
+        """Row-major byte buffer a GEMM epilogue may write this tensor's fp8 form into (gemm_fp8(out_fp8=self)); finish with
+        transpose_from_q()."""
+        q = self.q if self.q is not None else q_scratch(self.R * self.C, self.device, pool=1)    # not the pool the GEMM's own fp8
+        self.last_q = q.data_ptr()                                                              # input operand may live in
+        return self.last_q
+
+    def transpose_from_q(self):
+        check(L.lib().vaw_fp8_transpose(self.last_q, self.R, self.C, self.C, self.qt.data_ptr(), self.R, stream_ptr()), "vaw_fp8_transpose")
+        return self
+
     def dequant(self):
         return self.q.view(torch.float8_e5m2 if self.fmt == L.BF8 else torch.float8_e4m3fn).float() * self.scale
 
@@ -223,17 +234,20 @@ class Fp8:
 _q_scratch = {}
 
 
-def q_scratch(n, device):
-    """Grow-only byte scratch for row-major fp8 copies that only the very next GEMM reads."""
-    t = _q_scratch.get(device)
+def q_scratch(n, device, pool=0):
+    """Grow-only byte scratch for row-major fp8 copies that only the very next GEMM reads (pool 0: quantiser outputs, pool 1:
+    tensors a GEMM epilogue writes as fp8 while its input operand sits in pool 0)."""
+    t = _q_scratch.get((device, pool))
     if t is None or t.numel() < n:
-        t = _q_scratch[device] = torch.empty(n, device=device, dtype=torch.uint8)
+        t = _q_scratch[(device, pool)] = torch.empty(n, device=device, dtype=torch.uint8)
     return t
 
 
 def gemm_fp8(M, N, K, A, lda, scale_a, B, ldb, scale_b, Cp, ldc, *, a_format=L.FP8, bias=None, act=0, aux_in=None, aux_out=None,
-             gate=None, gate_ld=0, resid=None, rows_per_batch=0, alpha=1.0, out_f32=False, colsum_out=None, colsum_beta=0.0):
-    """Raw-pointer fp8 GEMM (vaw_gemm_fp8): A [M][K] bytes of a_format, B [N][K] e4m3 bytes; scale_a / scale_b device scalars."""
+             gate=None, gate_ld=0, resid=None, rows_per_batch=0, alpha=1.0, out_f32=False, colsum_out=None, colsum_beta=0.0,
+             out_fp8=None):
+    """Raw-pointer fp8 GEMM (vaw_gemm_fp8): A [M][K] bytes of a_format, B [N][K] e4m3 bytes; scale_a / scale_b device scalars.
+    out_fp8 = an Fp8 whose delayed-scaling state is current: C (= its row-major bytes) is written as fp8 by the epilogue."""
     e = Epilogue(bias or None, act, aux_in or None, aux_out or None, gate or None, gate_ld, resid or None, None, rows_per_batch,
                  alpha, 0.0, 1 if out_f32 else 0, colsum_out or None, colsum_beta, 0, None, 0.0)
     tr = gemm_trace
@@ -244,11 +258,13 @@ def gemm_fp8(M, N, K, A, lda, scale_a, B, ldb, scale_b, Cp, ldc, *, a_format=L.F
     if colsum_out:
         ws = scratch_f32(torch.device("cuda", torch.cuda.current_device()), 0)
         ws_ptr, ws_n = ws.data_ptr(), ws.numel()
-    check(L.lib().vaw_gemm_fp8(a_format, M, N, K, A, lda, scale_a, B, ldb, scale_b, Cp, ldc, C.byref(e), ws_ptr, ws_n, stream_ptr()),
-          "vaw_gemm_fp8")
+    check(L.lib().vaw_gemm_fp8(a_format, M, N, K, A, lda, scale_a, B, ldb, scale_b, Cp, ldc, C.byref(e),
+                               out_fp8.state.data_ptr() if out_fp8 is not None else None, out_fp8.fmt if out_fp8 is not None else 0,
+                               ws_ptr, ws_n, stream_ptr()), "vaw_gemm_fp8")
     if tr is not None:
         e1.record()
-        nb = M * K + N * K + M * N * ((4 if out_f32 else 2) + (2 if aux_out else 0) + (2 if aux_in else 0) + (4 if resid else 0))
+        nb = M * K + N * K + M * N * ((4 if out_f32 else 1 if out_fp8 is not None else 2) + (2 if aux_out else 0) + (2 if aux_in else 0) +
+                                      (4 if resid else 0))
         tr.add(2, True, a_format == L.FP8, M, N, K, e0, e1, float(nb))
 
 
