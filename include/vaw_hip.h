@@ -212,6 +212,14 @@ int vaw_ln_modulate_bwd(vaw_dtype dt, const void* dout, const float* x, const fl
                         const float* scale, int64_t mod_ld, const float* dres_in, float* dx, float* dshift,
                         float* dscale, int64_t dmod_ld, int B, int T, int D, float* workspace, int64_t workspace_floats,
                         vaw_stream stream);
+/* fp8 mode of the DiT blocks (delayed scaling): the same two kernels with their activation output written as fp8 BYTES [B*T][D]
+ * -- the bf16 rounding of each value divided by q_state[0], saturated: what vaw_fp8_quantize_delayed makes of the bf16 tensor,
+ * which then is never written -- and the tensor's max |x| folded into q_state[1]; vaw_fp8_transpose supplies the transposed copy. */
+int vaw_ln_modulate_fwd_fp8(const float* x, const float* shift, const float* scale, int64_t mod_ld, void* q_out, float* q_state,
+                            vaw_dtype q_format, float* mean, float* rstd, int B, int T, int D, float eps, vaw_stream stream);
+int vaw_gate_bwd_fp8(const float* dres, const void* y, const float* gate, int64_t mod_ld, void* dy_q, float* q_state,
+                     vaw_dtype q_format, float* dgate, int64_t dmod_ld, float* dy_colsum_partial, int B, int T, int D,
+                     float* workspace, int64_t workspace_floats, vaw_stream stream);
 /* Workspace (f32) of vaw_ln_modulate_bwd / vaw_gate_bwd: with it, a sample's T rows are cut into chunks handled by
  * separate workgroups (small per-GPU batches would otherwise leave most CUs idle: one workgroup per sample) and the
  * per-sample column sums are folded over the chunks in a fixed order by a second kernel.  NULL = one workgroup per sample. */

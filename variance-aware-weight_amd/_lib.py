@@ -80,6 +80,8 @@ _PROTOS = {
     "vaw_fp8_scale_update": [_p, _l, _p],
     "vaw_gemm_fp8": [_i, _l, _l, _l, _p, _l, _p, _p, _l, _p, _p, _l, C.POINTER(Epilogue), _p, _i, _p, _l, _p],
     "vaw_fp8_transpose": [_p, _l, _l, _l, _p, _l, _p],
+    "vaw_ln_modulate_fwd_fp8": [_p, _p, _p, _l, _p, _p, _i, _p, _p, _i, _i, _i, _f, _p],
+    "vaw_gate_bwd_fp8": [_p, _p, _p, _l, _p, _p, _i, _p, _l, _p, _i, _i, _i, _p, _l, _p],
 }
 
 _lib = None

@@ -62,6 +62,30 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+
+// ---- fp8 output of the row kernels (fp8 mode of dit.py with delayed scaling: the tensor's only reader is the quantiser) ----
+// four values -> the fp8 bytes vaw_fp8_quantize_delayed makes of their bf16 roundings (scale inv = 1 / state[0], saturating)
+__device__ __forceinline__ unsigned fp8_word_of_bf16(f32x4 v, float inv, int e5m2, float& amax) {
+    f32x4 r = {(float)(bf16_t)v[0], (float)(bf16_t)v[1], (float)(bf16_t)v[2], (float)(bf16_t)v[3]};
+    amax = fmaxf(fmaxf(amax, fmaxf(fabsf(r[0]), fabsf(r[1]))), fmaxf(fabsf(r[2]), fabsf(r[3])));
+    const float fm = e5m2 ? 57344.f : 448.f;
+    r = r * inv;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = __builtin_amdgcn_fmed3f(r[j], -fm, fm);
+    unsigned w = 0;
+    if (e5m2) { w = __builtin_amdgcn_cvt_pk_bf8_f32(r[0], r[1], w, false); w = __builtin_amdgcn_cvt_pk_bf8_f32(r[2], r[3], w, true); }
+    else { w = __builtin_amdgcn_cvt_pk_fp8_f32(r[0], r[1], w, false); w = __builtin_amdgcn_cvt_pk_fp8_f32(r[2], r[3], w, true); }
+    return w;
+}
+// a wave's max |x| -> the running max of the scaling state (integer atomic max on the bits; look first: it only grows)
+__device__ __forceinline__ void fp8_amax_commit(float m, float* acc, int lane) {
+    m = wave_max(m);
+    if (lane == 0 && m > 0.f && !(m != m)) {
+        unsigned* a = reinterpret_cast<unsigned*>(acc);
+        const unsigned mb = __float_as_uint(m);
+        if (mb > __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a, mb);
+    }
+}
 // Sum over a whole block; `scratch` needs blockDim.x/64 floats of LDS. Result valid in all threads.
 __device__ __forceinline__ float block_sum(float v, float* scratch) {
     v = wave_sum(v);

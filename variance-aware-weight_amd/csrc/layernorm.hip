@@ -10,7 +10,8 @@ template <typename T, int NV>
 __global__ void __launch_bounds__(256)
 ln_modulate_fwd_kernel(const float* __restrict__ x, const float* __restrict__ shift, const float* __restrict__ scale,
                        int64_t mod_ld, T* __restrict__ out, float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                       int64_t M, int Tt, int D, float eps) {
+                       int64_t M, int Tt, int D, float eps, unsigned char* __restrict__ q_out = nullptr,
+                       float* __restrict__ q_state = nullptr, int q_e5m2 = 0) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -41,6 +42,20 @@ ln_modulate_fwd_kernel(const float* __restrict__ x, const float* __restrict__ sh
     }
     const float* sh = shift + (int64_t)b * mod_ld;
     const float* sc = scale + (int64_t)b * mod_ld;
+    if (q_out) {      // fp8 mode: the row goes out as fp8 bytes of its bf16 rounding (the bf16 tensor has no other reader)
+        const float inv = 1.f / q_state[0];
+        float am = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < D) {
+                f32x4 xh = (v[i] - mean) * rstd;
+                *reinterpret_cast<unsigned*>(q_out + row * D + c) = fp8_word_of_bf16(xh * (1.f + load4(sc + c)) + load4(sh + c), inv, q_e5m2, am);
+            }
+        }
+        fp8_amax_commit(am, q_state + 1, lane);
+        return;
+    }
     T* orow = out + row * D;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -64,8 +79,12 @@ row_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ x, const fl
                T* __restrict__ dy, float* __restrict__ dgate, float* __restrict__ dy_colpart,
                // gridDim.y > 1: the sample's rows are cut into chunks of rows_per_chunk, one workgroup each; the per-sample
                // column sums then go to part[chunk][b][2][D] and row_bwd_finish_kernel folds the chunks in order
-               int rows_per_chunk, float* __restrict__ part) {
+               int rows_per_chunk, float* __restrict__ part,
+               // GATE_ONLY, fp8 mode: dy goes out as fp8 bytes of its bf16 rounding instead (q_state: its delayed-scaling state)
+               unsigned char* __restrict__ q_out = nullptr, float* __restrict__ q_state = nullptr, int q_e5m2 = 0) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][D]
+    const float q_inv = (GATE_ONLY && q_out) ? 1.f / q_state[0] : 1.f;
+    float q_am = 0.f;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int b = blockIdx.x;
     const int t_begin = blockIdx.y * rows_per_chunk;
@@ -89,7 +108,8 @@ row_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ x, const fl
                     f32x4 g = load4(dres + row * D + c);
                     f32x4 yv = load4(y + row * D + c);
                     f32x4 d = g * sc[i];
-                    store4(dy + row * D + c, d);
+                    if (q_out) *reinterpret_cast<unsigned*>(q_out + row * D + c) = fp8_word_of_bf16(d, q_inv, q_e5m2, q_am);
+                    else store4(dy + row * D + c, d);
                     acc0[i] += g * yv;
                     f32x4 dr = {to_f32(from_f32<T>(d[0])), to_f32(from_f32<T>(d[1])), to_f32(from_f32<T>(d[2])), to_f32(from_f32<T>(d[3]))};
                     acc1[i] += dr;                        // sum the values as stored (bf16-rounded in throughput mode)
@@ -127,6 +147,7 @@ row_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ x, const fl
             }
         }
     }
+    if (GATE_ONLY && q_out) fp8_amax_commit(q_am, q_state + 1, lane);
     // fixed-order combine of the per-wave column sums
     float* s0 = lds;
     float* s1p = lds + D;
@@ -223,6 +244,23 @@ extern "C" int vaw_ln_modulate_fwd(vaw_dtype dt, const float* x, const float* sh
     return VAW_OK;
 }
 
+// fp8 mode: the same forward with the output as fp8 bytes [B*T][D] of the bf16 roundings (delayed scaling: scale in q_state[0],
+// running max |x| folded into q_state[1]); bf16 arithmetic path only.
+extern "C" int vaw_ln_modulate_fwd_fp8(const float* x, const float* shift, const float* scale, int64_t mod_ld, void* q_out,
+                                       float* q_state, vaw_dtype q_format, float* mean, float* rstd, int B, int T, int D, float eps,
+                                       vaw_stream stream) {
+    VAW_CHECK_ARG(B > 0 && T > 0 && D > 0 && D % 4 == 0 && D <= 2048 && mod_ld % 4 == 0 && q_out && q_state,
+                  "ln_modulate_fwd_fp8: need D%%4==0, D<=2048, mod_ld%%4==0 (D=%d)", D);
+    VAW_CHECK_ARG(q_format == VAW_FP8 || q_format == VAW_BF8, "ln_modulate_fwd_fp8: q_format");
+    const int64_t M = (int64_t)B * T;
+    const int grid = ceil_div(M, 4);
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_NV(pick_nv(D), (ln_modulate_fwd_kernel<bf16_t, NV><<<grid, 256, 0, s>>>(x, shift, scale, mod_ld, nullptr, mean, rstd, M, T, D, eps,
+                                                                                  (unsigned char*)q_out, q_state, q_format == VAW_BF8)));
+    VAW_CHECK_LAUNCH("ln_modulate_fwd_fp8");
+    return VAW_OK;
+}
+
 extern "C" int vaw_ln_modulate_bwd(vaw_dtype dt, const void* dout, const float* x, const float* mean, const float* rstd,
                                    const float* scale, int64_t mod_ld, const float* dres_in, float* dx, float* dshift,
                                    float* dscale, int64_t dmod_ld, int B, int T, int D, float* workspace,
@@ -267,6 +305,27 @@ extern "C" int vaw_gate_bwd(vaw_dtype dt, const float* dres, const void* y, cons
     }
     if (nc > 1) row_bwd_finish_kernel<<<ceil_div((int64_t)B * D, 256), 256, 0, s>>>(part, nc, B, D, dgate, dmod_ld, dy_colsum_partial, D);
     VAW_CHECK_LAUNCH("gate_bwd");
+    return VAW_OK;
+}
+
+// fp8 mode: gate backward with dy as fp8 bytes [B*T][D] of the bf16 roundings (as vaw_ln_modulate_fwd_fp8); y is bf16.
+extern "C" int vaw_gate_bwd_fp8(const float* dres, const void* y, const float* gate, int64_t mod_ld, void* dy_q, float* q_state,
+                                vaw_dtype q_format, float* dgate, int64_t dmod_ld, float* dy_colsum_partial, int B, int T, int D,
+                                float* workspace, int64_t workspace_floats, vaw_stream stream) {
+    VAW_CHECK_ARG(B > 0 && T > 0 && D > 0 && D % 4 == 0 && D <= 2048 && mod_ld % 4 == 0 && dy_q && q_state,
+                  "gate_bwd_fp8: need D%%4==0, D<=2048, mod_ld%%4==0 (D=%d)", D);
+    VAW_CHECK_ARG(q_format == VAW_FP8 || q_format == VAW_BF8, "gate_bwd_fp8: q_format");
+    hipStream_t s = (hipStream_t)stream;
+    int nc = pick_chunks(B, T, workspace != nullptr);
+    if (nc > 1 && workspace_floats < (int64_t)nc * B * 2 * D) nc = 1;
+    const int rpc = (T + nc - 1) / nc;
+    float* part = nc > 1 ? workspace : nullptr;
+    const int block = pick_block(rpc);
+    const size_t lds = 2 * (size_t)D * sizeof(float);
+    dim3 grid(B, nc);
+    DISPATCH_NV(pick_nv(D), (row_bwd_kernel<bf16_t, NV, true><<<grid, block, lds, s>>>(nullptr, nullptr, nullptr, nullptr, nullptr, mod_ld, nullptr, nullptr, nullptr, nullptr, dmod_ld, T, D, dres, (const bf16_t*)y, gate, nullptr, dgate, dy_colsum_partial, rpc, part, (unsigned char*)dy_q, q_state, q_format == VAW_BF8)));
+    if (nc > 1) row_bwd_finish_kernel<<<ceil_div((int64_t)B * D, 256), 256, 0, s>>>(part, nc, B, D, dgate, dmod_ld, dy_colsum_partial, D);
+    VAW_CHECK_LAUNCH("gate_bwd_fp8");
     return VAW_OK;
 }
 

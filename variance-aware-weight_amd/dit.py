@@ -17,6 +17,7 @@ Data layout in HBM (B images, T tokens, D hidden, M = B*T rows):
                     -- attention, LayerNorm, embedders, final layer, adaLN, optimizer -- is the bf16 mode's.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -210,7 +211,8 @@ class DiT(FlatModule):
         self.fp8_scaling, self.fp8_margin = "delayed", 2.0
         # with delayed scaling, fc1's GELU epilogue and fc2's GELU' epilogue write their results (`a`, d hidden) as fp8 themselves --
         # byte-identical to quantising the bf16 tensor, which is then never written or read
-        self.fp8_fuse_epilogue = True
+        self.fp8_fuse_epilogue = os.environ.get("VAW_FP8_FUSE", "1") != "0"
+        self.fp8_fuse_rows = os.environ.get("VAW_FP8_FUSE_ROWS", "1") != "0"      # ... and LN-modulate / gate backward their outputs
         self._fp8_w, self._fp8_epoch, self._fp8_wstates = {}, None, None
         self.set_compute_dtype(compute_dtype)
         self._anchor = torch.zeros(1, requires_grad=True)
@@ -414,16 +416,23 @@ class DiT(FlatModule):
             b, pre = ws.blk[l], f"blocks.{l}."
             mo = mod + 4 * (6 * l * D)
             xin, xmid, xout = ptr(ws.xres[2 * l]), ptr(ws.xres[2 * l + 1]), ptr(ws.xres[2 * l + 2])
-            ops.ln_modulate_fwd(dt, xin, mo, mo + 4 * D, ld, ptr(b["xm"]), ptr(b["mean1"]), ptr(b["rstd1"]), B, T, D)
-            self._linear_fwd(ws, b, "f_xm", b["xm"], pre + "attn.qkv.", M, 3 * D, D, ptr(b["qkv"]), 3 * D)
+            fuse_rows = ws.fp8 and ws.d_fwd and self.fp8_fuse_epilogue and self.fp8_fuse_rows and M % 64 == 0 and D % 128 == 0    # LN writes fp8 itself
+            if fuse_rows:
+                ops.ln_modulate_fwd_fp8(xin, mo, mo + 4 * D, ld, b["f_xm"], ptr(b["mean1"]), ptr(b["rstd1"]), B, T, D)
+            else:
+                ops.ln_modulate_fwd(dt, xin, mo, mo + 4 * D, ld, ptr(b["xm"]), ptr(b["mean1"]), ptr(b["rstd1"]), B, T, D)
+            self._linear_fwd(ws, b, "f_xm", None if fuse_rows else b["xm"], pre + "attn.qkv.", M, 3 * D, D, ptr(b["qkv"]), 3 * D)
             q = ptr(b["qkv"])
             es = self._wsize
             ops.attn_fwd(dt, self._attn_desc(B), q, q + es * D, q + 2 * es * D, ptr(b["ao"]), ptr(b["lse"]))
             self._linear_fwd(ws, b, "f_ao", b["ao"], pre + "attn.proj.", M, D, D, xmid, D, aux_out=ptr(b["y1"]), gate=mo + 4 * 2 * D,
                              gate_ld=ld, resid=xin, rows_per_batch=T, out_f32=True)
-            ops.ln_modulate_fwd(dt, xmid, mo + 4 * 3 * D, mo + 4 * 4 * D, ld, ptr(b["xm2"]), ptr(b["mean2"]), ptr(b["rstd2"]), B, T, D)
+            if fuse_rows:
+                ops.ln_modulate_fwd_fp8(xmid, mo + 4 * 3 * D, mo + 4 * 4 * D, ld, b["f_xm2"], ptr(b["mean2"]), ptr(b["rstd2"]), B, T, D)
+            else:
+                ops.ln_modulate_fwd(dt, xmid, mo + 4 * 3 * D, mo + 4 * 4 * D, ld, ptr(b["xm2"]), ptr(b["mean2"]), ptr(b["rstd2"]), B, T, D)
             fuse_a = ws.fp8 and ws.d_fwd and self.fp8_fuse_epilogue and M % 64 == 0      # fc1's epilogue writes `a` as e4m3 itself
-            self._linear_fwd(ws, b, "f_xm2", b["xm2"], pre + "mlp.fc1.", M, Dm, D, b["f_a"].epilogue_target() if fuse_a else ptr(b["a"]), Dm,
+            self._linear_fwd(ws, b, "f_xm2", None if fuse_rows else b["xm2"], pre + "mlp.fc1.", M, Dm, D, b["f_a"].epilogue_target() if fuse_a else ptr(b["a"]), Dm,
                              act=1, aux_out=ptr(b["hpre"]), **({"out_fp8": b["f_a"]} if fuse_a else {}))
             self._linear_fwd(ws, b, "f_a", None if fuse_a else b["a"], pre + "mlp.fc2.", M, D, Dm, xout, D, aux_out=ptr(b["y2"]),
                              gate=mo + 4 * 5 * D, gate_ld=ld, resid=xmid, rows_per_batch=T, out_f32=True)
@@ -543,12 +552,16 @@ class DiT(FlatModule):
                                   else (dD, dDm, dD, ptr(ws.dqkv)))
             # MLP branch
             # bias gradients ride on the kernels that produce dy (per-sample partials / GEMM epilogue): no re-read
-            ops.gate_bwd(dt, dres, ptr(b["y2"]), mo + 4 * 5 * D, ld, dy2, dmo + 4 * 5 * D, ld, B, T, D, colpart)
+            fuse_rows = fp8 and ws.d_bwd and self.fp8_fuse_epilogue and self.fp8_fuse_rows and M % 64 == 0 and D % 128 == 0     # gate backward writes fp8 itself
+            if fuse_rows:
+                ops.gate_bwd_fp8(dres, ptr(b["y2"]), mo + 4 * 5 * D, ld, b["f_dy2"], dmo + 4 * 5 * D, ld, B, T, D, colpart)
+            else:
+                ops.gate_bwd(dt, dres, ptr(b["y2"]), mo + 4 * 5 * D, ld, dy2, dmo + 4 * 5 * D, ld, B, T, D, colpart)
             ops.reduce_rows(colpart, B, D, self._g(pre + "mlp.fc2.bias"), beta)
             if not defer:
                 self._wgrad(dt, pre + "mlp.fc2.", dy2, ptr(b["a"]), D, Dm, M, beta, bias=False)
             fuse_dh = fp8 and ws.d_bwd and self.fp8_fuse_epilogue and M % 64 == 0       # fc2's input-gradient epilogue writes dhid as fp8
-            self._linear_dgrad(ws, b, "f_dy2", dy2, pre + "mlp.fc2.", M, D, Dm, b["f_dhid"].epilogue_target() if fuse_dh else dhid, act=2,
+            self._linear_dgrad(ws, b, "f_dy2", None if fuse_rows else dy2, pre + "mlp.fc2.", M, D, Dm, b["f_dhid"].epilogue_target() if fuse_dh else dhid, act=2,
                                aux_in=ptr(b["hpre"]), colsum_out=self._g(pre + "mlp.fc1.bias"), colsum_beta=beta,
                                **({"out_fp8": b["f_dhid"]} if fuse_dh else {}))
             if not defer:
@@ -557,11 +570,14 @@ class DiT(FlatModule):
             ops.ln_modulate_bwd(dt, dD, xmid, ptr(b["mean2"]), ptr(b["rstd2"]), mo + 4 * 4 * D, ld, dres, dres,
                                 dmo + 4 * 3 * D, dmo + 4 * 4 * D, ld, B, T, D)
             # attention branch
-            ops.gate_bwd(dt, dres, ptr(b["y1"]), mo + 4 * 2 * D, ld, dy1, dmo + 4 * 2 * D, ld, B, T, D, colpart)
+            if fuse_rows:
+                ops.gate_bwd_fp8(dres, ptr(b["y1"]), mo + 4 * 2 * D, ld, b["f_dy1"], dmo + 4 * 2 * D, ld, B, T, D, colpart)
+            else:
+                ops.gate_bwd(dt, dres, ptr(b["y1"]), mo + 4 * 2 * D, ld, dy1, dmo + 4 * 2 * D, ld, B, T, D, colpart)
             ops.reduce_rows(colpart, B, D, self._g(pre + "attn.proj.bias"), beta)
             if not defer:
                 self._wgrad(dt, pre + "attn.proj.", dy1, ptr(b["ao"]), D, D, M, beta, bias=False)
-            self._linear_dgrad(ws, b, "f_dy1", dy1, pre + "attn.proj.", M, D, D, ptr(ws.dao))
+            self._linear_dgrad(ws, b, "f_dy1", None if fuse_rows else dy1, pre + "attn.proj.", M, D, D, ptr(ws.dao))
             q = ptr(b["qkv"])
             ops.attn_bwd(dt, self._attn_desc(B), q, q + es * D, q + 2 * es * D, ptr(b["ao"]), ptr(ws.dao), ptr(b["lse"]),
                          ptr(ws.delta), dq, dq + es * D, dq + 2 * es * D)

@@ -216,11 +216,12 @@ class Fp8:
         self.last_q = q.data_ptr()
         return self
 
-    def epilogue_target(self):
-        """Row-major byte buffer a GEMM epilogue may write this tensor's fp8 form into (gemm_fp8(out_fp8=self)); finish with
-        transpose_from_q()."""
-        q = self.q if self.q is not None else q_scratch(self.R * self.C, self.device, pool=1)    # not the pool the GEMM's own fp8
-        self.last_q = q.data_ptr()                                                              # input operand may live in
+    def epilogue_target(self, pool=1):
+        """Row-major byte buffer a producing kernel may write this tensor's fp8 form into (gemm_fp8(out_fp8=self),
+        ln_modulate_fwd_fp8, gate_bwd_fp8); finish with transpose_from_q().  Pools keep a GEMM's fp8 input (pool 0: quantiser
+        outputs, pool 2: row-kernel outputs) apart from the fp8 output its epilogue writes (pool 1)."""
+        q = self.q if self.q is not None else q_scratch(self.R * self.C, self.device, pool=pool)
+        self.last_q = q.data_ptr()
         return self.last_q
 
     def transpose_from_q(self):
@@ -418,6 +419,21 @@ def colsum(dt, X, M, N, ldx, out, beta=0.0, device=None):
 def ln_modulate_fwd(dt, x, shift, scale, mod_ld, out, mean, rstd, B, T, D, eps=1e-6):
     check(L.lib().vaw_ln_modulate_fwd(dt, x, shift, scale, mod_ld, out, mean, rstd, B, T, D, eps, stream_ptr()),
           "vaw_ln_modulate_fwd")
+
+
+def ln_modulate_fwd_fp8(x, shift, scale, mod_ld, f8, mean, rstd, B, T, D, eps=1e-6, pool=2):
+    """ln_modulate_fwd whose output goes straight into the Fp8 `f8` (row-major bytes + running max; delayed scaling state current)."""
+    q = f8.epilogue_target(pool)
+    check(L.lib().vaw_ln_modulate_fwd_fp8(x, shift, scale, mod_ld, q, f8.state.data_ptr(), f8.fmt, mean, rstd, B, T, D, eps, stream_ptr()),
+          "vaw_ln_modulate_fwd_fp8")
+
+
+def gate_bwd_fp8(dres, y, gate, mod_ld, f8, dgate, dmod_ld, B, T, D, dy_colpart=0, pool=2):
+    """gate_bwd whose dy goes straight into the Fp8 `f8`."""
+    ws = _row_ws(B, T, D)
+    q = f8.epilogue_target(pool)
+    check(L.lib().vaw_gate_bwd_fp8(dres, y, gate, mod_ld, q, f8.state.data_ptr(), f8.fmt, dgate, dmod_ld, dy_colpart or None, B, T, D,
+                                   ws.data_ptr(), ws.numel(), stream_ptr()), "vaw_gate_bwd_fp8")
 
 
 def _row_ws(B, T, D):
