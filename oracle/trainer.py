@@ -80,7 +80,8 @@ class Trainer:
                 loss = terms["loss"].mean() / accum
                 loss.backward()
             total += loss.item()
-            mse_avg += terms["mse"].mean().item() / accum
+            if "mse" in terms:                      # reference tools/trainer.py:116 (the KL objectives return only "loss")
+                mse_avg += terms["mse"].mean().item() / accum
             if (i + 1) % accum == 0:
                 if a.grad_clip:
                     nn.utils.clip_grad_norm_(self.model.parameters(), a.grad_clip)

@@ -125,6 +125,33 @@ def test_trainer_trajectory_tiny_dit_learned_variance_vs_reference():
     assert esum == pytest.approx(exp["ema_abs_sum"], rel=1e-6)
 
 
+@pytest.mark.parametrize("loss", ["KL", "RESCALED_KL"])
+def test_trainer_trajectory_kl_objective_vs_oracle_trainer(loss):
+    """`--loss_type kl / rescaled_kl` with a learned variance through the Trainer (the terms dict then has no "mse" entry:
+    reference tools/trainer.py:116 guards it): four steps of the HIP path in f32 against the oracle Trainer on the same CPU
+    RNG stream, 1e-4 relative; the progress bar / last_mse bookkeeping must not trip over the missing key."""
+    args = base_args(in_chans=4, class_cond=True, dataset="Latent", image_size=8, lr=1e-3, cpu_rng=True, learn_sigma=True)
+    kw = dict(image_size=8, patch_size=2, in_channels=4, hidden_size=64, depth=2, num_heads=2, class_dropout_prob=0.0, num_classes=10,
+              learn_sigma=True)
+
+    def run(pkg, diff_pkg, trainer_cls, dev, **mk):
+        random.seed(42); np.random.seed(42); torch.manual_seed(42)
+        model = pkg.DiT(**kw, **mk).to(dev)
+        ema_model = copy.deepcopy(model)
+        opt = torch.optim.AdamW(model.parameters(), lr=args.lr, betas=(0.9, 0.95), weight_decay=0.0, eps=1e-8)
+        sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=vaw_amd.get_lr_lambda(args))
+        diff = diff_pkg.GaussianDiffusion(args=args, betas=diff_pkg.get_named_beta_schedule(args.path_type, 1000),
+                                          model_mean_type=diff_pkg.ModelMeanType.EPSILON, model_var_type=diff_pkg.ModelVarType.LEARNED_RANGE,
+                                          loss_type=diff_pkg.LossType[loss], rescale_timesteps=True)
+        tr = trainer_cls(args, torch.device(dev), model, ema_model, opt, sched, diff, synth_loader(8, 8, 8, 3, 10, latent=True), Pbar())
+        return [tr.train_step(s) for s in range(1, 5)]
+
+    want = run(odit, od, otr.Trainer, "cpu")
+    got = run(vaw_amd, vaw_amd, vaw_amd.Trainer, DEV, compute_dtype="fp32")
+    assert all(np.isfinite(want)) and want[0] != want[-1]
+    np.testing.assert_allclose(got, want, rtol=1e-4)
+
+
 def test_trainer_trajectory_dit_b4_fp32_vs_reference():
     """BASELINE config 4 (DiT-B/4 on 4x32x32 latents, 130 M parameters) at batch 8: 3 reference steps."""
     exp = load_json("trainer.json")["dit_b4_b8"]
