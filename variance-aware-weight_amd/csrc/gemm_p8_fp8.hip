@@ -340,6 +340,11 @@ extern "C" int vaw_gemm_fp8(vaw_dtype a_format, int64_t M, int64_t N, int64_t K,
     VAW_CHECK_ARG(!colsum_out || (workspace && workspace_floats >= ((M + 127) / 128) * N), "gemm_fp8: colsum_out needs a workspace");
     e.M = M; e.N = N; e.ldc = ldc; e.C = C; e.slab = workspace; e.nt_off = 1;
     e.scale_a = scale_a; e.scale_b = scale_b;
+    {
+        static int dbg = -1;
+        if (dbg < 0) { const char* v = getenv("VAW_GEMM_DEBUG"); dbg = v ? atoi(v) : 0; }
+        e.debug = dbg;
+    }
     e.colpart = colsum_out ? workspace : nullptr;
     // plan in units of the kernel's K tiles: 128 fp8 elements = one K tile = what 64 bf16 elements are to vaw_p8_plan
     // (plain_f32 = false: no K split -- the long-K launches of the step are the weight gradients, served by vaw_wgrad_grouped)

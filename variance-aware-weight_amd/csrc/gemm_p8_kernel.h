@@ -199,6 +199,7 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
         const int b = blockIdx.x, x = b & 7, q = G >> 3, r = G & 7;
         it_cur = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
     }
+    const bool gm_on = CONV == 0 && e.debug != 3;     // (VAW_GEMM_DEBUG=3: row-major item order, for A/B runs)
     const int nk_per = GRP ? (nk_total + grp.n_split - 1) / grp.n_split : (nk_total + n_split - 1) / n_split;
     auto decode = [&](int it) {
         P8Item t;
@@ -222,11 +223,24 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
             t.m0 = (int64_t)tm * P8_BM;
             t.n0 = (int64_t)(tile - tm * pr.tiles_n) * Cfg::BN;
         } else {
-            const int split = it / n_tiles, tile = it - split * n_tiles, tm = tile / tiles_n;
+            const int split = it / n_tiles, tile = it - split * n_tiles;
+            // wide outputs (>= 8 column tiles): rows in groups of 4, column tile slow within a group, so the 32 consecutive items
+            // an XCD works on in a round form a 4 x 8 block of tiles instead of 1-2 rows x all columns -- it then pulls 4 A
+            // panels + 8 B panels through its L2 per round, not the whole B operand (DiT-XL fc1: 444 MB fetched for 43 MB of operands)
+            int tm, tn;
+            if (tiles_n >= 8 && gm_on) {
+                const int gsz = 4 * tiles_n, gi = tile / gsz, within = tile - gi * gsz;
+                const int rows = tiles_m - 4 * gi < 4 ? tiles_m - 4 * gi : 4;
+                tn = within / rows;
+                tm = 4 * gi + within - tn * rows;
+            } else {
+                tm = tile / tiles_n;
+                tn = tile - tm * tiles_n;
+            }
             t.split = split; t.rem = 0; t.prob = 0; t.tm = tm;
             t.a = A; t.b = B; t.lda = lda; t.ldb = ldb; t.M = (int)e.M; t.N = (int)e.N;
             t.m0 = (int64_t)tm * P8_BM;
-            t.n0 = (int64_t)(tile - tm * tiles_n) * Cfg::BN;
+            t.n0 = (int64_t)tn * Cfg::BN;
             t.kt0 = split * nk_per;
             t.nk = t.kt0 + nk_per <= nk_total ? nk_per : nk_total - t.kt0;
         }
