@@ -95,6 +95,23 @@ gemm_p4_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_
             bfr[i] = frag(bp + (i >> 2) * PART, 16 * (i & 3), ks, lane);
         }
     };
+    // one of this wave's 16 pieces of a K tile: c = 2 part + j (part 0-3 = A, 4-7 = B)
+    auto issue_piece = [&](int kt, int stage, int c) {
+        char* st = smem + stage * STAGE;
+        const int part = c >> 1, j = c & 1;
+        dma16(part < 4 ? rs_a : rs_b, st + part * PART + (2 * wid + j) * 1024, off[j] + (unsigned)((part & 3) * 64 * K * 2), (unsigned)(kt * 128));
+    };
+    // the same 64 MFMAs with the DMA of K tile kt_dma spread between them, two pieces per 8 MFMAs: issued in one burst the
+    // 64 wave-instructions of a K tile queue up in front of the texture addresser (16 cycles each) and the waves stall on issue
+    auto mma_dma = [&](const bf16x8 (&af)[8], const bf16x8 (&bfr)[8], int kt_dma, int stage, bool on) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(bfr[j]), "v"(af[i]));
+            if (on) { issue_piece(kt_dma, stage, 2 * i); issue_piece(kt_dma, stage, 2 * i + 1); }
+        }
+    };
     auto mma = [&](const bf16x8 (&af)[8], const bf16x8 (&bfr)[8]) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -115,11 +132,20 @@ gemm_p4_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_
         load_frags(stage, 1, af1, bf1);
         mma(af0, bf0);
         // K tile kt + 1 (this wave's 16 pieces, issued a whole K tile ago) has landed; my reads of stage kt are complete
+#ifdef P4_NO_VMWAIT          // ablations (wrong results, timing only): how much the DMA wait / the barrier / the DMA itself cost
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+#ifndef P4_NO_BARRIER
         __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nk) issue(kt + 2, stage);
+#endif
         if (kt + 1 < nk) load_frags(stage ^ 1, 0, af0, bf0);
+#ifndef P4_NO_DMA
+        mma_dma(af1, bf1, kt + 2, stage, kt + 2 < nk);
+#else
         mma(af1, bf1);
+#endif
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // (the asm MFMAs are invisible to the compiler's hazard recogniser)
     // epilogue: lane (l & 15) = row within the 16-row tile, 4 consecutive columns 4 (l >> 4) .. of each 16-column tile
