@@ -380,7 +380,12 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
     auto issue_ph2 = [&]() { P8_PIECE(6); if (LS == 8) P8_PIECE(LS - 1); iss_advance(); };
     auto issue_ph3 = [&]() { P8_PIECE(0); P8_PIECE(1); };
     auto issue_ph4 = [&]() { P8_PIECE(2); P8_PIECE(3); };
-    // counted waits: pieces younger than the one the NEXT phase reads (derivation in DESIGN.md §5)
+    // counted waits: pieces younger than the one the NEXT phase reads (derivation in DESIGN.md §5).
+    // LATE (gather modes and mn-major A -- convs and weight gradients): a phase's two pieces are issued between the two halves of
+    // its MFMAs instead of before its wait, so their address arithmetic and any issue stall run under MFMAs already in the pipe
+    // (UNet_64 step -4.9 %, plain weight gradients +6 %); the wait then counts two pieces fewer.  Plain k-major A keeps the early
+    // issue (late placement measured -4 ... -8 % there).
+    constexpr bool LATE = CONV != 0 || !AK;
 #define P8_WAIT(n_full)                                                                     \
     do {                                                                                    \
         if (iss_done) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      \
@@ -455,7 +460,7 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
 #pragma unroll
                     for (int s = 0; s < 2; ++s) af[s][t] = p8_frag<AK>(st + j * P8_PART, wr * 32 + 16 * t, s, lane_k);
             };
-#define P8_MMA(j)                                                                                                     \
+#define P8_MMA(j, ISSUE)                                                                                              \
     do {                                                                                                              \
         if (!AK || !BKM) {      /* fragments read by inline asm: the compiler does not wait for them itself */          \
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
@@ -463,18 +468,24 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
         }                                                                                                             \
         __builtin_amdgcn_s_setprio(1);                                                                                \
         if (F8) {   /* one scaled fp8 MFMA (K = 128, unit block scales) where the bf16 kernel issues two of K = 32 */   \
-            _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                             \
+            _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                           \
+                if (t == 1) { ISSUE; }                                                                                \
                 _Pragma("unroll") for (int u = 0; u < NTW; ++u)                                                       \
                     /* the MFMA's first matrix is our B tile (cbsz: e4m3), its second our A tile (blgp: 0 e4m3 | 1 e5m2) */ \
                     acc[2 * (j) + t][u] = F8 == 2 ? __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                  \
                         p8_cat(bfr[0][u], bfr[1][u]), p8_cat(af[0][t], af[1][t]), acc[2 * (j) + t][u], 0, 1, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F) \
                                                   : __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                  \
                         p8_cat(bfr[0][u], bfr[1][u]), p8_cat(af[0][t], af[1][t]), acc[2 * (j) + t][u], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F); \
+            }                                                                                                         \
         } else {                                                                                                      \
-            _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                             \
+            _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                           \
+                /* this phase's two DMA pieces go out between the two halves of its MFMAs: an issue stall (the texture \
+                   addresser takes 16 cycles per wave-instruction) then overlaps MFMAs already in the pipe */          \
+                if (s == 1) { ISSUE; }                                                                                \
                 _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                         \
                     _Pragma("unroll") for (int u = 0; u < NTW; ++u)                                                   \
                         acc[2 * (j) + t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[s][u], af[s][t], acc[2 * (j) + t][u], 0, 0, 0); \
+            }                                                                                                         \
         }                                                                                                             \
         __builtin_amdgcn_s_setprio(0);                                                                                \
         if (F8) {   /* pin the results here: the accumulators are only read after the loop, and LLVM's code sinking   \
@@ -492,13 +503,13 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
             }
             P8_TS(t1a);
             load_a(0);
-            issue_ph1();
+            if (!LATE) issue_ph1();
             P8_TS(t1b);
-            P8_WAIT(8);
+            if (LATE) P8_WAIT(6); else P8_WAIT(8);
             P8_TS(t1c);
             __builtin_amdgcn_s_barrier();
             P8_TS(t1d);
-            P8_MMA(0);
+            P8_MMA(0, if (LATE) issue_ph1());
             if (CONV == 3 && do_colsum_b) {      // column sums of the B tile (dy): B . ones -- every column of the result holds them
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
@@ -511,39 +522,39 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
             // ---- phase 2
             P8_TS(t2a);
             load_a(1);
-            issue_ph2();
+            if (!LATE) issue_ph2();
             P8_TS(t2b);
-            if (LS == 8) P8_WAIT(9); else P8_WAIT(8);
+            if (LATE) P8_WAIT(7); else if (LS == 8) P8_WAIT(9); else P8_WAIT(8);
             P8_TS(t2c);
             __builtin_amdgcn_s_barrier();
             P8_TS(t2d);
-            P8_MMA(1);
+            P8_MMA(1, if (LATE) issue_ph2());
             P8_TS(t2e);
             P8_TACC(t2a, t2b, t2c, t2d, t2e);
             __builtin_amdgcn_s_barrier();
             // ---- phase 3
             P8_TS(t3a);
             load_a(2);
-            issue_ph3();
+            if (!LATE) issue_ph3();
             P8_TS(t3b);
-            if (LS == 8) P8_WAIT(10); else P8_WAIT(9);
+            if (LATE) { if (LS == 8) P8_WAIT(8); else P8_WAIT(7); } else { if (LS == 8) P8_WAIT(10); else P8_WAIT(9); }
             P8_TS(t3c);
             __builtin_amdgcn_s_barrier();
             P8_TS(t3d);
-            P8_MMA(2);
+            P8_MMA(2, if (LATE) issue_ph3());
             P8_TS(t3e);
             P8_TACC(t3a, t3b, t3c, t3d, t3e);
             __builtin_amdgcn_s_barrier();
             // ---- phase 4
             P8_TS(t4a);
             load_a(3);
-            issue_ph4();
+            if (!LATE) issue_ph4();
             P8_TS(t4b);
-            P8_WAIT(7);
+            if (LATE) P8_WAIT(5); else P8_WAIT(7);
             P8_TS(t4c);
             __builtin_amdgcn_s_barrier();
             P8_TS(t4d);
-            P8_MMA(3);
+            P8_MMA(3, if (LATE) issue_ph4());
             P8_TS(t4e);
             P8_TACC(t4a, t4b, t4c, t4d, t4e);
             __builtin_amdgcn_s_barrier();
