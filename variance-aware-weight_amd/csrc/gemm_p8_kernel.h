@@ -50,6 +50,9 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 #define P8_TACC(tA, tB, tC, tD, tE) do { } while (0)
 #endif
 
+#ifndef P8_LATE_AT
+#define P8_LATE_AT 1
+#endif
 #define P8_BM 256
 #define P8_PART 8192
 #define P8_EPI_BYTES 32768
@@ -481,7 +484,7 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
             _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                           \
                 /* this phase's two DMA pieces go out between the two halves of its MFMAs: an issue stall (the texture \
                    addresser takes 16 cycles per wave-instruction) then overlaps MFMAs already in the pipe */          \
-                if (s == 1) { ISSUE; }                                                                                \
+                if (s == P8_LATE_AT) { ISSUE; }                                                                             \
                 _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                         \
                     _Pragma("unroll") for (int u = 0; u < NTW; ++u)                                                   \
                         acc[2 * (j) + t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[s][u], af[s][t], acc[2 * (j) + t][u], 0, 0, 0); \
