@@ -68,7 +68,7 @@ ln_modulate_fwd_kernel(const float* __restrict__ x, const float* __restrict__ sh
 }
 
 // One block per sample; NW waves stride over that sample's T rows.
-template <typename T, int NV, bool GATE_ONLY>
+template <typename T, int NV, bool GATE_ONLY, bool QOUT = false>
 __global__ void __launch_bounds__(1024)
 row_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ x, const float* __restrict__ mean,
                const float* __restrict__ rstd, const float* __restrict__ scale, int64_t mod_ld,
@@ -83,7 +83,7 @@ row_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ x, const fl
                // GATE_ONLY, fp8 mode: dy goes out as fp8 bytes of its bf16 rounding instead (q_state: its delayed-scaling state)
                unsigned char* __restrict__ q_out = nullptr, float* __restrict__ q_state = nullptr, int q_e5m2 = 0) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][D]
-    const float q_inv = (GATE_ONLY && q_out) ? 1.f / q_state[0] : 1.f;
+    const float q_inv = (GATE_ONLY && QOUT) ? 1.f / q_state[0] : 1.f;
     float q_am = 0.f;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int b = blockIdx.x;
@@ -108,7 +108,7 @@ row_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ x, const fl
                     f32x4 g = load4(dres + row * D + c);
                     f32x4 yv = load4(y + row * D + c);
                     f32x4 d = g * sc[i];
-                    if (q_out) *reinterpret_cast<unsigned*>(q_out + row * D + c) = fp8_word_of_bf16(d, q_inv, q_e5m2, q_am);
+                    if (QOUT) *reinterpret_cast<unsigned*>(q_out + row * D + c) = fp8_word_of_bf16(d, q_inv, q_e5m2, q_am);
                     else store4(dy + row * D + c, d);
                     acc0[i] += g * yv;
                     f32x4 dr = {to_f32(from_f32<T>(d[0])), to_f32(from_f32<T>(d[1])), to_f32(from_f32<T>(d[2])), to_f32(from_f32<T>(d[3]))};
@@ -147,7 +147,7 @@ row_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ x, const fl
             }
         }
     }
-    if (GATE_ONLY && q_out) fp8_amax_commit(q_am, q_state + 1, lane);
+    if (GATE_ONLY && QOUT) fp8_amax_commit(q_am, q_state + 1, lane);
     // fixed-order combine of the per-wave column sums
     float* s0 = lds;
     float* s1p = lds + D;
@@ -323,7 +323,7 @@ extern "C" int vaw_gate_bwd_fp8(const float* dres, const void* y, const float* g
     const int block = pick_block(rpc);
     const size_t lds = 2 * (size_t)D * sizeof(float);
     dim3 grid(B, nc);
-    DISPATCH_NV(pick_nv(D), (row_bwd_kernel<bf16_t, NV, true><<<grid, block, lds, s>>>(nullptr, nullptr, nullptr, nullptr, nullptr, mod_ld, nullptr, nullptr, nullptr, nullptr, dmod_ld, T, D, dres, (const bf16_t*)y, gate, nullptr, dgate, dy_colsum_partial, rpc, part, (unsigned char*)dy_q, q_state, q_format == VAW_BF8)));
+    DISPATCH_NV(pick_nv(D), (row_bwd_kernel<bf16_t, NV, true, true><<<grid, block, lds, s>>>(nullptr, nullptr, nullptr, nullptr, nullptr, mod_ld, nullptr, nullptr, nullptr, nullptr, dmod_ld, T, D, dres, (const bf16_t*)y, gate, nullptr, dgate, dy_colsum_partial, rpc, part, (unsigned char*)dy_q, q_state, q_format == VAW_BF8)));
     if (nc > 1) row_bwd_finish_kernel<<<ceil_div((int64_t)B * D, 256), 256, 0, s>>>(part, nc, B, D, dgate, dmod_ld, dy_colsum_partial, D);
     VAW_CHECK_LAUNCH("gate_bwd_fp8");
     return VAW_OK;
