@@ -51,7 +51,7 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 #endif
 
 #ifndef P8_LATE_AT
-#define P8_LATE_AT 1
+#define P8_LATE_AT 2
 #endif
 #define P8_BM 256
 #define P8_PART 8192
@@ -484,10 +484,11 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
             _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                           \
                 /* this phase's two DMA pieces go out between the two halves of its MFMAs: an issue stall (the texture \
                    addresser takes 16 cycles per wave-instruction) then overlaps MFMAs already in the pipe */          \
-                if (s == P8_LATE_AT) { ISSUE; }                                                                             \
-                _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                         \
+                _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                       \
+                    if (2 * s + t == P8_LATE_AT) { ISSUE; }     /* quarter of the MFMA block after which the pieces go out */ \
                     _Pragma("unroll") for (int u = 0; u < NTW; ++u)                                                   \
                         acc[2 * (j) + t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[s][u], af[s][t], acc[2 * (j) + t][u], 0, 0, 0); \
+                }                                                                                                     \
             }                                                                                                         \
         }                                                                                                             \
         __builtin_amdgcn_s_setprio(0);                                                                                \
