@@ -192,3 +192,48 @@ def test_wgrad_grouped_fp8_exact_integers(case, dyfmt):
         grp.launch(code, 0.0)
         for got, ref in refs:
             assert torch.equal(got.cpu().double(), ref)
+
+
+@pytest.mark.parametrize("fmt", ["e4m3", "e5m2"])
+def test_row_kernels_with_fp8_output_match_the_quantiser(fmt):
+    """vaw_ln_modulate_fwd_fp8 / vaw_gate_bwd_fp8 / vaw_fp8_transpose: the bytes, the transposed copy, the running max and the
+    side outputs (mean / rstd, dgate, bias-gradient partials) must equal what the bf16 kernels followed by
+    vaw_fp8_quantize_delayed produce with the same scale."""
+    code, E, FMAX = FMT[fmt]
+    dev = torch.device(DEV)
+    B, T, D = 4, 64, 256
+    M = B * T
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(M, D, generator=g).to(DEV)
+    mod = (torch.randn(B, 3 * D, generator=g) * 0.3).to(DEV)
+    scale0 = 0.01
+    # --- LayerNorm + modulate forward
+    st = ops.fp8_states([code, code], dev)
+    st[:, 0] = scale0
+    ref_bf16 = torch.empty(M, D, device=DEV, dtype=torch.bfloat16)
+    mean1, rstd1 = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    ops.ln_modulate_fwd(vaw_amd._lib.BF16, ptr(x), ptr(mod), ptr(mod) + 4 * D, 3 * D, ptr(ref_bf16), ptr(mean1), ptr(rstd1), B, T, D)
+    fa = ops.Fp8(M, D, dev, fmt=code, state=st[0]).quantize(ref_bf16, delayed=True)
+    fb = ops.Fp8(M, D, dev, fmt=code, state=st[1])
+    mean2, rstd2 = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    ops.ln_modulate_fwd_fp8(ptr(x), ptr(mod), ptr(mod) + 4 * D, 3 * D, fb, ptr(mean2), ptr(rstd2), B, T, D)
+    fb.transpose_from_q()
+    assert torch.equal(fb.q, fa.q) and torch.equal(fb.qt, fa.qt) and torch.equal(fb.qt, fb.q.t())
+    assert float(st[1, 1]) == float(st[0, 1]) == float(ref_bf16.float().abs().max())
+    assert torch.equal(mean1, mean2) and torch.equal(rstd1, rstd2)
+    # --- gate backward
+    st = ops.fp8_states([code, code], dev)
+    st[:, 0] = scale0
+    dres = torch.randn(M, D, generator=g).to(DEV)
+    y = torch.randn(M, D, generator=g).to(DEV).bfloat16()
+    dy = torch.empty(M, D, device=DEV, dtype=torch.bfloat16)
+    dg1, cp1 = torch.empty(B, 3 * D, device=DEV), torch.empty(B, D, device=DEV)
+    ops.gate_bwd(vaw_amd._lib.BF16, ptr(dres), ptr(y), ptr(mod) + 4 * 2 * D, 3 * D, ptr(dy), ptr(dg1), 3 * D, B, T, D, ptr(cp1))
+    fa = ops.Fp8(M, D, dev, fmt=code, state=st[0]).quantize(dy, delayed=True)
+    fb = ops.Fp8(M, D, dev, fmt=code, state=st[1])
+    dg2, cp2 = torch.empty(B, 3 * D, device=DEV), torch.empty(B, D, device=DEV)
+    ops.gate_bwd_fp8(ptr(dres), ptr(y), ptr(mod) + 4 * 2 * D, 3 * D, fb, ptr(dg2), 3 * D, B, T, D, ptr(cp2))
+    fb.transpose_from_q()
+    assert torch.equal(fb.q, fa.q) and torch.equal(fb.qt, fa.qt)
+    assert float(st[1, 1]) == float(st[0, 1])
+    assert torch.equal(dg1[:, :D], dg2[:, :D]) and torch.equal(cp1, cp2)
