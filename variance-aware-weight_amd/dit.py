@@ -16,7 +16,6 @@ Data layout in HBM (B images, T tokens, D hidden, M = B*T rows):
                     copy (W^T for dgrad; x^T, dy^T [*, M] per block for the deferred grouped weight gradients).  Everything else
                     -- attention, LayerNorm, embedders, final layer, adaLN, optimizer -- is the bf16 mode's.
 """
-import math
 import os
 
 import numpy as np

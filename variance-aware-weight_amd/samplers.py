@@ -10,7 +10,6 @@
 
 The denoiser call is the hot part and runs on the HIP kernels; the per-step update is a handful of elementwise torch ops
 on [B, C, H, W] (float64 for EDM, as in the reference)."""
-import math
 
 import numpy as np
 import torch

@@ -15,7 +15,6 @@ All ResBlocks' `emb_layers` Linear weights are packed into one matrix: one GEMM 
 (scale, shift) from SiLU(emb).  Forward builds a short tape of coarse ops; backward walks it in reverse (no
 torch autograd graph inside the model).
 """
-import math
 
 import torch
 import torch.nn as nn
