@@ -121,7 +121,52 @@ gemm_p4_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_
                 // both files and moves fragments through v_accvgpr_write: 200 extra VALU ops per K tile)
                 asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(bfr[j]), "v"(af[i]));   // transposed: lane = row, 4 cols
     };
+#ifdef P4_REGSTAGE
+    // Variant: global -> VGPR -> LDS (ds_write_b128) instead of LDS-DMA.  The 16 pieces of K tile kt + 2 are loaded into 64
+    // staging VGPRs during the second half of K tile kt (spread between the MFMAs) and written to the stage that K tile kt has
+    // just released during the first half of K tile kt + 1.
+    bf16x8 stg[16];
+    auto g_load = [&](int kt, int c) {
+        const int part = c >> 1, j = c & 1;
+        const bf16_t* base = part < 4 ? A + m0 * K : B + n0 * K;
+        const char* src = (const char*)base + off[j] + (size_t)((part & 3) * 64) * K * 2 + (size_t)kt * 128;
+        stg[c] = *reinterpret_cast<const bf16x8*>(src);
+    };
+    auto l_store = [&](int stage, int c) {
+        const int part = c >> 1, j = c & 1;
+        *reinterpret_cast<bf16x8*>(smem + stage * STAGE + part * PART + (2 * wid + j) * 1024 + lane * 16) = stg[c];
+    };
+#endif
     bf16x8 af0[8], bf0[8], af1[8], bf1[8];
+#ifdef P4_REGSTAGE
+    for (int c = 0; c < 16; ++c) { g_load(0, c); }
+    for (int c = 0; c < 16; ++c) { l_store(0, c); }
+    if (nk > 1) { for (int c = 0; c < 16; ++c) g_load(1, c); }
+    __syncthreads();
+    load_frags(0, 0, af0, bf0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int stage = kt & 1;
+        load_frags(stage, 1, af1, bf1);
+        // first half: MFMAs of k-step 0, with the staged K tile kt + 1 going to the other stage (released at the barrier below of
+        // the previous iteration)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(bf0[j]), "v"(af0[i]));
+            if (kt + 1 < nk) { l_store(stage ^ 1, 2 * i); l_store(stage ^ 1, 2 * i + 1); }
+        }
+        __syncthreads();                                       // stage kt + 1 complete and visible; (kt, 1) fragments are in registers
+        if (kt + 1 < nk) load_frags(stage ^ 1, 0, af0, bf0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(bf1[j]), "v"(af1[i]));
+            if (kt + 2 < nk) { g_load(kt + 2, 2 * i); g_load(kt + 2, 2 * i + 1); }
+        }
+    }
+#else
     issue(0, 0);
     if (nk > 1) issue(1, 1);
     if (nk > 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -147,6 +192,7 @@ gemm_p4_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_
         mma(af1, bf1);
 #endif
     }
+#endif
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // (the asm MFMAs are invisible to the compiler's hazard recogniser)
     // epilogue: lane (l & 15) = row within the 16-row tile, 4 consecutive columns 4 (l >> 4) .. of each 16-column tile
     const int64_t mrow = m0 + wr * 128 + (lane & 15);
