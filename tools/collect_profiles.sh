@@ -18,7 +18,7 @@ for wl in $WLS; do
   timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $d -o p -- python3 bench.py --workload $wl ${FLAGS[$wl]} --no-cpu-baseline > $d.log 2>&1 || { tail -5 $d.log; exit 1; }
   cp $d/p_kernel_stats.csv $OUT/${base}_kernel_stats.csv
   grep '^{"metric"' $d.log | tail -1 > $OUT/${base}_bench_under_rocprof.json
-  if [ $wl = dit_b4 ] || [ $wl = dit_xl2_fp8 ]; then
+  if [ $wl = dit_b4 ] || [ $wl = dit_xl2_fp8 ] || [ $wl = unet64 ] || [ "$PMC_ALL" = 1 ]; then
     echo "== $wl: PMC passes"
     for c in FETCH_SIZE WRITE_SIZE; do
       rm -rf gpurun_out/pmc_$c
