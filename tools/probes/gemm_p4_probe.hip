@@ -23,8 +23,11 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)0x80000000u, 0x00020000);
 }
+#ifndef P4_AUX
+#define P4_AUX 0             // cache-policy bits of the DMA loads (1 = sc0, 2 = nt): measurement switch
+#endif
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, char* dst, unsigned voff, unsigned soff) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)dst, 16, voff, soff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)dst, 16, voff, soff, 0, P4_AUX);
 }
 // 16 rows x 32 k fragment of a k-major part: row r16 + (l & 15), k-step s, chunk swizzled by (row >> 1) & 7
 __device__ __forceinline__ bf16x8 frag(const char* part, int r16, int s, int lane) {
@@ -107,9 +110,16 @@ gemm_p4_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+            for (int j = 0; j < 8; ++j) {
                 asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(bfr[j]), "v"(af[i]));
+#ifdef P4_FINE
+                if (on && j == 3) issue_piece(kt_dma, stage, 2 * i);          // one piece per 4 MFMAs instead of two per 8
+                if (on && j == 7) issue_piece(kt_dma, stage, 2 * i + 1);
+#endif
+            }
+#ifndef P4_FINE
             if (on) { issue_piece(kt_dma, stage, 2 * i); issue_piece(kt_dma, stage, 2 * i + 1); }
+#endif
         }
     };
     auto mma = [&](const bf16x8 (&af)[8], const bf16x8 (&bfr)[8]) {
