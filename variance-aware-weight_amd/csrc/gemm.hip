@@ -885,7 +885,8 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
             const int force = g_gemm_tile == -1 ? -1 : g_gemm_tile == 4 ? 1 : (g_gemm_tile == 2 || g_gemm_tile == 3) ? g_gemm_tile : 0;
             const bool p8_epi_ok = !(e.act == 2 && e.gate) && !(e.resid && e.rowadd);     // gemm_epi.h: EpiOps has two slots
             const P8Plan pl = (bk_env == 0 && !fused_rowsum && p8_epi_ok)
-                                  ? vaw_p8_plan(M, N, K, plain_f32, colsum_out != nullptr, workspace_floats, force)
+                                  ? vaw_p8_plan(M, N, K, plain_f32 || (plain_bf16 && !rowsum_out && K >= 2048 && workspace != nullptr),
+                                                colsum_out != nullptr, workspace_floats, force)
                                   : P8Plan{false, 4, 1, 0};
             if (pl.use) {
                 EpiDev ep8 = e;
@@ -898,7 +899,10 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
                 ep8.colpart = colsum_out ? workspace : nullptr;
                 ep8.rowpart = nullptr;
                 vaw_p8_launch(pl, a_kmajor, b_kmajor, M, N, K, a, lda, b, ldb, ep8, s);
-                if (pl.split > 1)
+                if (pl.split > 1 && !e.out_f32)      // plain bf16 result (input gradients of half-full launches): slabs -> bf16
+                    splitk_reduce_kernel<bf16_t><<<ceil_div(M * N / 4, 256) > 2048 ? 2048 : ceil_div(M * N / 4, 256), 256, 0, s>>>(
+                        workspace, pl.split, M, N, ldc, C, e.alpha, 0.f, 0);
+                else if (pl.split > 1)
                     splitk_reduce_kernel<float><<<ceil_div(M * N / 4, 256) > 2048 ? 2048 : ceil_div(M * N / 4, 256), 256, 0, s>>>(
                         workspace, pl.split, M, N, ldc, C, e.alpha, e.beta, 1);
                 VAW_CHECK_LAUNCH("gemm_p8");
