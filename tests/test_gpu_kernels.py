@@ -334,17 +334,19 @@ def test_wgrad_grouped_exact_integers(case):
             assert torch.equal(got.cpu().double(), ref)
 
 
+@pytest.mark.parametrize("M,tile", [(2048, 0), (8192, 4)])
 @pytest.mark.parametrize("layout", ["fwd", "dgrad"])
-def test_gemm_small_m_long_k_bf16_split_exact_integers(layout):
-    """The strong-scaling shapes (few output tiles, long K, plain bf16 result) take the K-split path of the 128 x 128 kernel:
-    f32 slabs + a fixed-order reduce that writes bf16.  Small integers: exact, and identical on a repeat."""
-    M, N, K = 2048, 768, 3072
+def test_gemm_small_m_long_k_bf16_split_exact_integers(layout, M, tile):
+    """The strong-scaling shapes (few output tiles, long K, plain bf16 result) take a K-split path -- of the 128 x 128 kernel at
+    2048 rows, of the persistent kernel (half-full launch) at 8192: f32 slabs + a fixed-order reduce that writes bf16.  Small
+    integers: exact, and identical on a repeat."""
+    N, K = 768, 3072
     g = torch.Generator().manual_seed(5)
     A = torch.randint(-2, 3, (M, K), generator=g).float()
     B = torch.randint(-2, 3, (N, K) if layout == "fwd" else (K, N), generator=g).float()
     ref = (A.double() @ (B.double().t() if layout == "fwd" else B.double())).float().bfloat16()
     Ad, Bd = A.to(DEV).bfloat16(), B.to(DEV).bfloat16()
-    lib().vaw_debug_gemm_tile(0)          # the 128 x 128 kernel (what the planner picks at this size)
+    lib().vaw_debug_gemm_tile(tile)       # 0: the 128 x 128 kernel (what the planner picks at 2048 rows), 4: the persistent one
     try:
         out = ops.gemm_t(Ad, Bd, a_kmajor=True, b_kmajor=layout == "fwd")
         out2 = ops.gemm_t(Ad, Bd, a_kmajor=True, b_kmajor=layout == "fwd")
