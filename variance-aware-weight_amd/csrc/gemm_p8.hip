@@ -14,6 +14,10 @@ struct P8Plan {
     int ntw, split, grid;
 };
 
+// Workgroups a persistent launch may use.  VAW_P8_RESERVE_CUS=n keeps n CUs out of every persistent grid: a workgroup of this
+// kernel owns a CU's whole register file and LDS, so a concurrently running kernel of another stream (RCCL's all-reduce during a
+// data-parallel backward) takes CUs away, and with the static item partition a persistent grid that does not fit runs its last
+// workgroups in a second pass.  Unmeasured here (one GPU per box): default 0.
 static int p8_num_cus() {
     static int n = 0;
     if (!n) {
@@ -21,6 +25,9 @@ static int p8_num_cus() {
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
         if (n <= 0) n = 256;
+        const char* v = getenv("VAW_P8_RESERVE_CUS");
+        const int r = v ? atoi(v) : 0;
+        if (r > 0 && r < n - 8) n -= r;
     }
     return n;
 }
