@@ -182,6 +182,9 @@ int vaw_gemm_fp8(vaw_dtype a_format, int64_t M, int64_t N, int64_t K, const void
 /* qt[c][r] = q[r][c] for fp8 bytes; R % 64 == 0, C % 128 == 0, ldq % 8 == 0, ldt % 4 == 0. */
 int vaw_fp8_transpose(const void* q, int64_t R, int64_t C, int64_t ldq, void* qt, int64_t ldt, vaw_stream stream);
 
+/* Keep n CUs out of every persistent-GEMM grid from now on (0 = none): for the time a kernel of another stream (a collective)
+ * holds CUs of its own -- a persistent workgroup cannot share its CU, and a grid that does not fit runs a second pass. */
+void vaw_p8_set_reserved_cus(int n);
 /* 1 when vaw_gemm would run these operands on the bf16 MFMA kernel (M%128==0, N%128==0, K%64==0, 16-byte
  * aligned rows), 0 when it takes the exact-f32 generic kernel.  For measurement and tests. */
 int vaw_gemm_uses_bf16_mfma(vaw_dtype dt, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,

@@ -125,6 +125,10 @@ def lib():
         L.vaw_debug_force_generic_gemm.restype = None
         L.vaw_debug_gemm_tile.argtypes = [_i]
         L.vaw_debug_gemm_tile.restype = None
+        L.vaw_p8_set_reserved_cus.argtypes = [_i]
+        L.vaw_p8_set_reserved_cus.restype = None
+        L.vaw_debug_cu_hog.argtypes = [_i, _i, _p]
+        L.vaw_debug_cu_hog.restype = _i
         _lib = L
     return _lib
 
@@ -133,7 +137,7 @@ def exported_symbols():
     return sorted(list(_PROTOS) + ["vaw_version", "vaw_last_error_string", "vaw_colsum_workspace_floats",
                                    "vaw_sumsq_workspace_floats", "vaw_groupnorm_workspace_floats", "vaw_wgrad_grouped_desc_bytes",
                                    "vaw_conv3x3_wgrad_small_workspace_floats", "vaw_row_bwd_workspace_floats",
-                                   "vaw_fp8_quantize_workspace_floats"])
+                                   "vaw_fp8_quantize_workspace_floats", "vaw_p8_set_reserved_cus"])
 
 
 def check(rc, what):

@@ -15,3 +15,20 @@ void vaw_set_error(const char* fmt, ...) {
 
 extern "C" int vaw_version(void) { return 100; }   // 0.1.0
 extern "C" const char* vaw_last_error_string(void) { return g_err; }
+
+// Measurement aid (tools/contention_bench.py): n_wgs workgroups that each take a whole CU (160 KiB of LDS) and idle there for
+// `microseconds` -- a stand-in for a collective kernel running on another stream beside the compute kernels.
+__global__ void __launch_bounds__(64) cu_hog_kernel(uint64_t ticks) {
+    extern __shared__ char hog_lds[];
+    if (threadIdx.x == 0) hog_lds[0] = 1;
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();       // 100 MHz
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+extern "C" int vaw_debug_cu_hog(int n_wgs, int microseconds, vaw_stream stream) {
+    VAW_CHECK_ARG(n_wgs > 0 && n_wgs <= 256 && microseconds > 0 && microseconds <= 2000000, "cu_hog: arguments");
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)cu_hog_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    cu_hog_kernel<<<n_wgs, 64, 160 * 1024, (hipStream_t)stream>>>((uint64_t)microseconds * 100);
+    VAW_CHECK_LAUNCH("cu_hog");
+    return VAW_OK;
+}

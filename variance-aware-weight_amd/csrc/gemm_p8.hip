@@ -14,22 +14,25 @@ struct P8Plan {
     int ntw, split, grid;
 };
 
-// Workgroups a persistent launch may use.  VAW_P8_RESERVE_CUS=n keeps n CUs out of every persistent grid: a workgroup of this
-// kernel owns a CU's whole register file and LDS, so a concurrently running kernel of another stream (RCCL's all-reduce during a
-// data-parallel backward) takes CUs away, and with the static item partition a persistent grid that does not fit runs its last
-// workgroups in a second pass.  Unmeasured here (one GPU per box): default 0.
+// Workgroups a persistent launch may use = CUs - reserved.  A workgroup of this kernel owns a CU's whole register file and LDS
+// and the items are partitioned statically, so a kernel of another stream that holds even 8 CUs (RCCL's all-reduce during a
+// data-parallel backward) makes a full-width persistent grid run its last workgroups in a second pass: measured with a stand-in
+// (tools/contention_bench.py) 14.3 -> 19.6 ms/step, against 16.0 when the persistent grids leave those CUs alone.
+// vaw_p8_set_reserved_cus(n) (parallel.py: during the backward of a data-parallel step) / VAW_P8_RESERVE_CUS=n (always).
+static int g_p8_reserved = 0;
+extern "C" void vaw_p8_set_reserved_cus(int n) { g_p8_reserved = n > 0 ? n : 0; }
 static int p8_num_cus() {
-    static int n = 0;
+    static int n = 0, env_r = 0;
     if (!n) {
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
         if (n <= 0) n = 256;
         const char* v = getenv("VAW_P8_RESERVE_CUS");
-        const int r = v ? atoi(v) : 0;
-        if (r > 0 && r < n - 8) n -= r;
+        env_r = v ? atoi(v) : 0;
     }
-    return n;
+    const int r = env_r > g_p8_reserved ? env_r : g_p8_reserved;
+    return (r > 0 && r < n - 8) ? n - r : n;
 }
 
 // Measured on MI355X (tools/gemm_bench.py --tile cmp, DiT-B/4 shapes, one process): per item the 192-column tile costs

@@ -54,6 +54,13 @@ class DistributedDataParallel(nn.Module):
         n_buckets = sum(len(r) if isinstance(r, list) else 1 for r in self._ranges.values())
         self._events = [torch.cuda.Event() for _ in range(n_buckets)] if self._cuda else []   # one per bucket, reused every step
         self._issued = 0
+        # While RCCL's kernels hold CUs of their own, the persistent GEMMs leave that many alone (gemm_p8.hip: p8_num_cus).  32 is a
+        # guess at RCCL's channel count on an 8-GPU xGMI node -- it could not be measured on the one-GPU boxes; VAW_DDP_RESERVE_CUS
+        # overrides (0 = off).  Only with the RCCL backend: gloo reduces on the host.
+        import os
+        explicit = "VAW_DDP_RESERVE_CUS" in os.environ        # (set explicitly it also applies to a gloo rehearsal: tests)
+        self._reserve = int(os.environ.get("VAW_DDP_RESERVE_CUS", "32")) if (self._cuda and (self._backend_avg or explicit)) else 0
+        self._reserved_now = False
         module.grad_ready_hook = self._on_stage
 
     # stage -> (start, end) element range of the flat gradient buffer that is final once `stage` fires
@@ -115,6 +122,10 @@ class DistributedDataParallel(nn.Module):
             if hi <= lo:
                 continue
             g = self.module.flat_grads()[lo:hi]
+            if self._reserve and not self._reserved_now:
+                from . import _lib
+                _lib.lib().vaw_p8_set_reserved_cus(self._reserve)
+                self._reserved_now = True
             if self._cuda:
                 ev = self._events[self._issued % len(self._events)]
                 self._issued += 1
@@ -147,3 +158,7 @@ class DistributedDataParallel(nn.Module):
                 self._retire(entry)
         self._pending = []
         self._issued = 0
+        if self._reserved_now:
+            from . import _lib
+            _lib.lib().vaw_p8_set_reserved_cus(0)
+            self._reserved_now = False
