@@ -54,12 +54,14 @@ class DistributedDataParallel(nn.Module):
         n_buckets = sum(len(r) if isinstance(r, list) else 1 for r in self._ranges.values())
         self._events = [torch.cuda.Event() for _ in range(n_buckets)] if self._cuda else []   # one per bucket, reused every step
         self._issued = 0
-        # While RCCL's kernels hold CUs of their own, the persistent GEMMs leave that many alone (gemm_p8.hip: p8_num_cus).  32 is a
-        # guess at RCCL's channel count on an 8-GPU xGMI node -- it could not be measured on the one-GPU boxes; VAW_DDP_RESERVE_CUS
-        # overrides (0 = off).  Only with the RCCL backend: gloo reduces on the host.
+        # While RCCL's kernels hold CUs of their own, the persistent GEMMs leave that many alone (gemm_p8.hip: p8_num_cus).  64 covers
+        # RCCL's largest channel count; its real use on an 8-GPU xGMI node could not be measured on the one-GPU boxes, and with the
+        # stand-in of tools/contention_bench.py leaving out 64 costs the DiT-B/4 step no more than leaving out 32 or 16 (the 768-item
+        # launches need four rounds either way).  VAW_DDP_RESERVE_CUS overrides (0 = off).  Only with the RCCL backend: gloo reduces
+        # on the host.
         import os
         explicit = "VAW_DDP_RESERVE_CUS" in os.environ        # (set explicitly it also applies to a gloo rehearsal: tests)
-        self._reserve = int(os.environ.get("VAW_DDP_RESERVE_CUS", "32")) if (self._cuda and (self._backend_avg or explicit)) else 0
+        self._reserve = int(os.environ.get("VAW_DDP_RESERVE_CUS", "64")) if (self._cuda and (self._backend_avg or explicit)) else 0
         self._reserved_now = False
         module.grad_ready_hook = self._on_stage
 
