@@ -76,6 +76,17 @@ def pmc_traffic(workload, batch):
         return None, None
 
 
+def pmc_collected(src):
+    """Collection date recorded inside a committed traffic fold (tools/pmc_traffic.py writes it), else None."""
+    if not src:
+        return None
+    try:
+        with open(os.path.join(REPO, src)) as f:
+            return json.load(f).get("collected")
+    except (OSError, ValueError):
+        return None
+
+
 def make_args(**kw):
     a = dict(weight_type="lambda", gamma=0.0, learn_sigma=False, p2_gamma=1, p2_k=1, time_dist=["uniform", -0.8, 0.8],
              learn_align=False, align_type="mse", amp=True, dataset="Latent", class_cond=True, parallel=False,
@@ -203,30 +214,76 @@ def cpu_baseline(wl, batch, budget_s=25.0):
                       f"after 2 warm-up steps at batch {probe_b}"}
 
 
+def visible_gpus():
+    """GPU count WITHOUT any HIP call (torch.cuda.device_count() may reach hipGetDeviceCount, i.e. initialise the runtime in a
+    parent that is about to start child processes): KFD topology nodes with SIMDs are GPUs; HIP_/ROCR_VISIBLE_DEVICES narrow them."""
+    import glob
+    n = 0
+    for path in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            props = dict(line.split()[:2] for line in open(path) if len(line.split()) >= 2)
+        except OSError:
+            continue
+        n += int(props.get("simd_count", "0")) > 0
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and v.strip() != "":
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks as child processes (this parent never touches the
-    GPU: device_count() does not initialise it), relay rank 0's JSON line, exit with the worst return code."""
+    GPU or the HIP runtime), relay rank 0's JSON line, exit with the worst return code.  All children are polled: when one
+    dies the others (parked in a collective) are terminated instead of waiting for the backend watchdog, and every rank's
+    stderr is kept."""
     import socket
     import subprocess
+    import tempfile
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    if torch.cuda.device_count() < n and "VAW_REHEARSE_ONE_GPU" not in base:
-        raise SystemExit(f"--gpus {n} but only {torch.cuda.device_count()} visible (VAW_REHEARSE_ONE_GPU=1 rehearses the "
+    have = visible_gpus()
+    if have < n and "VAW_REHEARSE_ONE_GPU" not in base:
+        raise SystemExit(f"--gpus {n} but only {have} visible (VAW_REHEARSE_ONE_GPU=1 rehearses the "
                          f"{n}-rank control flow on one GPU over gloo; its numbers are not a multi-GPU measurement)")
-    procs = []
+    procs, logs = [], []
+    out0 = tempfile.TemporaryFile(mode="w+")
     for r in range(n):
         env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        err = tempfile.TemporaryFile(mode="w+")
+        logs.append(err)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        rc = rc or p.wait()
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=err, text=True))
+    rc, live = 0, set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f"[bench] rank {r} exited with {code}: stopping the other ranks", file=sys.stderr, flush=True)
+                for o in live:
+                    procs[o].terminate()
+                deadline = time.time() + 10
+                while any(procs[o].poll() is None for o in live) and time.time() < deadline:
+                    time.sleep(0.2)
+                for o in live:
+                    if procs[o].poll() is None:
+                        procs[o].kill()
+        time.sleep(0.05)
+    for r, err in enumerate(logs):
+        err.seek(0)
+        text = err.read()
+        if text and (r == 0 or rc != 0):
+            sys.stderr.write("".join(f"[rank {r}] {ln}\n" for ln in text.splitlines()) if r else text)
+    out0.seek(0)
     # rank 0's stdout may carry backend chatter (e.g. gloo's connection notice): relay the result line alone on stdout
-    for line in out.splitlines():
+    for line in out0.read().splitlines():
         (sys.stdout if line.startswith('{"metric"') else sys.stderr).write(line + "\n")
     sys.stdout.flush()
     raise SystemExit(rc)
@@ -369,7 +426,8 @@ def main():
                                       f"AdamW + EMA; global batch {main_res['global_batch']} = {main_res['per_gpu_batch']} per GPU",
                           "global_batch": main_res["global_batch"], "per_gpu_batch": main_res["per_gpu_batch"],
                           "parallelism": f"dp{world}", "weight_type": args.weight_type, "last_loss": main_res["last_loss"],
-                          "grad_bucket_dtype": a.bucket_dtype if parallel else None}}
+                          "grad_bucket_dtype": a.bucket_dtype if parallel else None,
+                          "ddp_reserved_cus": net.reserved_cus if parallel else None}}
         if weak_res is not None:
             rec["weak"] = dict(weak_res, scaling="weak", note=f"same process, {B} images per GPU")
         if wl["gflop_per_img"]:
@@ -393,9 +451,11 @@ def main():
                               "LDS-DMA ring, counted vmcnt) for the large Linear launches, gemm_bf16_kernel (128 x 128) for the rest; "
                               "fwd/dgrad/wgrad variants",
                     "bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
-                    "traffic_unit": "HBM bytes per launch (PMC, separate passes)",
+                    "traffic_unit": "HBM bytes per launch (PMC, separate rocprofv3 --pmc passes of this command; a COMMITTED-PROFILE "
+                                    "figure, not measured in this run: see traffic_source / traffic_collected)",
                     "frac": round(ach / peak, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": round(sum(v["bytes"] for v in fast.values()) / n_l), "traffic_source": src,
+                    "traffic_collected": pmc_collected(src),
                     "launches_per_step": n_l / traced_steps, "avg_launch_us": round(1e3 * t_ms / n_l, 2),
                     "traced_steps": traced_steps, "traced_where": "extra steps after the timed region",
                     "gemm_share_of_step": round(t_ms / traced_steps / ms, 4),

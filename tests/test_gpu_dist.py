@@ -62,9 +62,11 @@ def _one_step(vaw_amd, net, model, x, y, t, noise, micro=1):
             terms = diff.training_losses(net, x[sl], None, t=t[sl], model_kwargs={"y": y[sl]}, noise=noise[sl])
             (terms["loss"].mean() / micro).backward()
         mses.append(terms["mse"].detach().cpu())
+    torch.cuda.synchronize()
+    grads = model.flat_grads().detach().cpu().clone()      # what the wrapper is responsible for: the averaged flat gradient
     opt.step()
     torch.cuda.synchronize()
-    return torch.cat(mses), model._flat.detach().cpu().clone()
+    return torch.cat(mses), model._flat.detach().cpu().clone(), grads
 
 
 def _worker(rank, world, port, q, kind, variant):
@@ -81,11 +83,11 @@ def _worker(rank, world, port, q, kind, variant):
                 model._flat.add_(0.5)                      # ranks start different: the wrapper's broadcast must equalise them
         net = vaw_amd.DistributedDataParallel(model, bucket_dtype="bf16" if variant == "bf16_buckets" else "f32")
         x, y, t, noise = (v[4 * rank:4 * rank + 4].to(dev) for v in _data(kind))
-        mse, flat = _one_step(vaw_amd, net, model, x, y, t, noise, micro=2 if variant == "no_sync" else 1)
-        q.put((rank, mse.numpy(), flat.numpy(), None))      # by value: the worker exits before the parent reads
+        mse, flat, grads = _one_step(vaw_amd, net, model, x, y, t, noise, micro=2 if variant == "no_sync" else 1)
+        q.put((rank, mse.numpy(), flat.numpy(), grads.numpy(), None))      # by value: the worker exits before the parent reads
         vaw_amd.dist_util.cleanup_dist()
     except Exception:
-        q.put((rank, None, None, traceback.format_exc()))
+        q.put((rank, None, None, None, traceback.format_exc()))
 
 
 @pytest.mark.parametrize("kind,variant", [("dit", "sync"), ("dit", "no_sync"), ("dit", "bf16_buckets"), ("unet", "sync"), ("unet", "no_sync")])
@@ -94,7 +96,7 @@ def test_two_rank_step_reproduces_single_rank_step(kind, variant):
     dev = torch.device("cuda", 0)
     model = _build(vaw_amd, dev, kind)
     x, y, t, noise = (v.to(dev) for v in _data(kind))
-    mse1, flat1 = _one_step(vaw_amd, model, model, x, y, t, noise)
+    mse1, flat1, grads1 = _one_step(vaw_amd, model, model, x, y, t, noise)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -103,13 +105,24 @@ def test_two_rank_step_reproduces_single_rank_step(kind, variant):
         p.start()
     res = {}
     for _ in range(2):
-        rank, mse, flat, err = q.get(timeout=300)
+        rank, mse, flat, grads, err = q.get(timeout=300)
         assert err is None, err
-        res[rank] = (torch.from_numpy(mse), torch.from_numpy(flat))
+        res[rank] = (torch.from_numpy(mse), torch.from_numpy(flat), torch.from_numpy(grads))
     for p in procs:
         p.join(timeout=60)
     # per-sample objective: each rank's half equals the corresponding half of the single-rank batch
     torch.testing.assert_close(torch.cat([res[0][0], res[1][0]]), mse1, rtol=1e-5, atol=1e-7)
+    # the averaged flat gradient itself: bitwise equal on both ranks, and equal to the single-rank gradient of the whole batch
+    # within 1e-6 of the tensor's rms (f32 buckets: only the order of summation differs; bf16 buckets round each rank's
+    # contribution to 8 bits on the wire: 2^-8 relative per element)
+    assert torch.equal(res[0][2], res[1][2])
+    rms = float(grads1.pow(2).mean().sqrt())
+    gd = (res[0][2] - grads1).abs()
+    if variant == "bf16_buckets":       # each rank's share and the wire sum are rounded to 8 significant bits
+        tol = 2.0 ** -7 * grads1.abs() + 2.0 ** -6 * rms
+    else:                               # order of summation only: 1e-6 of the tensor's rms (+ f32 rounding of large elements)
+        tol = 1e-6 * rms + 2e-6 * grads1.abs()
+    assert bool((gd <= tol).all()), (float(gd.max()), rms, int((gd > tol).sum()))
     # averaged gradients -> identical AdamW update on both ranks, equal to the single-rank update (reduction-order tolerance)
     assert torch.equal(res[0][1], res[1][1])
     if variant == "bf16_buckets":       # the sum is taken in bf16 on the wire: AdamW's first step is +-lr per element whatever the

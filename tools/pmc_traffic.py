@@ -36,7 +36,9 @@ def main():
     sel = {k: v for k, v in rows.items() if key in k}
     n = sum(v["launches"] for v in sel.values())
     total = sum(v["launches"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) for v in sel.values())
+    import datetime
     rec = {"kernel": key, "launches": n, "hbm_bytes_per_launch": total / n,
+           "collected": datetime.datetime.now(datetime.timezone.utc).strftime("%Y-%m-%dT%H:%MZ"),
            "note": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, KiB -> bytes; separate PMC passes of the same command",
            "by_kernel": {k[:100]: v for k, v in sorted(sel.items(), key=lambda kv: -kv[1]["launches"])}}
     json.dump(rec, open(out, "w"), indent=1)

@@ -168,6 +168,13 @@ class FlatModule(nn.Module):
             self._weights_epoch += 1
         return self._flat_shadow
 
+    def mark_weights_changed(self):
+        """The flat buffer was rewritten through raw pointers (fused AdamW+EMA kernel on an EMA copy, `ops.ema_update`,
+        a sharded optimizer's all-gather): parameter `_version`s did not move, so drop every derived copy explicitly --
+        the bf16 shadow is re-cast and the fp8 weights (dit.py) re-quantised on the next forward."""
+        self._shadow_version = None
+        self._weights_epoch = getattr(self, "_weights_epoch", 0) + 1
+
     def mark_shadow_fresh(self):
         """Called by the fused optimizer after it rewrote parameters AND shadow in one pass."""
         self._weights_epoch += 1          # (other derived copies -- the fp8 weights of dit.py -- follow this counter)

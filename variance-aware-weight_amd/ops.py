@@ -213,6 +213,9 @@ class Fp8:
                                                    self.R, self.state.data_ptr(), stream_ptr()), "vaw_fp8_quantize_delayed")
         else:
             fp8_quantize(src_dt, src, self.R, self.C, ld or self.C, q.data_ptr(), ptr(self.qt), self.scale.data_ptr(), self.fmt, self.device)
+            # leave this pass's max |x| in the running-max slot too: the first vaw_fp8_scale_update after a just-in-time pass then
+            # yields amax * margin / FMAX like every later one (otherwise the first delayed step would run without headroom)
+            torch.mul(self.state[0:1], FP8_MAX[self.fmt], out=self.state[1:2])
         self.last_q = q.data_ptr()
         return self
 

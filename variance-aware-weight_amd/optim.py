@@ -88,6 +88,8 @@ class FusedAdamW(torch.optim.Optimizer):
         if ema_flat is not None and ema_flat.numel() > n:
             ops.ema_update(ema_flat[n:], m._flat[n:], self.ema_decay)   # frozen entries (pos_embed) are EMA'd too
         m.mark_shadow_fresh()
+        if self.ema_model is not None:
+            self.ema_model.mark_weights_changed()      # its bf16 / fp8 copies (periodic sampling, eval) follow the new average
         self.ema_done_in_step = ema_flat is not None
 
     def zero_grad(self, set_to_none=True):

@@ -74,7 +74,27 @@ class DistributedDataParallel(nn.Module):
         return bounds()
 
     def forward(self, *args, **kwargs):
+        if self._reserved_now or self._pending or self._issued:
+            self._abandon()          # a backward that raised never reached finish(): do not run the next step on its leftovers
         return self.module(*args, **kwargs)
+
+    @property
+    def reserved_cus(self):
+        """CUs the persistent GEMM grids leave to the collectives during a synchronised backward (0 = none)."""
+        return self._reserve
+
+    def _abandon(self):
+        """Drop the bookkeeping of an interrupted backward: wait for its collectives, give the reserved CUs back."""
+        for work, _, _ in self._pending:
+            try:
+                work.wait()
+            except Exception:
+                pass
+        self._pending, self._issued = [], 0
+        if self._reserved_now:
+            from . import _lib
+            _lib.lib().vaw_p8_set_reserved_cus(0)
+            self._reserved_now = False
 
     @contextmanager
     def no_sync(self):

@@ -1,5 +1,5 @@
 """Timestep respacing for the sampling side: same names and behaviour as the reference's tools/respace.py
-(space_timesteps :8-62, SpacedDiffusion :65-112, _WrappedModel :115-130) over the HIP-backed GaussianDiffusion."""
+(space_timesteps :8-62, SpacedDiffusion :65-112; its model wrapper :115-130 is a closure here) over the HIP-backed GaussianDiffusion."""
 import numpy as np
 import torch
 
@@ -57,37 +57,35 @@ class SpacedDiffusion(GaussianDiffusion):
         super().__init__(**kwargs)
 
     def _reverse_step(self, kind, model, *args, **kwargs):       # p_mean_variance / p_sample / ddim_sample all come here
-        return super()._reverse_step(kind, self._wrap_model(model), *args, **kwargs)
+        return super()._reverse_step(kind, self._respaced(model), *args, **kwargs)
 
     def training_losses(self, model, *args, **kwargs):
-        return super().training_losses(self._wrap_model(model), *args, **kwargs)
-
-    def _wrap_model(self, model):
-        if isinstance(model, _WrappedModel):
-            return model
-        return _WrappedModel(model, self.timestep_map, self.rescale_timesteps, self.original_num_steps)
+        return super().training_losses(self._respaced(model), *args, **kwargs)
 
     def _scale_timesteps(self, t):
-        return t            # scaling is done by the wrapped model
+        return t            # the respaced call (below) hands the model original, already rescaled timesteps
 
+    def _kept_steps_on(self, like):
+        """The kept original timesteps k_j as a tensor living beside `like` (one upload per device / index dtype)."""
+        cache = self.__dict__.setdefault("_kept_cache", {})
+        key = (like.device, like.dtype)
+        if key not in cache:
+            cache[key] = torch.as_tensor(self.timestep_map, device=like.device, dtype=like.dtype)
+        return cache[key]
 
-class _WrappedModel:
-    def __init__(self, model, timestep_map, rescale_timesteps, original_num_steps):
-        self.model = model
-        self.timestep_map = timestep_map
-        self.rescale_timesteps = rescale_timesteps
-        self.original_num_steps = original_num_steps
-        self._map = {}
+    def _respaced(self, model):
+        """Callable with the model's signature that receives indices j of the SHORT chain and evaluates the model at the
+        ORIGINAL timestep k_j (times 1000 / T_original when rescale_timesteps), what the reference's `_WrappedModel`
+        (tools/respace.py:115-130) does.  A model wrapped once is passed through unchanged."""
+        if getattr(model, "_vaw_respaced_by", None) is self:
+            return model
+        factor = 1000.0 / self.original_num_steps if self.rescale_timesteps else None
 
-    def parameters(self):
-        return self.model.parameters()
+        def call(x, j, **kwargs):
+            k = self._kept_steps_on(j).index_select(0, j.reshape(-1)).reshape(j.shape)
+            return model(x, k.float() * factor if factor is not None else k, **kwargs)
 
-    def __call__(self, x, ts, **kwargs):
-        key = (str(ts.device), ts.dtype)
-        m = self._map.get(key)
-        if m is None:
-            m = self._map[key] = torch.tensor(self.timestep_map, device=ts.device, dtype=ts.dtype)
-        new_ts = m[ts]
-        if self.rescale_timesteps:
-            new_ts = new_ts.float() * (1000.0 / self.original_num_steps)
-        return self.model(x, new_ts, **kwargs)
+        call._vaw_respaced_by = self
+        if hasattr(model, "parameters"):
+            call.parameters = model.parameters      # GaussianDiffusion asks the model for its device through this
+        return call

@@ -31,10 +31,13 @@ def ema(source, target, decay):
             s.ensure_flat(); t.ensure_flat()
             if s._flat_offsets == t._flat_offsets and s._flat.is_cuda and not list(s.buffers()):
                 ops.ema_update(t._flat, s._flat, decay)
+                t.mark_weights_changed()
                 return
         src, dst = source.state_dict(), target.state_dict()
         for k in src:
             dst[k].data.copy_(dst[k].data * decay + src[k].data * (1 - decay))
+        if isinstance(t, FlatModule) and getattr(t, "_flat", None) is not None:
+            t.mark_weights_changed()           # `.data` writes do not move parameter versions either
 
 
 def sample_from_latent(latent, latent_scale=1.0, cpu_rng=False):
