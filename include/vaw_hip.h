@@ -109,6 +109,11 @@ typedef struct {
                             * the dy tiles the MFMA kernel stages anyway (one extra MFMA against a ones operand, fixed
                             * order); other layouts / the generic kernel honour it with a separate pass.  Needs the workspace */
     float rowsum_a_beta;
+    float* colsum_partial_out;  /* deferred form of colsum_out (which must then be NULL): the kernel leaves its per-row-tile partial
+                                 * column sums of C, [*colsum_rows_out][N] f32 (at most ceil(M/128) rows: size the buffer for that),
+                                 * here and does NOT fold them; the caller folds many such buffers in one launch
+                                 * (vaw_reduce_rows_batched).  No workspace needed for it */
+    int64_t* colsum_rows_out;   /* HOST address that receives the number of partial rows written (required with the above) */
 } vaw_epilogue;
 
 /* C[M,N] = epilogue( alpha * op(A)[M,K] . op(B)[K,N] )
@@ -197,6 +202,19 @@ int vaw_colsum(vaw_dtype dt, const void* X, int64_t M, int64_t N, int64_t ldx, f
                float* workspace, int64_t workspace_floats, vaw_stream stream);
 /* out[n] = beta*out[n] + sum_{r<R} partial[r,n], r ascending (second stage of the fixed-order column sums) */
 int vaw_reduce_rows(const float* partial, int64_t R, int64_t N, float* out, float beta, vaw_stream stream);
+/* The same fold for MANY (partial, out) pairs in one launch: out_j[n] = beta*out_j[n] + sum_{r<R_j} partial_j[r,n], each with
+ * vaw_reduce_rows' summation tree (bitwise the same results).  Used for the bias gradients of all Linear layers of a group of
+ * DiT blocks (autograd of `x W^T + b`, models/dit.py:126-137: db = sum_rows dy), whose partial rows the dy-producing kernels
+ * leave behind: one launch per group instead of one per layer.  jobs: host array; desc_dev: device buffer of
+ * vaw_reduce_rows_batched_desc_bytes(n_jobs) bytes that receives the table when upload != 0 (addresses are static between
+ * steps: upload once). */
+typedef struct {
+    const float* partial;  /* f32 [R][N] */
+    float* out;            /* f32 [N] */
+    int64_t R, N;
+} vaw_reduce_job;
+int64_t vaw_reduce_rows_batched_desc_bytes(int n_jobs);
+int vaw_reduce_rows_batched(int n_jobs, const vaw_reduce_job* jobs, float beta, void* desc_dev, int upload, vaw_stream stream);
 
 /* ---------------------------------------------------------------------------
  * DiT pieces  (models/dit.py)
@@ -233,6 +251,20 @@ int64_t vaw_row_bwd_workspace_floats(int B, int T, int D);
  *   bias gradient of the branch's last Linear without re-reading dy. */
 int vaw_gate_bwd(vaw_dtype dt, const float* dres, const void* y, const float* gate, int64_t mod_ld, void* dy,
                  float* dgate, int64_t dmod_ld, float* dy_colsum_partial, int B, int T, int D, float* workspace, int64_t workspace_floats, vaw_stream stream);
+/* vaw_ln_modulate_bwd and the vaw_gate_bwd that consumes its dx, as ONE pass over the rows (autograd of models/dit.py:135-136
+ * walked backwards: the LayerNorm+modulate of a branch, then the gated residual add in front of it): dx as vaw_ln_modulate_bwd;
+ * dy_next = dx * gate_next (act dtype), dgate_next[b,:] = sum_t dx * y_next, dy_colsum_partial [B,D] = per-sample sum_t dy_next.
+ * dgate_next shares dmod_ld with dshift / dscale.  Saves the re-read of dx (f32) and a launch; bitwise equal to the pair. */
+int vaw_ln_modulate_bwd_gate(vaw_dtype dt, const void* dout, const float* x, const float* mean, const float* rstd,
+                             const float* scale, int64_t mod_ld, const float* dres_in, float* dx, float* dshift, float* dscale,
+                             int64_t dmod_ld, const void* y_next, const float* gate_next, void* dy_next, float* dgate_next,
+                             float* dy_colsum_partial, int B, int T, int D, float* workspace, int64_t workspace_floats, vaw_stream stream);
+/* fp8 mode: dy_next as fp8 bytes of its bf16 roundings (see vaw_gate_bwd_fp8) */
+int vaw_ln_modulate_bwd_gate_fp8(const void* dout, const float* x, const float* mean, const float* rstd, const float* scale,
+                                 int64_t mod_ld, const float* dres_in, float* dx, float* dshift, float* dscale, int64_t dmod_ld,
+                                 const void* y_next, const float* gate_next, void* dy_q, float* q_state, vaw_dtype q_format,
+                                 float* dgate_next, float* dy_colsum_partial, int B, int T, int D, float* workspace,
+                                 int64_t workspace_floats, vaw_stream stream);
 
 /* timm PatchEmbed (dit.py:192) input side: x f32 [B,C,H,W] -> tokens act dtype [B*(H/p)*(W/p), C*p*p],
  * column order (c, i, j) = Conv2d weight flattening. */
@@ -277,6 +309,14 @@ int vaw_attn_fwd(vaw_dtype dt, const vaw_attn_desc* d_host, const void* q, const
 int vaw_attn_bwd(vaw_dtype dt, const vaw_attn_desc* d_host, const void* q, const void* k, const void* v,
                  const void* o, const void* d_o, const float* lse, float* delta, void* dq, void* dk, void* dv,
                  vaw_stream stream);
+/* vaw_attn_bwd that also leaves the column sums of dq | dk | dv behind as PARTIAL rows -- the bias gradient of the qkv Linear in
+ * front of the attention (timm Attention, models/dit.py:126: db = sum over tokens of dqkv) without a second pass over dqkv:
+ * colsum_partial [*rows_out][3*H*hd] f32 in packed-qkv column order [3][H][hd]; at most B*T/64 rows (size the buffer for
+ * that); fold them with vaw_reduce_rows / vaw_reduce_rows_batched.  Only the bf16 MFMA kernels offer it (token-major or any
+ * layout they accept): VAW_ERR_UNSUPPORTED, nothing launched, otherwise -- use vaw_attn_bwd + vaw_colsum then. */
+int vaw_attn_bwd_colsum(vaw_dtype dt, const vaw_attn_desc* d, const void* q, const void* k, const void* v, const void* o,
+                        const void* d_o, const float* lse, float* delta, void* dq, void* dk, void* dv, float* colsum_partial,
+                        int64_t* rows_out, vaw_stream stream);
 
 /* ---------------------------------------------------------------------------
  * UNet pieces  (models/unet.py, tools/nn.py) -- activations are NHWC: [B*H*W pixels, C channels], act dtype

@@ -189,7 +189,7 @@ def _mk(M, N, K, a_k, b_k, dtype, seed, ints=False):
 
 
 @pytest.mark.parametrize("a_k,b_k", [(True, True), (True, False), (False, False), (False, True)])
-@pytest.mark.parametrize("mode", ["f32", "bf16_generic", "bf16_fast", "bf16_big", "bf16_p8_256", "bf16_p8_192"])
+@pytest.mark.parametrize("mode", ["f32", "bf16_generic", "bf16_fast", "bf16_big", "bf16_p8_256", "bf16_p8_192", "bf16_sm64", "bf16_sm128"])
 def test_gemm_layouts_exact_integers(a_k, b_k, mode):
     """Small-integer operands are exact in bf16 and f32: any fragment-layout or swizzle error shows as a
     wrong integer, with asymmetric data on both sides (a symmetric operand would hide a transpose)."""
@@ -204,13 +204,20 @@ def test_gemm_layouts_exact_integers(a_k, b_k, mode):
               if mode.startswith("bf16_p8") else [(256, 384, 192), (70, 45, 23), (129, 1, 17), (5, 200, 64)])
     if mode.startswith("bf16_"):
         dtype = torch.bfloat16
+    if mode.startswith("bf16_sm"):
+        # the small-M kernel (64-row tiles, deep LDS-DMA ring; A k-major only): edge tiles in M and N, K of one tile (ring never
+        # fills), of exactly / fewer / more tiles than the ring is deep, many tiles per XCD run
+        if not a_k:
+            pytest.skip("gemm_sm takes A k-major (forward / input-gradient layouts)")
+        shapes = [(256, 384, 192), (200, 72, 128), (136, 200, 64), (520, 264, 256), (304, 776, 320), (64, 64, 64), (2048, 768, 768),
+                  (1000, 3072, 128), (4096, 128, 3072)]
     lib().vaw_debug_force_generic_gemm(1 if mode == "bf16_generic" else 0)
-    lib().vaw_debug_gemm_tile({"bf16_fast": 0, "bf16_big": 1, "bf16_p8_256": 2, "bf16_p8_192": 3}.get(mode, -1))
+    lib().vaw_debug_gemm_tile({"bf16_fast": 0, "bf16_big": 1, "bf16_p8_256": 2, "bf16_p8_192": 3, "bf16_sm64": 6, "bf16_sm128": 7}.get(mode, -1))
     try:
         for (M, N, K) in shapes:
             A, B = _mk(M, N, K, a_k, b_k, dtype, seed=M + N + K, ints=True)
             Ad, Bd = A.to(DEV), B.to(DEV)
-            if mode in ("bf16_fast", "bf16_big", "bf16_p8_256", "bf16_p8_192"):
+            if mode in ("bf16_fast", "bf16_big", "bf16_p8_256", "bf16_p8_192", "bf16_sm64", "bf16_sm128"):
                 assert lib().vaw_gemm_uses_bf16_mfma(BF16, M, N, K, ptr(Ad), Ad.shape[1], ptr(Bd), Bd.shape[1]) == 1
             got = ops.gemm_t(Ad, Bd, a_kmajor=a_k, b_kmajor=b_k, out_dtype=torch.float32).cpu()
             ref = _gemm_ref(A, B, a_k, b_k)
@@ -240,7 +247,7 @@ def test_gemm_bf16_fast_random_and_large_k(a_k, b_k, tile):
 
 
 @pytest.mark.parametrize("dtype,tile", [(torch.float32, -1), (torch.bfloat16, 0), (torch.bfloat16, 1), (torch.bfloat16, 2),
-                                        (torch.bfloat16, 3)])
+                                        (torch.bfloat16, 3), (torch.bfloat16, 5)])
 def test_gemm_epilogues(dtype, tile):
     lib().vaw_debug_gemm_tile(tile)
     try:
@@ -438,6 +445,55 @@ def test_gate_bwd(dtype):
     torch.testing.assert_close(out.cpu().double(), 1.0 + dy.cpu().double().sum(0), rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,T,D", [(3, 16, 64), (2, 64, 768), (2, 24, 1152), (300, 8, 192)])
+def test_ln_modulate_bwd_fused_with_gate_bwd_is_bitwise_the_pair(dtype, B, T, D):
+    """vaw_ln_modulate_bwd_gate = vaw_ln_modulate_bwd followed by vaw_gate_bwd on its dx, one pass: every output bitwise equal
+    (B = 2, 3: rows split over several workgroups + fold launch; B = 300: one workgroup per sample)."""
+    x = (_rand(B * T, D, seed=1) * 2 + 0.5).to(DEV)
+    mod = (_rand(B, 6 * D, seed=2) * 0.5).to(DEV)
+    dout = _rand(B * T, D, seed=3).to(dtype).to(DEV)
+    dres = _rand(B * T, D, seed=4).to(DEV)
+    y = _rand(B * T, D, seed=5).to(dtype).to(DEV)
+    mean, rstd = torch.empty(B * T, device=DEV), torch.empty(B * T, device=DEV)
+    out = torch.empty(B * T, D, device=DEV, dtype=dtype)
+    dt = ops.dt_of(out)
+    ops.ln_modulate_fwd(dt, ptr(x), ptr(mod) + 4 * 3 * D, ptr(mod) + 4 * 4 * D, 6 * D, ptr(out), ptr(mean), ptr(rstd), B, T, D)
+
+    def run(fused):
+        dmod = torch.zeros(B, 6 * D, device=DEV)
+        dx, dy, part = torch.empty(B * T, D, device=DEV), torch.empty(B * T, D, device=DEV, dtype=dtype), torch.empty(B, D, device=DEV)
+        a = (dt, ptr(dout), ptr(x), ptr(mean), ptr(rstd), ptr(mod) + 4 * 4 * D, 6 * D, ptr(dres), ptr(dx), ptr(dmod) + 4 * 3 * D,
+             ptr(dmod) + 4 * 4 * D, 6 * D)
+        if fused:
+            ops.ln_modulate_bwd_gate(*a, ptr(y), ptr(mod) + 4 * 5 * D, ptr(dy), ptr(dmod) + 4 * 5 * D, B, T, D, ptr(part))
+        else:
+            ops.ln_modulate_bwd(*a, B, T, D)
+            ops.gate_bwd(dt, ptr(dx), ptr(y), ptr(mod) + 4 * 5 * D, 6 * D, ptr(dy), ptr(dmod) + 4 * 5 * D, 6 * D, B, T, D, ptr(part))
+        torch.cuda.synchronize()
+        return dx, dy, dmod, part
+    for u, f in zip(run(False), run(True)):
+        assert torch.equal(u, f)
+
+
+def test_reduce_rows_batched_is_bitwise_reduce_rows():
+    """One launch for many (partial rows -> column sums) folds, each with vaw_reduce_rows' summation tree."""
+    shapes = [(256, 768), (128, 3072), (1, 2304), (37, 40), (300, 8), (33, 1000)]
+    parts = [(_rand(R, N, seed=10 + i) * 3).to(DEV) for i, (R, N) in enumerate(shapes)]
+    for beta in (0.0, 1.0):
+        ref = [(_rand(N, seed=50 + i)).to(DEV) for i, (R, N) in enumerate(shapes)]
+        got = [r.clone() for r in ref]
+        for p_, r_ in zip(parts, ref):
+            ops.reduce_rows(ptr(p_), p_.shape[0], p_.shape[1], ptr(r_), beta)
+        grp = ops.ReduceGroup([(ptr(p_), ptr(g_), p_.shape[0], p_.shape[1]) for p_, g_ in zip(parts, got)], torch.device(DEV))
+        grp.launch(beta)
+        torch.cuda.synchronize()
+        for r_, g_, p_ in zip(ref, got, parts):
+            assert torch.equal(r_, g_)
+            if beta == 0.0:
+                torch.testing.assert_close(g_.cpu().double(), p_.cpu().double().sum(0), rtol=1e-5, atol=1e-4)
+
+
 # ------------------------------------------------------------------------------------------------
 # attention: both memory layouts, forward + backward
 # ------------------------------------------------------------------------------------------------
@@ -456,10 +512,12 @@ def test_attention_token_major(dtype, rowwise, B, H, T, hd):
     are zero-padded to 96 in LDS and must not spill into the neighbouring head); the others always run rowwise."""
     tol = dict(rtol=1e-4, atol=2e-5) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2)
     lib().vaw_debug_force_rowwise_attention(1 if rowwise else 0)
+    _forced_rowwise[0] = bool(rowwise)
     try:
         _attention_token_major(dtype, tol, B, H, T, hd)
     finally:
         lib().vaw_debug_force_rowwise_attention(0)
+        _forced_rowwise[0] = False
 
 
 def _attention_token_major(dtype, tol, B, H, T, hd):
@@ -481,6 +539,25 @@ def _attention_token_major(dtype, tol, B, H, T, hd):
     ops.attn_bwd(dt, desc, ptr(qd), ptr(qd) + es * D, ptr(qd) + 2 * es * D, ptr(o), ptr(dod), ptr(lse), ptr(delta),
                  ptr(dqkv), ptr(dqkv) + es * D, ptr(dqkv) + 2 * es * D)
     torch.testing.assert_close(dqkv.cpu().double(), qr.grad, **tol)
+    # the same backward with the column sums of dq | dk | dv as partial rows (the qkv bias gradient): MFMA kernels only
+    part = ops.ColsumPartial(max(B, B * T // 64), 3 * D, torch.device(DEV))
+    dqkv2 = torch.zeros_like(qd)
+    took = ops.attn_bwd_colsum(dt, desc, ptr(qd), ptr(qd) + es * D, ptr(qd) + 2 * es * D, ptr(o), ptr(dod), ptr(lse), ptr(delta),
+                               ptr(dqkv2), ptr(dqkv2) + es * D, ptr(dqkv2) + 2 * es * D, part)
+    mfma = dtype == torch.bfloat16 and T % 64 == 0 and hd % 8 == 0 and not lib_forced_rowwise()
+    assert took == mfma
+    if took:
+        assert torch.equal(dqkv2, dqkv)
+        R = part.rows.value
+        assert R == (B if T == 64 else B * (T // 64) // (2 if (T % 128 == 0 and 64 < hd <= 96) else 1))
+        torch.testing.assert_close(part.buf[:R].sum(0).cpu().double(), dqkv.cpu().double().sum(0), rtol=1e-5, atol=1e-3)
+
+
+_forced_rowwise = [False]
+
+
+def lib_forced_rowwise():
+    return _forced_rowwise[0]
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -1,14 +1,15 @@
 #!/usr/bin/env python3
-"""Per-step summary of a rocprofv3 --kernel-trace --stats kernel_stats.csv:  python tools/kstats.py <csv> <steps> [rows]"""
+"""Per-step view of a rocprofv3 *_kernel_stats.csv:  python tools/kstats.py <csv> <steps counted in the run> [top]"""
 import csv
-import re
 import sys
 
-path, steps = sys.argv[1], float(sys.argv[2])
-n = int(sys.argv[3]) if len(sys.argv) > 3 else 30
-rows = list(csv.DictReader(open(path)))
+rows = list(csv.DictReader(open(sys.argv[1])))
+steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+top = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
-print(f"total kernel ms/step {tot / steps / 1e6:.3f}")
-for r in rows[:n]:
-    name = re.sub(r"\(.*", "", r["Name"])[:64]
-    print(f"{name:64s} calls/step {int(r['Calls']) / steps:7.1f}  ms/step {float(r['TotalDurationNs']) / steps / 1e6:7.3f}  avg us {float(r['AverageNs']) / 1e3:8.1f}")
+calls = sum(int(r["Calls"]) for r in rows)
+print(f"total {tot / 1e6 / steps:.3f} ms/step, {calls / steps:.0f} launches/step")
+gemm = sum(float(r["TotalDurationNs"]) for r in rows if any(k in r["Name"] for k in ("gemm_", "splitk_reduce", "p8_group_fixup")))
+print(f"GEMM family {gemm / 1e6 / steps:.3f} ms/step, everything else {(tot - gemm) / 1e6 / steps:.3f}")
+for r in rows[:top]:
+    print(f"{r['Name'][:96]:96s} {int(r['Calls']) / steps:7.1f}/step {float(r['TotalDurationNs']) / 1e6 / steps:8.3f} ms  avg {float(r['AverageNs']) / 1e3:8.1f} us")

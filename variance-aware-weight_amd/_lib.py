@@ -17,7 +17,8 @@ _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 class Epilogue(C.Structure):
     _fields_ = [("bias", _p), ("act", _i), ("aux_in", _p), ("aux_out", _p), ("gate", _p), ("gate_ld", _l),
                 ("resid", _p), ("rowadd", _p), ("rows_per_batch", _i), ("alpha", _f), ("beta", _f), ("out_f32", _i),
-                ("colsum_out", _p), ("colsum_beta", _f), ("resid_is_act", _i), ("rowsum_a_out", _p), ("rowsum_a_beta", _f)]
+                ("colsum_out", _p), ("colsum_beta", _f), ("resid_is_act", _i), ("rowsum_a_out", _p), ("rowsum_a_beta", _f),
+                ("colsum_partial_out", _p), ("colsum_rows_out", C.POINTER(C.c_int64))]
 
 
 class AttnDesc(C.Structure):
@@ -38,6 +39,9 @@ _PROTOS = {
     "vaw_ln_modulate_bwd": [_i, _p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _l, _i, _i, _i, _p, _l, _p],
     "vaw_gate_bwd": [_i, _p, _p, _p, _l, _p, _p, _l, _p, _i, _i, _i, _p, _l, _p],
     "vaw_reduce_rows": [_p, _l, _l, _p, _f, _p],
+    "vaw_reduce_rows_batched": [_i, _p, _f, _p, _i, _p],
+    "vaw_ln_modulate_bwd_gate": [_i, _p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _i, _i, _i, _p, _l, _p],
+    "vaw_ln_modulate_bwd_gate_fp8": [_p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _l, _p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _p, _l, _p],
     "vaw_patchify": [_i, _p, _p, _i, _i, _i, _i, _i, _p],
     "vaw_patchify_bwd": [_p, _p, _i, _i, _i, _i, _i, _p],
     "vaw_unpatchify": [_i, _p, _p, _i, _i, _i, _i, _i, _p],
@@ -49,6 +53,7 @@ _PROTOS = {
     "vaw_embedding_bwd": [_p, _p, _p, _i, _i, _i, _f, _p],
     "vaw_attn_fwd": [_i, C.POINTER(AttnDesc), _p, _p, _p, _p, _p, _p],
     "vaw_attn_bwd": [_i, C.POINTER(AttnDesc), _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "vaw_attn_bwd_colsum": [_i, C.POINTER(AttnDesc), _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, C.POINTER(C.c_int64), _p],
     "vaw_groupnorm_fwd": [_i, _p, _p, _p, _p, _p, _l, _i, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p],
     "vaw_groupnorm_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _l, _i, _p, _p, _p, _p, _f, _p, _p, _l, _i, _i, _i, _i, _p, _p],
     "vaw_im2col3x3": [_i, _p, _p, _i, _i, _i, _i, _p],
@@ -115,6 +120,8 @@ def lib():
         L.vaw_groupnorm_workspace_floats.restype = _l
         L.vaw_wgrad_grouped_desc_bytes.argtypes = [_i]
         L.vaw_wgrad_grouped_desc_bytes.restype = _l
+        L.vaw_reduce_rows_batched_desc_bytes.argtypes = [_i]
+        L.vaw_reduce_rows_batched_desc_bytes.restype = _l
         L.vaw_fp8_quantize_workspace_floats.argtypes = []
         L.vaw_fp8_quantize_workspace_floats.restype = _l
         L.vaw_sumsq_workspace_floats.argtypes = []
@@ -137,7 +144,7 @@ def exported_symbols():
     return sorted(list(_PROTOS) + ["vaw_version", "vaw_last_error_string", "vaw_colsum_workspace_floats",
                                    "vaw_sumsq_workspace_floats", "vaw_groupnorm_workspace_floats", "vaw_wgrad_grouped_desc_bytes",
                                    "vaw_conv3x3_wgrad_small_workspace_floats", "vaw_row_bwd_workspace_floats",
-                                   "vaw_fp8_quantize_workspace_floats", "vaw_p8_set_reserved_cus"])
+                                   "vaw_fp8_quantize_workspace_floats", "vaw_p8_set_reserved_cus", "vaw_reduce_rows_batched_desc_bytes"])
 
 
 def check(rc, what):

@@ -181,7 +181,8 @@ attn_bwd_kv_rowwise(AttnDev a, const T* __restrict__ q, const T* __restrict__ k,
 bool vaw_attn_mfma_ok(vaw_dtype dt, const vaw_attn_desc* d, const void* q, const void* k, const void* v, const void* o);
 int vaw_attn_fwd_mfma(const vaw_attn_desc* d, const void* q, const void* k, const void* v, void* o, float* lse, hipStream_t s);
 int vaw_attn_bwd_mfma(const vaw_attn_desc* d, const void* q, const void* k, const void* v, const void* o, const void* d_o,
-                      const float* lse, float* delta, void* dq, void* dk, void* dv, hipStream_t s);
+                      const float* lse, float* delta, void* dq, void* dk, void* dv, hipStream_t s, float* cs_part = nullptr,
+                      int64_t* cs_rows_out = nullptr);
 static int g_force_rowwise = 0;
 extern "C" void vaw_debug_force_rowwise_attention(int on) { g_force_rowwise = on; }
 
@@ -234,4 +235,19 @@ extern "C" int vaw_attn_bwd(vaw_dtype dt, const vaw_attn_desc* d, const void* q,
     }
     VAW_CHECK_LAUNCH("attn_bwd");
     return VAW_OK;
+}
+
+// vaw_attn_bwd that also leaves the column sums of dq | dk | dv behind as partial rows (packed-qkv column order [3][H][hd], the
+// bias layout of timm Attention's qkv Linear): colsum_partial [*rows_out][3 H hd] f32, at most B * T / 64 rows.  Only the bf16
+// MFMA kernels offer it: VAW_ERR_UNSUPPORTED (nothing launched) otherwise -- call vaw_attn_bwd and vaw_colsum then.
+extern "C" int vaw_attn_bwd_colsum(vaw_dtype dt, const vaw_attn_desc* d, const void* q, const void* k, const void* v, const void* o,
+                                   const void* d_o, const float* lse, float* delta, void* dq, void* dk, void* dv,
+                                   float* colsum_partial, int64_t* rows_out, vaw_stream stream) {
+    int rc = check_desc(d, "attn_bwd_colsum");
+    if (rc) return rc;
+    VAW_CHECK_ARG(colsum_partial && rows_out, "attn_bwd_colsum: colsum_partial and rows_out are required");
+    if (!g_force_rowwise && vaw_attn_mfma_ok(dt, d, q, k, v, d_o) && (((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 7) == 0 && d->hd % 4 == 0)
+        return vaw_attn_bwd_mfma(d, q, k, v, o, d_o, lse, delta, dq, dk, dv, (hipStream_t)stream, colsum_partial, rows_out);
+    vaw_set_error("attn_bwd_colsum: only the bf16 MFMA attention kernels carry column sums");
+    return VAW_ERR_UNSUPPORTED;
 }

@@ -89,6 +89,39 @@ __device__ __forceinline__ float group_sum(float v) {   // over the 4 lanes l, l
     v += __shfl_xor(v, 32, 64);
     return v;
 }
+
+// Column sums of a [rows][hd] gradient block held as transposed accumulator tiles (a lane owns row li = lane & 15 of its wave's
+// 16 rows, columns 16 dt + 4 g .. + 3): the values AS STORED (bf16 roundings) are summed over the 16 rows of the wave by
+// shuffles and left in this wave's slot cs_w [16 DT] of the workgroup's LDS scratch; attn_cs_commit folds the four waves in a
+// fixed order.  The qkv bias gradient (autograd of timm Attention's qkv Linear, models/dit.py:126) is the sum of these over all
+// tokens: taking them here saves re-reading dqkv (75 MB per DiT-B/4 block) in a separate column-sum pass.
+__device__ __forceinline__ f32x4 as_stored_bf16(f32x4 a) {
+    return f32x4{(float)(bf16_t)a[0], (float)(bf16_t)a[1], (float)(bf16_t)a[2], (float)(bf16_t)a[3]};
+}
+template <int DT>
+__device__ __forceinline__ void attn_cs_wave(const f32x4 (&stored)[DT], float* cs_w, int lane) {      // stored: as_stored_bf16 values
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        f32x4 v = stored[dt];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] += __shfl_xor(v[j], 1, 64); v[j] += __shfl_xor(v[j], 2, 64);
+            v[j] += __shfl_xor(v[j], 4, 64); v[j] += __shfl_xor(v[j], 8, 64);
+        }
+        if ((lane & 15) == 0) store4(cs_w + 16 * dt + 4 * (lane >> 4), v);
+    }
+}
+// after a workgroup barrier: out[c] = ((w0 + w1) + w2) + w3 for the hd real columns of `n_which` quantities (cs: [which][4 waves][HD])
+// quantity w of the scratch goes to columns (first_which + w) * H hd + h hd + c of the partial row (packed qkv order [3][H][hd])
+template <int HD>
+__device__ __forceinline__ void attn_cs_commit(const float* cs, int n_which, int first_which, int hd, int Hhd, int h, float* out_row) {
+    for (int i = threadIdx.x; i < n_which * HD; i += blockDim.x) {
+        const int w = i / HD, c = i - w * HD;
+        if (c >= hd) continue;
+        const float* p = cs + w * 4 * HD + c;
+        out_row[(first_which + w) * Hhd + h * hd + c] = ((p[0] + p[HD]) + p[2 * HD]) + p[3 * HD];
+    }
+}
 __device__ __forceinline__ float group_max(float v) {
     v = fmaxf(v, __shfl_xor(v, 16, 64));
     v = fmaxf(v, __shfl_xor(v, 32, 64));
@@ -229,7 +262,7 @@ template <int HD, int G>
 __global__ void __launch_bounds__(256)
 attn_bwd_dq_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                  const bf16_t* __restrict__ o, const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
-                 float* __restrict__ delta_out, bf16_t* __restrict__ dq) {
+                 float* __restrict__ delta_out, bf16_t* __restrict__ dq, float* __restrict__ cs_part = nullptr, int64_t cs_ld = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 G + 2 images of 64 x HD bf16
     constexpr int KS = HD / 32, DT = HD / 16, IMG = Img<HD>::BYTES;
     char* qimg = smem;                       // G images
@@ -325,6 +358,20 @@ attn_bwd_dq_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __r
         for (int dt = 0; dt < DT; ++dt)
             if (16 * dt + 4 * g < a.hd) store4(row + 16 * dt, acc[u][dt]);
     }
+    if (cs_part) {     // per-(sample, query block) column sums of dq -> cs_part[b * gridDim.x + block][0 * H hd + h hd + c]
+        __syncthreads();                          // the K / V images are free now: reuse the first one as scratch
+        float* cs = reinterpret_cast<float*>(smem);
+        f32x4 t[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {         // groups folded in order, each value rounded as stored
+            t[dt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < G; ++u) t[dt] += as_stored_bf16(acc[u][dt]);
+        }
+        attn_cs_wave<DT>(t, cs + wid * HD, lane);
+        __syncthreads();
+        attn_cs_commit<HD>(cs, 1, 0, a.hd, a.H * a.hd, h, cs_part + ((int64_t)b * gridDim.x + blockIdx.x) * cs_ld);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -334,7 +381,7 @@ template <int HD, int G>
 __global__ void __launch_bounds__(256)
 attn_bwd_dkv_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                   const bf16_t* __restrict__ d_o, const float* __restrict__ lse, const float* __restrict__ delta,
-                  bf16_t* __restrict__ dk, bf16_t* __restrict__ dv) {
+                  bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, float* __restrict__ cs_part = nullptr, int64_t cs_ld = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 G + 2 images of 64 x HD bf16 + lse / delta of the query block
     constexpr int KS = HD / 32, DT = HD / 16, IMG = Img<HD>::BYTES;
     char* kimg = smem;                       // G images
@@ -433,6 +480,24 @@ attn_bwd_dkv_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __
             store4(dk + off + 16 * dt, ak[u][dt]);
         }
     }
+    if (cs_part) {     // per-(sample, key block) column sums of dk | dv -> columns H hd + h hd + c and 2 H hd + h hd + c
+        __syncthreads();                          // the Q / dO images are free now
+        float* cs = reinterpret_cast<float*>(qimg);                    // [2][4 waves][HD] floats <= 2 images
+        f32x4 tk[DT], tv[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            tk[dt] = tv[dt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                tk[dt] += as_stored_bf16(ak[u][dt]);
+                tv[dt] += as_stored_bf16(av[u][dt]);
+            }
+        }
+        attn_cs_wave<DT>(tk, cs + wid * HD, lane);
+        attn_cs_wave<DT>(tv, cs + 4 * HD + wid * HD, lane);
+        __syncthreads();
+        attn_cs_commit<HD>(cs, 2, 1, a.hd, a.H * a.hd, h, cs_part + ((int64_t)b * gridDim.x + blockIdx.x) * cs_ld);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -445,8 +510,9 @@ template <int HD>
 __global__ void __launch_bounds__(256)
 attn_bwd_t64_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                   const bf16_t* __restrict__ o, const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
-                  float* __restrict__ delta_out, bf16_t* __restrict__ dq, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 images of 64 x HD bf16 + lse / delta
+                  float* __restrict__ delta_out, bf16_t* __restrict__ dq, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv,
+                  float* __restrict__ cs_part = nullptr, int64_t cs_ld = 0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 images of 64 x HD bf16 + lse / delta + column-sum scratch [3][4][HD] f32
     constexpr int KS = HD / 32, DT = HD / 16;
     char* qimg = smem;
     char* gimg = qimg + Img<HD>::BYTES;
@@ -454,6 +520,7 @@ attn_bwd_t64_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __
     char* vimg = kimg + Img<HD>::BYTES;
     float* lse_s = reinterpret_cast<float*>(vimg + Img<HD>::BYTES);
     float* del_s = lse_s + 64;
+    float* cs = del_s + 64;
     const int lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
@@ -514,6 +581,11 @@ attn_bwd_t64_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
             if (16 * dt + 4 * g < a.hd) store4(row + 16 * dt, acc[dt]);
+        if (cs_part) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) acc[dt] = as_stored_bf16(acc[dt]);
+            attn_cs_wave<DT>(acc, cs + wid * HD, lane);
+        }
     }
     // ---- phase 2: dK, dV of this wave's 16 keys (all four images stay as staged; lse_s / del_s were written before the sync) ----
     {
@@ -559,6 +631,16 @@ attn_bwd_t64_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __
             store4(dv + off + 16 * dt, av[dt]);
             store4(dk + off + 16 * dt, ak[dt]);
         }
+        if (cs_part) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) { ak[dt] = as_stored_bf16(ak[dt]); av[dt] = as_stored_bf16(av[dt]); }
+            attn_cs_wave<DT>(ak, cs + 4 * HD + wid * HD, lane);
+            attn_cs_wave<DT>(av, cs + 8 * HD + wid * HD, lane);
+        }
+    }
+    if (cs_part) {     // this (sample, head)'s column sums of dq | dk | dv -> its columns of the sample's partial row [3 H hd]
+        __syncthreads();
+        attn_cs_commit<HD>(cs, 3, 0, a.hd, a.H * a.hd, h, cs_part + (int64_t)b * cs_ld);
     }
 }
 
@@ -627,17 +709,21 @@ int vaw_attn_fwd_mfma(const vaw_attn_desc* d, const void* q, const void* k, cons
     return VAW_OK;
 }
 
+// cs_part (may be NULL): [cs_rows][3 H hd] f32 partial column sums of dq | dk | dv, one row per (sample, 64 G-token block);
+// *cs_rows_out receives the row count
 int vaw_attn_bwd_mfma(const vaw_attn_desc* d, const void* q, const void* k, const void* v, const void* o, const void* d_o,
-                      const float* lse, float* delta, void* dq, void* dk, void* dv, hipStream_t s) {
+                      const float* lse, float* delta, void* dq, void* dk, void* dv, hipStream_t s, float* cs_part, int64_t* cs_rows_out) {
     AttnMfmaArgs a = mk_args(d);
+    const int64_t cs_ld = 3LL * d->H * d->hd;
     dim3 grid(d->T / 64, d->B * d->H);
     if (d->T == 64) {      // single block of queries and keys: one fused launch
         DISPATCH_HD(d->hd,
-            const int lds = 4 * Img<HD>::BYTES + 2 * 64 * 4;
+            const int lds = 4 * Img<HD>::BYTES + 2 * 64 * 4 + 12 * HD * 4;
             (void)hipFuncSetAttribute((const void*)attn_bwd_t64_mfma<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             attn_bwd_t64_mfma<HD><<<d->B * d->H, 256, lds, s>>>(a, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o,
-                                                              (const bf16_t*)d_o, lse, delta, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv);
+                                                              (const bf16_t*)d_o, lse, delta, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, cs_part, cs_ld);
         )
+        if (cs_rows_out) *cs_rows_out = d->B;
         VAW_CHECK_LAUNCH("attn_bwd_t64_mfma");
         return VAW_OK;
     }
@@ -650,9 +736,10 @@ int vaw_attn_bwd_mfma(const vaw_attn_desc* d, const void* q, const void* k, cons
         (void)hipFuncSetAttribute((const void*)attn_bwd_dq_mfma<HD, Gv>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);       \
         (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_mfma<HD, Gv>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);      \
         attn_bwd_dq_mfma<HD, Gv><<<gridg, 256, lds, s>>>(a, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o, \
-                                                        (const bf16_t*)d_o, lse, delta, (bf16_t*)dq);                            \
+                                                        (const bf16_t*)d_o, lse, delta, (bf16_t*)dq, cs_part, cs_ld);            \
         attn_bwd_dkv_mfma<HD, Gv><<<gridg, 256, lds, s>>>(a, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)d_o, \
-                                                         lse, delta, (bf16_t*)dk, (bf16_t*)dv);                                  \
+                                                         lse, delta, (bf16_t*)dk, (bf16_t*)dv, cs_part, cs_ld);                  \
+        if (cs_rows_out) *cs_rows_out = (int64_t)d->B * (d->T / (64 * Gv));                                                      \
     } while (0)
     // measured (tools/attn_bench.py, T = 256 / 1024): two groups are +10 % on the 96-wide images with 96 real channels
     // (UNet_64), neutral on DiT-XL's 72-in-96, and 10-20 % SLOWER on 64-wide images, where the third resident workgroup is

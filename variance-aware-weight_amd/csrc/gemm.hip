@@ -726,6 +726,8 @@ struct P8Plan {
     int ntw, split, grid;
 };
 P8Plan vaw_p8_plan(int64_t M, int64_t N, int64_t K, bool plain_f32, bool want_colsum, int64_t ws_floats, int force);
+void vaw_sm_launch(int nb, int stages, int b_kmajor, int64_t M, int64_t N, int64_t K, const bf16_t* a, int64_t lda, const bf16_t* b,
+                   int64_t ldb, const EpiDev& e, hipStream_t s);      // gemm_sm.hip
 bool vaw_p8_conv(int mode, const bf16_t* act, const bf16_t* act2, const bf16_t* w, void* out, int B, int H, int W, int Ci, int Co,
                  EpiDev e, float* workspace, int64_t workspace_floats, int force, hipStream_t s, float* bias_grad, float bias_beta,
                  int* bias_done);
@@ -790,8 +792,16 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
         e.gate_ld = ep->gate_ld; e.resid = ep->resid; e.rowadd = ep->rowadd; e.rpb = ep->rows_per_batch;
         e.alpha = ep->alpha; e.beta = ep->beta; e.out_f32 = ep->out_f32; e.resid_act = ep->resid_is_act;
     }
-    float* colsum_out = ep ? ep->colsum_out : nullptr;
+    float* const colsum_final = ep ? ep->colsum_out : nullptr;
+    float* const colsum_part = ep ? ep->colsum_partial_out : nullptr;      // deferred fold: partial rows stay with the caller
+    VAW_CHECK_ARG(!colsum_part || (!colsum_final && ep->colsum_rows_out), "gemm: colsum_partial_out excludes colsum_out and needs colsum_rows_out");
+    const bool colsum_out = colsum_final || colsum_part;                  // "this launch carries column sums"
+    float* const colsum_dst = colsum_part ? colsum_part : workspace;      // where the kernels leave their partial rows
     const float colsum_beta = ep ? ep->colsum_beta : 0.f;
+    auto fold_colsum = [&](int64_t R) -> int {
+        if (colsum_part) { *ep->colsum_rows_out = R; return VAW_OK; }
+        return vaw_reduce_rows(workspace, R, N, colsum_final, colsum_beta, stream);
+    };
     float* rowsum_out = ep ? ep->rowsum_a_out : nullptr;
     const float rowsum_beta = ep ? ep->rowsum_a_beta : 0.f;
     VAW_CHECK_ARG(!rowsum_out || (workspace && workspace_floats >= 64 * M), "gemm: rowsum_a_out needs a workspace");
@@ -818,10 +828,37 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
     const bool epi_aligned = ldc % 8 == 0 && e.gate_ld % 4 == 0 &&
                              ((((uintptr_t)C | (uintptr_t)e.bias | (uintptr_t)e.aux_in | (uintptr_t)e.aux_out |
                                 (uintptr_t)e.gate | (uintptr_t)e.resid | (uintptr_t)e.rowadd) & 15) == 0);
-    VAW_CHECK_ARG(!colsum_out || (workspace && workspace_floats >= vaw_colsum_workspace_floats(M, N) &&
-                                  workspace_floats >= ((M + 127) / 128) * N),
+    VAW_CHECK_ARG(!colsum_final || (workspace && workspace_floats >= vaw_colsum_workspace_floats(M, N) &&
+                                    workspace_floats >= ((M + 127) / 128) * N),
                   "gemm: colsum_out needs a workspace of max(ceil(M/128), ceil(M/512))*N floats");
     if (takes_fast_path(dt, M, N, K, A, lda, B, ldb) && epi_aligned && fast_layout_ok(a_kmajor, M)) {
+        // small M (strong-scaling batches: a few thousand token rows): 64-row tiles with a deep LDS-DMA ring (gemm_sm.hip)
+        // -- the launches the 128- and 256-row kernels can only give a quarter of the chip, one exposed memory latency per K step
+        {
+            static int sm_max_m = -1, sm_nb = 0, sm_st = 0;
+            if (sm_max_m < 0) {
+                const char* v = getenv("VAW_SM_MAX_M"); sm_max_m = v ? atoi(v) : 4096;
+                v = getenv("VAW_SM_NB"); sm_nb = v ? atoi(v) : 0;
+                v = getenv("VAW_SM_STAGES"); sm_st = v ? atoi(v) : 0;
+            }
+            const int64_t rows64 = (M + 63) / 64;
+            const bool cs_room = !colsum_out || colsum_part || workspace_floats >= rows64 * N;
+            const bool sm_forced = g_gemm_tile >= 5 && g_gemm_tile <= 7;     // vaw_debug_gemm_tile: 5 always, 6 / 7 always with 64 / 128-column tiles
+            if (a_kmajor && ((M <= sm_max_m && g_gemm_tile < 0) || sm_forced) && !rowsum_out && cs_room && N % 8 == 0) {
+                // 64 x 128 tiles when they still give every CU a workgroup, 64 x 64 otherwise; ring depth by the LDS it leaves:
+                // 3 stages = two (64 x 128) or three (64 x 64) workgroups per CU for multi-round launches, 4 for single rounds
+                const int64_t t2 = rows64 * ((N + 127) / 128);
+                const int nb = g_gemm_tile == 6 ? 1 : g_gemm_tile == 7 ? 2 : sm_nb ? sm_nb : (t2 >= 256 ? 2 : 1);
+                const int64_t tiles = rows64 * ((N + 64 * nb - 1) / (64 * nb));
+                const int stages = sm_st ? sm_st : (tiles > 256 ? 3 : 4);
+                EpiDev es = e;
+                if (colsum_out) es.colpart = colsum_dst;
+                vaw_sm_launch(nb, stages, b_kmajor, M, N, K, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, es, s);
+                VAW_CHECK_LAUNCH("gemm_sm");
+                if (colsum_out) return fold_colsum(rows64);
+                return VAW_OK;
+            }
+        }
         const int tiles_n = (int)((N + BN - 1) / BN);
         const int64_t n_wg = ((M + BM - 1) / BM) * tiles_n;
         VAW_CHECK_ARG(n_wg < (1LL << 31), "gemm: grid too large");
@@ -849,7 +886,7 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
             if (sp > 8) sp = 8;
             if (sp >= 2) split = (int)sp;
         }
-        if (colsum_out) e.colpart = workspace;
+        if (colsum_out) e.colpart = colsum_dst;
         if (split > 1) {   // no empty splits
             const int per = (nk_total + split - 1) / split;
             split = (nk_total + per - 1) / per;
@@ -886,7 +923,7 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
             const bool p8_epi_ok = !(e.act == 2 && e.gate) && !(e.resid && e.rowadd);     // gemm_epi.h: EpiOps has two slots
             const P8Plan pl = (bk_env == 0 && !fused_rowsum && p8_epi_ok)
                                   ? vaw_p8_plan(M, N, K, plain_f32 || (plain_bf16 && !rowsum_out && K >= 2048 && workspace != nullptr),
-                                                colsum_out != nullptr, workspace_floats, force)
+                                                colsum_out, workspace_floats, force)
                                   : P8Plan{false, 4, 1, 0};
             if (pl.use) {
                 EpiDev ep8 = e;
@@ -896,7 +933,7 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
                 // output from L2 / MALL anyway); VAW_P8_NT=1 switches the non-temporal hint on
                 if (nt_off < 0) { const char* v = getenv("VAW_P8_NT"); nt_off = (v && atoi(v) == 1) ? 0 : 1; }
                 ep8.nt_off = nt_off;
-                ep8.colpart = colsum_out ? workspace : nullptr;
+                ep8.colpart = colsum_out ? colsum_dst : nullptr;
                 ep8.rowpart = nullptr;
                 vaw_p8_launch(pl, a_kmajor, b_kmajor, M, N, K, a, lda, b, ldb, ep8, s);
                 if (pl.split > 1 && !e.out_f32)      // plain bf16 result (input gradients of half-full launches): slabs -> bf16
@@ -910,7 +947,7 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
                     const int rc = rowsum_a_separate(dt, a_kmajor, M, K, A, lda, rowsum_out, rowsum_beta, workspace, workspace_floats, stream);
                     if (rc != VAW_OK) return rc;
                 }
-                if (colsum_out) return vaw_reduce_rows(workspace, (M + 127) / 128, N, colsum_out, colsum_beta, stream);
+                if (colsum_out) return fold_colsum((M + 127) / 128);
                 return VAW_OK;
             }
         }
@@ -946,7 +983,7 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
                 const int rc = rowsum_a_separate(dt, a_kmajor, M, K, A, lda, rowsum_out, rowsum_beta, workspace, workspace_floats, stream);
                 if (rc != VAW_OK) return rc;
             }
-            if (colsum_out) return vaw_reduce_rows(workspace, (M + BIG_BM - 1) / BIG_BM, N, colsum_out, colsum_beta, stream);
+            if (colsum_out) return fold_colsum((M + BIG_BM - 1) / BIG_BM);
             return VAW_OK;
         }
         if (bkt == 32) LAUNCH_FAST_BK(32);
@@ -965,7 +1002,7 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
             const int rc = rowsum_a_separate(dt, a_kmajor, M, K, A, lda, rowsum_out, rowsum_beta, workspace, workspace_floats, stream);
             if (rc != VAW_OK) return rc;
         }
-        if (colsum_out) return vaw_reduce_rows(workspace, (M + BM - 1) / BM, N, colsum_out, colsum_beta, stream);
+        if (colsum_out) return fold_colsum((M + BM - 1) / BM);
         return VAW_OK;
     }
     const int64_t tiles = (int64_t)ceil_div(N, GBN) * ceil_div(M, GBM);
@@ -995,8 +1032,13 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
         const int rc = rowsum_a_separate(dt, a_kmajor, M, K, A, lda, rowsum_out, rowsum_beta, workspace, workspace_floats, stream);
         if (rc != VAW_OK) return rc;
     }
+    if (colsum_part) {   // generic path, deferred fold: one complete row of column sums as the only "partial" row
+        VAW_CHECK_ARG(workspace && workspace_floats >= vaw_colsum_workspace_floats(M, N), "gemm: colsum_partial_out on the generic path needs the workspace");
+        *ep->colsum_rows_out = 1;
+        return vaw_colsum(e.out_f32 ? VAW_F32 : dt, C, M, N, ldc, colsum_part, 0.f, workspace, workspace_floats, stream);
+    }
     if (colsum_out)   // generic path: a separate pass over the output just written
-        return vaw_colsum(e.out_f32 ? VAW_F32 : dt, C, M, N, ldc, colsum_out, colsum_beta, workspace, workspace_floats, stream);
+        return vaw_colsum(e.out_f32 ? VAW_F32 : dt, C, M, N, ldc, colsum_final, colsum_beta, workspace, workspace_floats, stream);
     return VAW_OK;
 }
 

@@ -128,7 +128,8 @@ __device__ __forceinline__ void epi_row8(const EpiDev& e, unsigned m, int64_t n,
 
 // Four consecutive columns n..n+3 of row m straight from a TRANSPOSED accumulator tile (the MFMA is issued with its
 // operands swapped, so a lane holds 4 consecutive columns of one row): the direct epilogue, no LDS round trip.
-__device__ __forceinline__ void epi_row4(const EpiDev& e, unsigned m, int64_t n, f32x4 v, f32x4 b) {
+// (v comes back as the value a later reader of C sees: callers that also carry column sums add it up)
+__device__ __forceinline__ void epi_row4(const EpiDev& e, unsigned m, int64_t n, f32x4& v, f32x4 b) {
     const int64_t off = (int64_t)m * e.ldc + n;
     v = v * e.alpha + b;
     if (e.aux_out) {
@@ -155,6 +156,7 @@ __device__ __forceinline__ void epi_row4(const EpiDev& e, unsigned m, int64_t n,
     } else {
         const bf16x4 r = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
         __builtin_nontemporal_store(r, reinterpret_cast<bf16x4*>((bf16_t*)e.C + off));
+        v = f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
     }
 }
 

@@ -336,8 +336,11 @@ extern "C" int vaw_gemm_fp8(vaw_dtype a_format, int64_t M, int64_t N, int64_t K,
     VAW_CHECK_ARG(!(e.gate || e.rowadd) || e.rpb > 0, "gemm_fp8: gate/rowadd need rows_per_batch");
     VAW_CHECK_ARG(!(e.act == 2 && e.gate) && !(e.resid && e.rowadd), "gemm_fp8: epilogue combination not offered");
     if (e.rpb <= 0) e.rpb = 1;
-    float* colsum_out = ep ? ep->colsum_out : nullptr;
-    VAW_CHECK_ARG(!colsum_out || (workspace && workspace_floats >= ((M + 127) / 128) * N), "gemm_fp8: colsum_out needs a workspace");
+    float* const colsum_final = ep ? ep->colsum_out : nullptr;
+    float* const colsum_part = ep ? ep->colsum_partial_out : nullptr;       // deferred fold (vaw_reduce_rows_batched): see vaw_epilogue
+    VAW_CHECK_ARG(!colsum_part || (!colsum_final && ep->colsum_rows_out), "gemm_fp8: colsum_partial_out excludes colsum_out and needs colsum_rows_out");
+    const bool colsum_out = colsum_final || colsum_part;
+    VAW_CHECK_ARG(!colsum_final || (workspace && workspace_floats >= ((M + 127) / 128) * N), "gemm_fp8: colsum_out needs a workspace");
     e.M = M; e.N = N; e.ldc = ldc; e.C = C; e.slab = workspace; e.nt_off = 1;
     e.scale_a = scale_a; e.scale_b = scale_b;
     {
@@ -345,10 +348,10 @@ extern "C" int vaw_gemm_fp8(vaw_dtype a_format, int64_t M, int64_t N, int64_t K,
         if (dbg < 0) { const char* v = getenv("VAW_GEMM_DEBUG"); dbg = v ? atoi(v) : 0; }
         e.debug = dbg;
     }
-    e.colpart = colsum_out ? workspace : nullptr;
+    e.colpart = colsum_part ? colsum_part : colsum_final ? workspace : nullptr;
     // plan in units of the kernel's K tiles: 128 fp8 elements = one K tile = what 64 bf16 elements are to vaw_p8_plan
     // (plain_f32 = false: no K split -- the long-K launches of the step are the weight gradients, served by vaw_wgrad_grouped)
-    const P8Plan pl = vaw_p8_plan(M, N, K / 2, false, colsum_out != nullptr, workspace_floats, 1);
+    const P8Plan pl = vaw_p8_plan(M, N, K / 2, false, colsum_out, workspace_floats, 1);
     hipStream_t s = (hipStream_t)stream;
     const int bn = 64 * pl.ntw, tiles_m = (int)((M + 255) / 256), tiles_n = (int)((N + bn - 1) / bn), nk = (int)(K / 128);
     int epi;
@@ -383,6 +386,7 @@ extern "C" int vaw_gemm_fp8(vaw_dtype a_format, int64_t M, int64_t N, int64_t K,
     else if (epi == P8_GELU_Q) F8_GO(P8_GELU_Q, 1);
     else F8_GO(P8_GATE, 1);
     VAW_CHECK_LAUNCH("gemm_fp8");
-    if (colsum_out) return vaw_reduce_rows(workspace, (M + 127) / 128, N, colsum_out, ep->colsum_beta, stream);
+    if (colsum_part) *ep->colsum_rows_out = (M + 127) / 128;
+    else if (colsum_final) return vaw_reduce_rows(workspace, (M + 127) / 128, N, colsum_final, ep->colsum_beta, stream);
     return VAW_OK;
 }

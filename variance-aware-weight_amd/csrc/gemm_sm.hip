@@ -1,0 +1,169 @@
+// Small-M bf16 MFMA GEMM: the Linear launches of a DiT step when the per-GPU batch is small (strong scaling of a global batch over
+// 8 GPUs, reference main.py:166-180: per-GPU batch = batch_size // world_size; DiT-B/4 at 32-64 images = 2048-4096 token rows).
+//
+// Why a third kernel.  At M = 2048 a 768-wide layer has 8 x 4 tiles of the persistent kernel (gemm_p8_kernel.h) and 16 x 6 of
+// the 128 x 128 one (gemm.hip): a quarter of the chip at best, each workgroup walking its K loop alone on its CU with ONE K tile
+// of LDS-DMA in flight -- every K step costs a whole memory latency (measured: 28 us for 2048 x 768 x 768, 2.4 GFLOP).  Here:
+//   * 64-row tiles, 64 or 128 columns wide: 384 / 192 workgroups for that launch, 256 threads = 4 waves as 2 (M) x 2 (N);
+//   * a ring of STAGES (3 or 4) LDS stages of one 64-deep K tile each, filled by `buffer_load_dwordx4 ... lds`, with a COUNTED
+//     s_waitcnt vmcnt(N) and a raw s_barrier per K tile: STAGES - 1 K tiles stay in flight, so the loop streams at the DMA
+//     rate of the CU instead of paying a latency per step (cdna_hip_programming.md "Pipelining across barriers");
+//   * LDS images, swizzles and fragment reads are those of the persistent kernel (8 KiB parts of 64 rows x 128 B, p8_frag);
+//   * register-direct epilogue (the accumulators are held transposed: a lane owns 4 consecutive columns of a row) with the row
+//     epilogue of gemm_epi.h, column sums of the output (the next bias gradient) folded per 64-row tile in a fixed order.
+// Layouts: A k-major ([M][K]); B k-major ([N][K], forward) or mn-major ([K][N], input gradients).  Weight gradients keep the
+// grouped persistent launch (K = tokens is long there and all layers together fill the chip).
+#include "gemm_p8_kernel.h"
+
+template <int NB> struct SmCfg {
+    static constexpr int BN = 64 * NB;
+    static constexpr int stage_bytes = (1 + NB) * P8_PART;     // A part (64 rows) + NB B parts
+    static constexpr int pieces = 2 * (1 + NB);                // DMA instructions per wave and K tile
+};
+
+template <bool BKM, int NB, int STAGES>
+__global__ void __launch_bounds__(256)
+gemm_sm_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb, int nk, int tiles_m, int tiles_n,
+               EpiDev e) {
+    using Cfg = SmCfg<NB>;
+    constexpr int NT = 2 * NB;                                  // 16-column MFMA tiles per wave (wave tile 32 x 32 NB)
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [STAGES][A part | B parts]
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wid >> 1, wc = wid & 1;
+    // XCD x (workgroups b = x mod 8) takes a contiguous run of tiles, column tile fastest: its workgroups share A row panels
+    // (and the small weight operand) in that XCD's L2
+    int tile;
+    {
+        const int n = tiles_m * tiles_n, b = blockIdx.x, x = b & 7, q = n >> 3, r = n & 7;
+        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+    }
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int64_t m0 = (int64_t)tm * 64, n0 = (int64_t)tn * Cfg::BN;
+    const int mvalid = e.M - m0 < 64 ? (int)(e.M - m0) : 64;
+    const int nvalid = e.N - n0 < Cfg::BN ? (int)(e.N - n0) : Cfg::BN;
+
+    // ---- DMA stream: per-lane byte offsets fixed for the tile, a scalar offset walks K ----
+    const __amdgpu_buffer_rsrc_t rs_a = epi_rsrc(A + m0 * lda);
+    const __amdgpu_buffer_rsrc_t rs_b = epi_rsrc(BKM ? B + n0 * ldb : B + n0);
+    unsigned off_a[2], off_b[NB][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        off_a[h] = p8_src_off<true>(false, 0, wid + 4 * h, lane, lda, mvalid);
+#pragma unroll
+        for (int p = 0; p < NB; ++p) off_b[p][h] = p8_src_off<BKM>(false, p, wid + 4 * h, lane, ldb, nvalid);
+    }
+    const unsigned step_a = 128u, step_b = BKM ? 128u : (unsigned)(64 * ldb * 2);
+    unsigned so_a = 0, so_b = 0;
+    int iss = 0;                                                // next K tile to issue
+    auto issue = [&]() {
+        char* dst = smem + (iss % STAGES) * Cfg::stage_bytes;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            p8_dma16(rs_a, dst + (wid + 4 * h) * 1024, off_a[h], so_a);
+#pragma unroll
+            for (int p = 0; p < NB; ++p) p8_dma16(rs_b, dst + (1 + p) * P8_PART + (wid + 4 * h) * 1024, off_b[p][h], so_b);
+        }
+        so_a += step_a;
+        so_b += step_b;
+        ++iss;
+    };
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (iss < nk) issue();
+
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+
+    for (int kt = 0; kt < nk; ++kt) {
+        // K tile kt has landed once at most the tiles issued after it are outstanding: (STAGES - 2) of them in steady state
+        if (kt + STAGES - 1 <= nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * Cfg::pieces) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // tail: fewer tiles behind it
+        __builtin_amdgcn_s_barrier();          // every wave's pieces of tile kt are in; everyone has finished reading tile kt - 1
+        if (iss < nk) issue();                 // ... so its stage takes tile kt + STAGES - 1
+        const char* st = smem + (kt % STAGES) * Cfg::stage_bytes;
+        bf16x8 af[2][2], bfr[2][NT];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int n = wc * (16 * NT) + 16 * j;
+                bfr[s][j] = p8_frag<BKM>(st + (1 + (n >> 6)) * P8_PART, n & 63, s, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[s][i] = p8_frag<true>(st, 32 * wr + 16 * i, s, lane);
+        }
+        if (!BKM) {        // transposing reads are inline asm: wait for them by hand (rule 18)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[s][j], af[s][i], acc[i][j], 0, 0, 0);
+    }
+
+    // ---- epilogue: lane (lr = lane & 15, g = lane >> 4) owns row lr of each 16-row tile and columns 4 g .. 4 g + 3 of each 16-column tile
+    const int lr = lane & 15, g4 = 4 * (lane >> 4);
+    f32x4 cs[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) cs[j] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int col = wc * (16 * NT) + 16 * j + g4;
+        if (col >= nvalid) continue;                                    // N % 8 == 0: four columns are in or out together
+        const f32x4 bj = e.bias ? load4(e.bias + n0 + col) : f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = 32 * wr + 16 * i + lr;
+            if (row >= mvalid) continue;
+            f32x4 v = acc[i][j];
+            epi_row4(e, (unsigned)(m0 + row), n0 + col, v, bj);          // v comes back as stored
+            cs[j] += v;
+        }
+    }
+    if (e.colpart) {       // column sums of this 64-row tile: 16 rows by shuffles, then the two wave rows through LDS, fixed order
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();                                                 // the ring is dead: reuse it
+        float* sc = reinterpret_cast<float*>(smem);                      // [2 wave rows][BN]
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float t = cs[j][c];
+                t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
+                cs[j][c] = t;
+            }
+            if (lr == 0) store4(sc + wr * Cfg::BN + wc * (16 * NT) + 16 * j + g4, cs[j]);
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < nvalid; c += 256) e.colpart[(int64_t)tm * e.N + n0 + c] = sc[c] + sc[Cfg::BN + c];
+    }
+}
+
+template <bool BKM, int NB, int STAGES>
+static void sm_launch_one(const bf16_t* a, int64_t lda, const bf16_t* b, int64_t ldb, int nk, int tiles_m, int tiles_n, const EpiDev& e,
+                          hipStream_t s) {
+    static bool attr_done = false;
+    const int lds = STAGES * SmCfg<NB>::stage_bytes;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)gemm_sm_kernel<BKM, NB, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_done = true;
+    }
+    gemm_sm_kernel<BKM, NB, STAGES><<<tiles_m * tiles_n, 256, lds, s>>>(a, lda, b, ldb, nk, tiles_m, tiles_n, e);
+}
+
+// nb = 1 | 2 (tile 64 x 64 | 64 x 128), stages = 3 | 4.  A k-major; b_kmajor selects the B layout.
+void vaw_sm_launch(int nb, int stages, int b_kmajor, int64_t M, int64_t N, int64_t K, const bf16_t* a, int64_t lda, const bf16_t* b,
+                   int64_t ldb, const EpiDev& e, hipStream_t s) {
+    const int tiles_m = (int)((M + 63) / 64), tiles_n = (int)((N + 64 * nb - 1) / (64 * nb)), nk = (int)(K / 64);
+#define SM_GO(BKv, NBv, STv) sm_launch_one<BKv, NBv, STv>(a, lda, b, ldb, nk, tiles_m, tiles_n, e, s)
+#define SM_GO_B(NBv, STv) do { if (b_kmajor) SM_GO(true, NBv, STv); else SM_GO(false, NBv, STv); } while (0)
+    if (nb == 1) { if (stages == 3) SM_GO_B(1, 3); else SM_GO_B(1, 4); }
+    else { if (stages == 3) SM_GO_B(2, 3); else SM_GO_B(2, 4); }
+}

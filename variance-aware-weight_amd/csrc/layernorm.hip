@@ -68,8 +68,11 @@ ln_modulate_fwd_kernel(const float* __restrict__ x, const float* __restrict__ sh
 }
 
 // One block per sample; NW waves stride over that sample's T rows.
-template <typename T, int NV, bool GATE_ONLY, bool QOUT = false>
-__global__ void __launch_bounds__(1024)
+// FUSE (LayerNorm mode only): the gate backward of the branch that PRECEDES this LayerNorm in the forward pass (its gradient is
+// the dres row this kernel has just produced) runs on the row while it is still in registers -- dy = dres * gate, dgate += dres * y,
+// column sums of dy -- instead of re-reading dres in a launch of its own (bitwise the same results: same values, same order).
+template <typename T, int NV, bool GATE_ONLY, bool QOUT = false, bool FUSE = false>
+__global__ void __launch_bounds__((FUSE && NV > 3) ? 512 : 1024)
 row_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ x, const float* __restrict__ mean,
                const float* __restrict__ rstd, const float* __restrict__ scale, int64_t mod_ld,
                const float* __restrict__ dres_in, float* __restrict__ dx, float* __restrict__ dshift,
@@ -82,14 +85,21 @@ row_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ x, const fl
                int rows_per_chunk, float* __restrict__ part,
                // GATE_ONLY, fp8 mode: dy goes out as fp8 bytes of its bf16 rounding instead (q_state: its delayed-scaling state)
                unsigned char* __restrict__ q_out = nullptr, float* __restrict__ q_state = nullptr, int q_e5m2 = 0) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][D]
-    const float q_inv = (GATE_ONLY && QOUT) ? 1.f / q_state[0] : 1.f;
+    static_assert(!(FUSE && GATE_ONLY), "FUSE extends the LayerNorm mode");
+    constexpr int NQ = FUSE ? 4 : 2;                               // per-sample column sums carried
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [NQ][D]
+    const float q_inv = ((GATE_ONLY || FUSE) && QOUT) ? 1.f / q_state[0] : 1.f;
     float q_am = 0.f;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int b = blockIdx.x;
     const int t_begin = blockIdx.y * rows_per_chunk;
     const int t_end = t_begin + rows_per_chunk < Tt ? t_begin + rows_per_chunk : Tt;
     f32x4 acc0[NV], acc1[NV], sc[NV];
+    f32x4 acc2[FUSE ? NV : 1], acc3[FUSE ? NV : 1];
+    // FUSE: four accumulator sets fill the 128 registers a 1024-thread workgroup may use; the sample's (1 + scale) and gate rows
+    // then stay in LDS ([NQ][D] sums first, then these two rows) and are re-read per token row
+    float* const sc_lds = lds + NQ * D;
+    float* const gsc_lds = sc_lds + D;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         acc0[i] = f32x4{0, 0, 0, 0};
@@ -97,7 +107,15 @@ row_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ x, const fl
         const int c = (i * 64 + lane) * 4;
         const float* src = GATE_ONLY ? gate : scale;
         sc[i] = c < D ? load4(src + (int64_t)b * mod_ld + c) : f32x4{0, 0, 0, 0};
+        if (FUSE) {
+            acc2[i] = acc3[i] = f32x4{0, 0, 0, 0};
+            if (wid == 0 && c < D) {
+                store4(sc_lds + c, 1.f + sc[i]);
+                store4(gsc_lds + c, load4(gate + (int64_t)b * mod_ld + c));
+            }
+        }
     }
+    if (FUSE) __syncthreads();
     for (int t = t_begin + wid; t < t_end; t += nw) {
         const int64_t row = (int64_t)b * Tt + t;
         if (GATE_ONLY) {
@@ -127,7 +145,7 @@ row_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ x, const fl
                     xh[i] = (load4(x + row * D + c) - mu) * rs;
                     acc0[i] += d;            // dshift
                     acc1[i] += d * xh[i];    // dscale
-                    g[i] = d * (1.f + sc[i]);
+                    g[i] = d * (FUSE ? load4(sc_lds + c) : 1.f + sc[i]);
                     s1 += g[i][0] + g[i][1] + g[i][2] + g[i][3];
                     f32x4 gx = g[i] * xh[i];
                     s2 += gx[0] + gx[1] + gx[2] + gx[3];
@@ -143,15 +161,24 @@ row_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ x, const fl
                     f32x4 r = (g[i] - c1 - xh[i] * c2) * rs;
                     if (dres_in) r += load4(dres_in + row * D + c);
                     store4(dx + row * D + c, r);
+                    if (FUSE) {      // the gate backward of vaw_gate_bwd, on the row just produced
+                        const f32x4 yv = load4(y + row * D + c);
+                        const f32x4 d = r * load4(gsc_lds + c);
+                        if (QOUT) *reinterpret_cast<unsigned*>(q_out + row * D + c) = fp8_word_of_bf16(d, q_inv, q_e5m2, q_am);
+                        else store4(dy + row * D + c, d);
+                        acc2[i] += r * yv;
+                        f32x4 dr = {to_f32(from_f32<T>(d[0])), to_f32(from_f32<T>(d[1])), to_f32(from_f32<T>(d[2])), to_f32(from_f32<T>(d[3]))};
+                        acc3[i] += dr;
+                    }
                 }
             }
         }
     }
-    if (GATE_ONLY && QOUT) fp8_amax_commit(q_am, q_state + 1, lane);
+    if ((GATE_ONLY || FUSE) && QOUT) fp8_amax_commit(q_am, q_state + 1, lane);
     // fixed-order combine of the per-wave column sums
     float* s0 = lds;
     float* s1p = lds + D;
-    for (int i = threadIdx.x; i < 2 * D; i += blockDim.x) lds[i] = 0.f;
+    for (int i = threadIdx.x; i < NQ * D; i += blockDim.x) lds[i] = 0.f;
     __syncthreads();
     for (int w = 0; w < nw; ++w) {
         if (wid == w) {
@@ -161,14 +188,18 @@ row_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ x, const fl
                 if (c < D) {
                     store4(s0 + c, load4(s0 + c) + acc0[i]);
                     store4(s1p + c, load4(s1p + c) + acc1[i]);
+                    if (FUSE) {
+                        store4(lds + 2 * D + c, load4(lds + 2 * D + c) + acc2[i]);
+                        store4(lds + 3 * D + c, load4(lds + 3 * D + c) + acc3[i]);
+                    }
                 }
             }
         }
         __syncthreads();
     }
     if (part) {
-        float* dst = part + ((int64_t)blockIdx.y * gridDim.x + b) * 2 * D;
-        for (int c = threadIdx.x; c < 2 * D; c += blockDim.x) dst[c] = lds[c];
+        float* dst = part + ((int64_t)blockIdx.y * gridDim.x + b) * NQ * D;
+        for (int c = threadIdx.x; c < NQ * D; c += blockDim.x) dst[c] = lds[c];
         return;
     }
     for (int c = threadIdx.x; c < D; c += blockDim.x) {
@@ -178,24 +209,36 @@ row_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ x, const fl
         } else {
             dshift[(int64_t)b * dmod_ld + c] = s0[c];
             dscale[(int64_t)b * dmod_ld + c] = s1p[c];
+            if (FUSE) {
+                dgate[(int64_t)b * dmod_ld + c] = lds[2 * D + c];
+                if (dy_colpart) dy_colpart[(int64_t)b * D + c] = lds[3 * D + c];
+            }
         }
     }
 }
 
-// out0[b][c] (row stride ld0) = sum_chunk part[chunk][b][0][c], out1 likewise from [1] (row stride ld1; may be NULL)
+// out0[b][c] (row stride ld0) = sum_chunk part[chunk][b][0][c], out1 likewise from [1] (row stride ld1; may be NULL); the fused
+// kernel's part rows carry four quantities: out2 / out3 from [2] / [3]
 __global__ void row_bwd_finish_kernel(const float* __restrict__ part, int NC, int B, int D, float* __restrict__ out0, int64_t ld0,
-                                      float* __restrict__ out1, int64_t ld1) {
+                                      float* __restrict__ out1, int64_t ld1, int NQ = 2, float* __restrict__ out2 = nullptr,
+                                      int64_t ld2 = 0, float* __restrict__ out3 = nullptr, int64_t ld3 = 0) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= (int64_t)B * D) return;
     const int b = (int)(i / D), c = (int)(i % D);
-    float a0 = 0.f, a1 = 0.f;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     for (int ch = 0; ch < NC; ++ch) {
-        const float* src = part + ((int64_t)ch * B + b) * 2 * D;
+        const float* src = part + ((int64_t)ch * B + b) * NQ * D;
         a0 += src[c];
         a1 += src[D + c];
+        if (NQ == 4) {
+            a2 += src[2 * D + c];
+            a3 += src[3 * D + c];
+        }
     }
     out0[(int64_t)b * ld0 + c] = a0;
     if (out1) out1[(int64_t)b * ld1 + c] = a1;
+    if (out2) out2[(int64_t)b * ld2 + c] = a2;
+    if (out3) out3[(int64_t)b * ld3 + c] = a3;
 }
 
 static int pick_nv(int D) { return (D + 255) / 256; }
@@ -208,10 +251,10 @@ static int pick_chunks(int B, int Tt, bool have_ws) {
     if (nc > max_nc) nc = max_nc;
     return nc < 1 ? 1 : nc;
 }
-extern "C" int64_t vaw_row_bwd_workspace_floats(int B, int T, int D) { return (int64_t)pick_chunks(B, T, true) * B * 2 * D; }
+extern "C" int64_t vaw_row_bwd_workspace_floats(int B, int T, int D) { return (int64_t)pick_chunks(B, T, true) * B * 4 * D; }
 
-static int pick_block(int Tt) {
-    int nw = Tt < 16 ? Tt : 16;
+static int pick_block(int Tt, int max_waves = 16) {
+    int nw = Tt < max_waves ? Tt : max_waves;
     if (nw < 1) nw = 1;
     return nw * 64;
 }
@@ -282,6 +325,65 @@ extern "C" int vaw_ln_modulate_bwd(vaw_dtype dt, const void* dout, const float* 
     }
     if (nc > 1) row_bwd_finish_kernel<<<ceil_div((int64_t)B * D, 256), 256, 0, s>>>(part, nc, B, D, dshift, dmod_ld, dscale, dmod_ld);
     VAW_CHECK_LAUNCH("ln_modulate_bwd");
+    return VAW_OK;
+}
+
+// vaw_ln_modulate_bwd followed by vaw_gate_bwd of the branch in front of this LayerNorm, as ONE pass (row_bwd_kernel<FUSE>):
+// dx = the residual-stream gradient as before; dy_next = dx * gate_next (act dtype), dgate_next[b] = sum_t dx * y_next,
+// dy_colsum_partial [B][D] = per-sample sum_t dy_next (as stored).  Bitwise equal to the two separate launches.
+extern "C" int vaw_ln_modulate_bwd_gate(vaw_dtype dt, const void* dout, const float* x, const float* mean, const float* rstd,
+                                        const float* scale, int64_t mod_ld, const float* dres_in, float* dx, float* dshift,
+                                        float* dscale, int64_t dmod_ld, const void* y_next, const float* gate_next, void* dy_next,
+                                        float* dgate_next, float* dy_colsum_partial, int B, int T, int D, float* workspace,
+                                        int64_t workspace_floats, vaw_stream stream) {
+    VAW_CHECK_ARG(B > 0 && T > 0 && D > 0 && D % 4 == 0 && D <= 2048 && mod_ld % 4 == 0,
+                  "ln_modulate_bwd_gate: need D%%4==0, D<=2048, mod_ld%%4==0 (D=%d)", D);
+    VAW_CHECK_ARG(y_next && gate_next && dy_next && dgate_next, "ln_modulate_bwd_gate: the gate operands are required");
+    hipStream_t s = (hipStream_t)stream;
+    int nc = pick_chunks(B, T, workspace != nullptr);
+    if (nc > 1 && workspace_floats < (int64_t)nc * B * 4 * D) nc = 1;
+    const int rpc = (T + nc - 1) / nc;
+    float* part = nc > 1 ? workspace : nullptr;
+    const int nv = pick_nv(D);
+    const int block = pick_block(rpc, nv > 3 ? 8 : 16);
+    const size_t lds = 6 * (size_t)D * sizeof(float);
+    dim3 grid(B, nc);
+    if (dt == VAW_F32) {
+        DISPATCH_NV(nv, (row_bwd_kernel<float, NV, false, false, true><<<grid, block, lds, s>>>((const float*)dout, x, mean, rstd, scale, mod_ld, dres_in, dx, dshift, dscale, dmod_ld, T, D, nullptr, (const float*)y_next, gate_next, (float*)dy_next, dgate_next, dy_colsum_partial, rpc, part)));
+    } else {
+        DISPATCH_NV(nv, (row_bwd_kernel<bf16_t, NV, false, false, true><<<grid, block, lds, s>>>((const bf16_t*)dout, x, mean, rstd, scale, mod_ld, dres_in, dx, dshift, dscale, dmod_ld, T, D, nullptr, (const bf16_t*)y_next, gate_next, (bf16_t*)dy_next, dgate_next, dy_colsum_partial, rpc, part)));
+    }
+    if (nc > 1)
+        row_bwd_finish_kernel<<<ceil_div((int64_t)B * D, 256), 256, 0, s>>>(part, nc, B, D, dshift, dmod_ld, dscale, dmod_ld, 4, dgate_next, dmod_ld,
+                                                                             dy_colsum_partial, D);
+    VAW_CHECK_LAUNCH("ln_modulate_bwd_gate");
+    return VAW_OK;
+}
+
+// fp8 mode: the same fused pass with dy_next as fp8 bytes [B*T][D] of its bf16 roundings (as vaw_gate_bwd_fp8); bf16 arithmetic path.
+extern "C" int vaw_ln_modulate_bwd_gate_fp8(const void* dout, const float* x, const float* mean, const float* rstd, const float* scale,
+                                            int64_t mod_ld, const float* dres_in, float* dx, float* dshift, float* dscale, int64_t dmod_ld,
+                                            const void* y_next, const float* gate_next, void* dy_q, float* q_state, vaw_dtype q_format,
+                                            float* dgate_next, float* dy_colsum_partial, int B, int T, int D, float* workspace,
+                                            int64_t workspace_floats, vaw_stream stream) {
+    VAW_CHECK_ARG(B > 0 && T > 0 && D > 0 && D % 4 == 0 && D <= 2048 && mod_ld % 4 == 0,
+                  "ln_modulate_bwd_gate_fp8: need D%%4==0, D<=2048, mod_ld%%4==0 (D=%d)", D);
+    VAW_CHECK_ARG(y_next && gate_next && dy_q && q_state && dgate_next, "ln_modulate_bwd_gate_fp8: the gate operands are required");
+    VAW_CHECK_ARG(q_format == VAW_FP8 || q_format == VAW_BF8, "ln_modulate_bwd_gate_fp8: q_format");
+    hipStream_t s = (hipStream_t)stream;
+    int nc = pick_chunks(B, T, workspace != nullptr);
+    if (nc > 1 && workspace_floats < (int64_t)nc * B * 4 * D) nc = 1;
+    const int rpc = (T + nc - 1) / nc;
+    float* part = nc > 1 ? workspace : nullptr;
+    const int nv = pick_nv(D);
+    const int block = pick_block(rpc, nv > 3 ? 8 : 16);
+    const size_t lds = 6 * (size_t)D * sizeof(float);
+    dim3 grid(B, nc);
+    DISPATCH_NV(nv, (row_bwd_kernel<bf16_t, NV, false, true, true><<<grid, block, lds, s>>>((const bf16_t*)dout, x, mean, rstd, scale, mod_ld, dres_in, dx, dshift, dscale, dmod_ld, T, D, nullptr, (const bf16_t*)y_next, gate_next, nullptr, dgate_next, dy_colsum_partial, rpc, part, (unsigned char*)dy_q, q_state, q_format == VAW_BF8)));
+    if (nc > 1)
+        row_bwd_finish_kernel<<<ceil_div((int64_t)B * D, 256), 256, 0, s>>>(part, nc, B, D, dshift, dmod_ld, dscale, dmod_ld, 4, dgate_next, dmod_ld,
+                                                                             dy_colsum_partial, D);
+    VAW_CHECK_LAUNCH("ln_modulate_bwd_gate_fp8");
     return VAW_OK;
 }
 
@@ -421,6 +523,62 @@ __global__ void colsum_partial_scalar_kernel(const T* __restrict__ X, int64_t M,
     float acc = 0.f;
     for (int64_t r = r0; r < r1; ++r) acc += to_f32(X[r * ldx + c]);
     part_out[(int64_t)blockIdx.y * N + c] = acc;
+}
+
+// Many column-sum folds in ONE launch: job j folds R_j partial rows of N_j columns into out_j exactly as colsum_final_kernel
+// would (same summation tree: bitwise the same result).  The bias gradients of all Linear layers of a group of DiT blocks are
+// produced as partial rows by the kernels that make dy (gate backward, GELU' epilogue, attention backward) and folded here
+// once per group instead of by one 5-microsecond launch each.
+struct ReduceJobDev {
+    const float* part;
+    float* out;
+    int64_t R, N;
+    int block0, pad_;
+};
+__global__ void __launch_bounds__(1024)
+colsum_final_batched_kernel(const ReduceJobDev* __restrict__ jobs, int n_jobs, float beta) {
+    __shared__ float fold[32][33];
+    int lo = 0, hi = n_jobs - 1;                      // last job with block0 <= blockIdx.x (uniform: scalar loads)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const ReduceJobDev jb = jobs[lo];
+    const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int64_t c = (int64_t)(blockIdx.x - jb.block0) * 32 + cl;
+    float acc = 0.f;
+    if (c < jb.N)
+        for (int64_t r = grp; r < jb.R; r += 32) acc += jb.part[r * jb.N + c];
+    fold[grp][cl] = acc;
+    __syncthreads();
+    if (grp == 0 && c < jb.N) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 32; ++g) t += fold[g][cl];
+        jb.out[c] = (beta != 0.f ? beta * jb.out[c] : 0.f) + t;
+    }
+}
+
+extern "C" int64_t vaw_reduce_rows_batched_desc_bytes(int n_jobs) { return (int64_t)n_jobs * (int64_t)sizeof(ReduceJobDev); }
+
+extern "C" int vaw_reduce_rows_batched(int n_jobs, const vaw_reduce_job* jobs, float beta, void* desc_dev, int upload, vaw_stream stream) {
+    VAW_CHECK_ARG(n_jobs > 0 && n_jobs <= 4096 && jobs && desc_dev, "reduce_rows_batched: bad arguments");
+    static thread_local ReduceJobDev host[4096];
+    int64_t blocks = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        VAW_CHECK_ARG(jobs[j].partial && jobs[j].out && jobs[j].R > 0 && jobs[j].N > 0, "reduce_rows_batched: job %d", j);
+        host[j] = ReduceJobDev{jobs[j].partial, jobs[j].out, jobs[j].R, jobs[j].N, (int)blocks, 0};
+        blocks += (jobs[j].N + 31) / 32;
+        VAW_CHECK_ARG(blocks < (1 << 30), "reduce_rows_batched: too many columns");
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (upload) {
+        const hipError_t rc = hipMemcpyAsync(desc_dev, host, sizeof(ReduceJobDev) * n_jobs, hipMemcpyHostToDevice, s);
+        VAW_CHECK_ARG(rc == hipSuccess, "reduce_rows_batched: descriptor upload failed: %s", hipGetErrorString(rc));
+    }
+    colsum_final_batched_kernel<<<(unsigned)blocks, 1024, 0, s>>>((const ReduceJobDev*)desc_dev, n_jobs, beta);
+    VAW_CHECK_LAUNCH("reduce_rows_batched");
+    return VAW_OK;
 }
 
 extern "C" int64_t vaw_colsum_workspace_floats(int64_t M, int64_t N) { return ((M + 127) / 128) * N; }

@@ -150,12 +150,20 @@ class _Workspace:
             for b in self.blk:
                 b.update(dy2=e(M, D), dDm=e(M, m.Dm), dy1=e(M, D), dqkv=e(M, 3 * D))
         self.wgrad_groups = {}
+        # bias gradients: the kernels that produce dy leave partial column sums per block (gate backward: one row per sample;
+        # fc2's GELU' epilogue: one per 128 token rows; attention backward: one per sample and 64-token block); ONE batched fold
+        # per group of blocks turns them into the four bias gradients of every block (ops.ReduceGroup)
+        self.bias_groups = {}
+        for b in self.blk:
+            b.update(cp_fc2=ops.ColsumPartial(B, D, dev), cp_proj=ops.ColsumPartial(B, D, dev),
+                     cp_fc1=ops.ColsumPartial((M + 127) // 128, m.Dm, dev), cp_qkv=ops.ColsumPartial(max(B, M // 64), 3 * D, dev))
+            b["cp_fc2"].rows.value = b["cp_proj"].rows.value = B
+        self.dyb = e(M, D)          # dy of a gated branch when the block keeps no buffer of its own (f32 / fp8 / per-layer wgrad modes)
         self.delta = e(B * m.num_heads * T, dtype=f32)
         self.dmod, self.dmod_a = e(B, m.mod_cols, dtype=f32), e(B, m.mod_cols)
         self.dcs, self.dc, self.dc_a = e(B, D, dtype=f32), e(B, D, dtype=f32), e(B, D)
         self.dh1s, self.dh1, self.dh1_a = e(B, D, dtype=f32), e(B, D, dtype=f32), e(B, D)
         self.dxp = e(M, m.Kp, dtype=f32)
-        self.colpart = e(B, D, dtype=f32)
 
 
 class _DiTFn(torch.autograd.Function):
@@ -502,21 +510,61 @@ class DiT(FlatModule):
         hook = self.grad_ready_hook
         ada_half = self._ada_split_block() if hook else None      # early adaLN bucket only when somebody listens (DDP)
         dres, dD, dDm, dmod = ptr(ws.dres), ptr(ws.dD), ptr(ws.dDm), ptr(ws.dmod)
-        colpart = ptr(ws.colpart)
         mod = ptr(ws.mod)
-        # head: unpatchify^T, final linear, final LN+modulate
+        es = self._wsize
+        defer = ws.defer and dt == BF16
+        fp8 = ws.fp8
+        own_dy = defer and not fp8            # every block keeps its four dy operands for the grouped weight-gradient launch
+        # fp8, delayed scaling: the row kernels write dy as fp8 themselves
+        fuse_rows = fp8 and ws.d_bwd and self.fp8_fuse_epilogue and self.fp8_fuse_rows and M % 64 == 0 and D % 128 == 0
+
+        def ln_bwd_and_gate(dout_p, x_p, mean_p, rstd_p, scale_p, dres_in, dsh, dsc, nxt):
+            """Backward of one LayerNorm+modulate (d of its output -> residual-stream gradient, dshift, dscale) and, in the same
+            pass over the rows, the gate backward of the branch in FRONT of it (nxt = (block index, "mlp" | "attn") or None):
+            dy of that branch, its dgate and the per-sample column sums of dy (the bias gradient of fc2 / proj)."""
+            if nxt is None:
+                ops.ln_modulate_bwd(dt, dout_p, x_p, mean_p, rstd_p, scale_p, ld, dres_in, dres, dsh, dsc, ld, B, T, D)
+                return
+            l2, which = nxt
+            nb = ws.blk[l2]
+            mo2, dmo2 = mod + 4 * (6 * l2 * D), dmod + 4 * (6 * l2 * D)
+            gcol = 5 if which == "mlp" else 2
+            y, cp = (nb["y2"], nb["cp_fc2"]) if which == "mlp" else (nb["y1"], nb["cp_proj"])
+            if fuse_rows:
+                ops.ln_modulate_bwd_gate_fp8(dout_p, x_p, mean_p, rstd_p, scale_p, ld, dres_in, dres, dsh, dsc, ld, ptr(y),
+                                             mo2 + 4 * gcol * D, nb["f_dy2" if which == "mlp" else "f_dy1"], dmo2 + 4 * gcol * D,
+                                             B, T, D, cp.buf.data_ptr())
+            else:
+                dy = ptr(nb["dy2" if which == "mlp" else "dy1"]) if own_dy else ptr(ws.dyb)
+                ops.ln_modulate_bwd_gate(dt, dout_p, x_p, mean_p, rstd_p, scale_p, ld, dres_in, dres, dsh, dsc, ld, ptr(y),
+                                         mo2 + 4 * gcol * D, dy, dmo2 + 4 * gcol * D, B, T, D, cp.buf.data_ptr())
+
+        # head: unpatchify^T, final linear, final LN+modulate (+ the gate backward of the last block's MLP branch)
         L.check(lib.vaw_unpatchify_bwd(dt, ptr(dout), ptr(ws.dotok), B, self.out_channels, H, W, self.patch_size, st), "unpatchify_bwd")
         self._wgrad(dt, "final_layer.linear.", ptr(ws.dotok), ptr(ws.xf), self.No, D, M, beta)
         ops.gemm(dt, 1, 0, M, D, self.No, ptr(ws.dotok), self.No, self._w("final_layer.linear.weight"), D, dD, D)
         mo, dmo = mod + 4 * (6 * Lyr * D), dmod + 4 * (6 * Lyr * D)
-        ops.ln_modulate_bwd(dt, dD, ptr(ws.xres[2 * Lyr]), ptr(ws.meanf), ptr(ws.rstdf), mo + 4 * D, ld, 0, dres, dmo, dmo + 4 * D, ld, B, T, D)
+        ln_bwd_and_gate(dD, ptr(ws.xres[2 * Lyr]), ptr(ws.meanf), ptr(ws.rstdf), mo + 4 * D, 0, dmo, dmo + 4 * D,
+                        (Lyr - 1, "mlp") if Lyr else None)
         if hook:
             hook(Lyr + 1)
-        es = self._wsize
-        defer = ws.defer and dt == BF16
-        fp8 = ws.fp8
         pending = []                      # blocks whose weight gradients wait for the next grouped launch
         group_cut = Lyr // 2 if (hook and Lyr >= 4) else 0      # with a listener: flush once half-way, once at the end
+
+        def fold_bias(blocks, qkv_too):
+            """The bias gradients of `blocks` from the partial column sums their backward left behind: one launch."""
+            key = (blocks[0], blocks[-1], self._gbase, qkv_too)
+            grp = ws.bias_groups.get(key)
+            if grp is None:
+                jobs = []
+                for l in blocks:
+                    b, pre = ws.blk[l], f"blocks.{l}."
+                    names = [("cp_fc2", "mlp.fc2."), ("cp_fc1", "mlp.fc1."), ("cp_proj", "attn.proj.")] + ([("cp_qkv", "attn.qkv.")] if qkv_too else [])
+                    for key_cp, nm in names:
+                        cp = b[key_cp]
+                        jobs.append((cp.buf.data_ptr(), self._g(pre + nm + "bias"), cp.rows.value, cp.N))
+                grp = ws.bias_groups[key] = ops.ReduceGroup(jobs, dout.device)
+            grp.launch(beta)
 
         def flush():
             """One grouped launch for the weight gradients of the blocks in `pending`, then their gradient-ready stages."""
@@ -538,6 +586,7 @@ class DiT(FlatModule):
                         probs.append((ptr(dy), ptr(x), self._g(name + "weight"), Nw, Kw, Nw, Kw, Kw))
                 grp = ws.wgrad_groups[key] = ops.WgradGroup(probs, M, dout.device)
             grp.launch((L.BF8 if self.fp8_grad_format == "e5m2" else L.FP8) if fp8 else dt, beta)
+            fold_bias(list(pending), True)
             if hook:
                 for l in pending:
                     hook(l + 1)
@@ -547,51 +596,45 @@ class DiT(FlatModule):
             b, pre = ws.blk[l], f"blocks.{l}."
             mo, dmo = mod + 4 * (6 * l * D), dmod + 4 * (6 * l * D)
             xin, xmid = ptr(ws.xres[2 * l]), ptr(ws.xres[2 * l + 1])
-            dy2, dhid, dy1, dq = ((ptr(b["dy2"]), ptr(b["dDm"]), ptr(b["dy1"]), ptr(b["dqkv"])) if (defer and not fp8)
-                                  else (dD, dDm, dD, ptr(ws.dqkv)))
-            # MLP branch
-            # bias gradients ride on the kernels that produce dy (per-sample partials / GEMM epilogue): no re-read
-            fuse_rows = fp8 and ws.d_bwd and self.fp8_fuse_epilogue and self.fp8_fuse_rows and M % 64 == 0 and D % 128 == 0     # gate backward writes fp8 itself
-            if fuse_rows:
-                ops.gate_bwd_fp8(dres, ptr(b["y2"]), mo + 4 * 5 * D, ld, b["f_dy2"], dmo + 4 * 5 * D, ld, B, T, D, colpart)
-            else:
-                ops.gate_bwd(dt, dres, ptr(b["y2"]), mo + 4 * 5 * D, ld, dy2, dmo + 4 * 5 * D, ld, B, T, D, colpart)
-            ops.reduce_rows(colpart, B, D, self._g(pre + "mlp.fc2.bias"), beta)
+            dy2, dhid, dy1, dq = ((ptr(b["dy2"]), ptr(b["dDm"]), ptr(b["dy1"]), ptr(b["dqkv"])) if own_dy
+                                  else (ptr(ws.dyb), dDm, ptr(ws.dyb), ptr(ws.dqkv)))
+            # MLP branch.  dy2, dgate and the partial column sums of dy2 (fc2's bias gradient) came out of the row kernel that
+            # produced this block's incoming residual gradient; bias gradients are folded per group (fold_bias)
             if not defer:
                 self._wgrad(dt, pre + "mlp.fc2.", dy2, ptr(b["a"]), D, Dm, M, beta, bias=False)
             fuse_dh = fp8 and ws.d_bwd and self.fp8_fuse_epilogue and M % 64 == 0       # fc2's input-gradient epilogue writes dhid as fp8
             self._linear_dgrad(ws, b, "f_dy2", None if fuse_rows else dy2, pre + "mlp.fc2.", M, D, Dm, b["f_dhid"].epilogue_target() if fuse_dh else dhid, act=2,
-                               aux_in=ptr(b["hpre"]), colsum_out=self._g(pre + "mlp.fc1.bias"), colsum_beta=beta,
-                               **({"out_fp8": b["f_dhid"]} if fuse_dh else {}))
+                               aux_in=ptr(b["hpre"]), colsum_partial=b["cp_fc1"], **({"out_fp8": b["f_dhid"]} if fuse_dh else {}))
             if not defer:
                 self._wgrad(dt, pre + "mlp.fc1.", dhid, ptr(b["xm2"]), Dm, D, M, beta, bias=False)
             self._linear_dgrad(ws, b, "f_dhid", None if (fp8 and fuse_dh) else dhid, pre + "mlp.fc1.", M, Dm, D, dD)
-            ops.ln_modulate_bwd(dt, dD, xmid, ptr(b["mean2"]), ptr(b["rstd2"]), mo + 4 * 4 * D, ld, dres, dres,
-                                dmo + 4 * 3 * D, dmo + 4 * 4 * D, ld, B, T, D)
-            # attention branch
-            if fuse_rows:
-                ops.gate_bwd_fp8(dres, ptr(b["y1"]), mo + 4 * 2 * D, ld, b["f_dy1"], dmo + 4 * 2 * D, ld, B, T, D, colpart)
-            else:
-                ops.gate_bwd(dt, dres, ptr(b["y1"]), mo + 4 * 2 * D, ld, dy1, dmo + 4 * 2 * D, ld, B, T, D, colpart)
-            ops.reduce_rows(colpart, B, D, self._g(pre + "attn.proj.bias"), beta)
+            ln_bwd_and_gate(dD, xmid, ptr(b["mean2"]), ptr(b["rstd2"]), mo + 4 * 4 * D, dres, dmo + 4 * 3 * D, dmo + 4 * 4 * D, (l, "attn"))
+            # attention branch (dy1 etc. from the fused row kernel just above)
             if not defer:
                 self._wgrad(dt, pre + "attn.proj.", dy1, ptr(b["ao"]), D, D, M, beta, bias=False)
             self._linear_dgrad(ws, b, "f_dy1", None if fuse_rows else dy1, pre + "attn.proj.", M, D, D, ptr(ws.dao))
             q = ptr(b["qkv"])
-            ops.attn_bwd(dt, self._attn_desc(B), q, q + es * D, q + 2 * es * D, ptr(b["ao"]), ptr(ws.dao), ptr(b["lse"]),
-                         ptr(ws.delta), dq, dq + es * D, dq + 2 * es * D)
-            if defer:      # the qkv bias gradient = column sums of dqkv (the per-layer launch takes them from its staged dy tiles)
-                ops.colsum(dt, dq, M, 3 * D, 3 * D, self._g(pre + "attn.qkv.bias"), beta, device=dout.device)
-            else:
-                self._wgrad(dt, pre + "attn.qkv.", dq, ptr(b["xm"]), 3 * D, D, M, beta)
+            qkv_bias_folded = False
+            if defer:      # the qkv bias gradient = column sums of dqkv: partial rows from the attention kernels where they offer it
+                qkv_bias_folded = ops.attn_bwd_colsum(dt, self._attn_desc(B), q, q + es * D, q + 2 * es * D, ptr(b["ao"]), ptr(ws.dao),
+                                                      ptr(b["lse"]), ptr(ws.delta), dq, dq + es * D, dq + 2 * es * D, b["cp_qkv"])
+            if not qkv_bias_folded:
+                ops.attn_bwd(dt, self._attn_desc(B), q, q + es * D, q + 2 * es * D, ptr(b["ao"]), ptr(ws.dao), ptr(b["lse"]),
+                             ptr(ws.delta), dq, dq + es * D, dq + 2 * es * D)
+                if defer:
+                    ops.colsum(dt, dq, M, 3 * D, 3 * D, b["cp_qkv"].buf.data_ptr(), 0.0, device=dout.device)     # one complete row
+                    b["cp_qkv"].rows.value = 1
+                else:      # (the per-layer launch takes the bias gradient from its staged dy tiles)
+                    self._wgrad(dt, pre + "attn.qkv.", dq, ptr(b["xm"]), 3 * D, D, M, beta)
             self._linear_dgrad(ws, b, "f_dqkv", dq, pre + "attn.qkv.", M, 3 * D, D, dD)
-            ops.ln_modulate_bwd(dt, dD, xin, ptr(b["mean1"]), ptr(b["rstd1"]), mo + 4 * D, ld, dres, dres, dmo, dmo + 4 * D,
-                                ld, B, T, D)
+            ln_bwd_and_gate(dD, xin, ptr(b["mean1"]), ptr(b["rstd1"]), mo + 4 * D, dres, dmo, dmo + 4 * D, (l - 1, "mlp") if l else None)
             if defer:
                 pending.append(l)
                 if l == group_cut:
                     pending.reverse()
                     flush()
+            else:
+                fold_bias([l], False)
             if hook:
                 if not defer:
                     hook(l + 1)

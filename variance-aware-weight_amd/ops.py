@@ -141,17 +141,20 @@ def sample_step(kind, mean_out, var_out, x, noise, coef, mean_mode, var_mode, cl
 # ---- dense -------------------------------------------------------------------------------------
 def gemm(dt, a_kmajor, b_kmajor, M, N, K, A, lda, B, ldb, Cp, ldc, *, bias=None, act=0, aux_in=None, aux_out=None,
          gate=None, gate_ld=0, resid=None, rowadd=None, rows_per_batch=0, alpha=1.0, beta=0.0, out_f32=False,
-         colsum_out=None, colsum_beta=0.0, resid_is_act=False, rowsum_a_out=None, rowsum_a_beta=0.0):
-    """Raw-pointer GEMM; A, B, Cp, bias... are integers (device addresses).  See vaw_gemm in the header."""
+         colsum_out=None, colsum_beta=0.0, resid_is_act=False, rowsum_a_out=None, rowsum_a_beta=0.0, colsum_partial=None):
+    """Raw-pointer GEMM; A, B, Cp, bias... are integers (device addresses).  See vaw_gemm in the header.
+    colsum_partial = ColsumPartial: the column sums of C stay as partial rows in its buffer (folded later, many at once)."""
     e = Epilogue(bias or None, act, aux_in or None, aux_out or None, gate or None, gate_ld, resid or None,
                  rowadd or None, rows_per_batch, alpha, beta, 1 if out_f32 else 0, colsum_out or None, colsum_beta,
                  1 if resid_is_act else 0, rowsum_a_out or None, rowsum_a_beta)
+    if colsum_partial is not None:
+        e.colsum_partial_out, e.colsum_rows_out = colsum_partial.buf.data_ptr(), C.pointer(colsum_partial.rows)
     tr = gemm_trace
     if tr is not None:
         e0, e1 = tr.events()
         e0.record()
     ws_ptr, ws_n = 0, 0
-    if colsum_out or rowsum_a_out or (beta_or_plain(bias, act, aux_out, gate, resid, rowadd) and K >= 2048):     # may run split-K
+    if colsum_out or colsum_partial is not None or rowsum_a_out or (beta_or_plain(bias, act, aux_out, gate, resid, rowadd) and K >= 2048):     # may run split-K
         ws = scratch_f32(torch.device("cuda", torch.cuda.current_device()), 0)
         ws_ptr, ws_n = ws.data_ptr(), ws.numel()
     check(L.lib().vaw_gemm(dt, 1 if a_kmajor else 0, 1 if b_kmajor else 0, M, N, K, A, lda, B, ldb, Cp, ldc,
@@ -249,11 +252,13 @@ def q_scratch(n, device, pool=0):
 
 def gemm_fp8(M, N, K, A, lda, scale_a, B, ldb, scale_b, Cp, ldc, *, a_format=L.FP8, bias=None, act=0, aux_in=None, aux_out=None,
              gate=None, gate_ld=0, resid=None, rows_per_batch=0, alpha=1.0, out_f32=False, colsum_out=None, colsum_beta=0.0,
-             out_fp8=None):
+             out_fp8=None, colsum_partial=None):
     """Raw-pointer fp8 GEMM (vaw_gemm_fp8): A [M][K] bytes of a_format, B [N][K] e4m3 bytes; scale_a / scale_b device scalars.
     out_fp8 = an Fp8 whose delayed-scaling state is current: C (= its row-major bytes) is written as fp8 by the epilogue."""
     e = Epilogue(bias or None, act, aux_in or None, aux_out or None, gate or None, gate_ld, resid or None, None, rows_per_batch,
                  alpha, 0.0, 1 if out_f32 else 0, colsum_out or None, colsum_beta, 0, None, 0.0)
+    if colsum_partial is not None:
+        e.colsum_partial_out, e.colsum_rows_out = colsum_partial.buf.data_ptr(), C.pointer(colsum_partial.rows)
     tr = gemm_trace
     if tr is not None:
         e0, e1 = tr.events()
@@ -449,6 +454,56 @@ def ln_modulate_bwd(dt, dout, x, mean, rstd, scale, mod_ld, dres_in, dx, dshift,
                                       dmod_ld, B, T, D, ws.data_ptr(), ws.numel(), stream_ptr()), "vaw_ln_modulate_bwd")
 
 
+def ln_modulate_bwd_gate(dt, dout, x, mean, rstd, scale, mod_ld, dres_in, dx, dshift, dscale, dmod_ld, y_next, gate_next, dy_next,
+                         dgate_next, B, T, D, dy_colpart=0):
+    """ln_modulate_bwd + the gate_bwd that consumes its dx, one pass (vaw_ln_modulate_bwd_gate)."""
+    ws = _row_ws(B, T, D)
+    check(L.lib().vaw_ln_modulate_bwd_gate(dt, dout, x, mean, rstd, scale, mod_ld, dres_in or None, dx, dshift, dscale, dmod_ld,
+                                           y_next, gate_next, dy_next, dgate_next, dy_colpart or None, B, T, D, ws.data_ptr(),
+                                           ws.numel(), stream_ptr()), "vaw_ln_modulate_bwd_gate")
+
+
+def ln_modulate_bwd_gate_fp8(dout, x, mean, rstd, scale, mod_ld, dres_in, dx, dshift, dscale, dmod_ld, y_next, gate_next, f8,
+                             dgate_next, B, T, D, dy_colpart=0, pool=2):
+    """The fused pass with dy_next going straight into the Fp8 `f8` (as gate_bwd_fp8)."""
+    ws = _row_ws(B, T, D)
+    q = f8.epilogue_target(pool)
+    check(L.lib().vaw_ln_modulate_bwd_gate_fp8(dout, x, mean, rstd, scale, mod_ld, dres_in or None, dx, dshift, dscale, dmod_ld,
+                                               y_next, gate_next, q, f8.state.data_ptr(), f8.fmt, dgate_next, dy_colpart or None,
+                                               B, T, D, ws.data_ptr(), ws.numel(), stream_ptr()), "vaw_ln_modulate_bwd_gate_fp8")
+
+
+class ColsumPartial:
+    """Partial column sums [rows][N] f32 a dy-producing kernel leaves behind (rows: set by the kernel / known to the caller),
+    folded later by a ReduceGroup."""
+
+    def __init__(self, max_rows, N, device):
+        self.buf = torch.empty(max_rows, N, device=device, dtype=torch.float32)
+        self.N = int(N)
+        self.rows = C.c_int64(0)
+
+
+class ReduceJob(C.Structure):
+    """vaw_reduce_job of include/vaw_hip.h."""
+    _fields_ = [("partial", C.c_void_p), ("out", C.c_void_p), ("R", C.c_int64), ("N", C.c_int64)]
+
+
+class ReduceGroup:
+    """out_j = beta * out_j + column sums of partial_j for many (partial, R, N, out) jobs in ONE launch
+    (vaw_reduce_rows_batched); addresses are workspace / flat-buffer addresses, so the device table is uploaded once."""
+
+    def __init__(self, jobs, device):
+        self.n = len(jobs)
+        self.table = (ReduceJob * self.n)(*[ReduceJob(*j) for j in jobs])
+        self.desc = torch.empty(L.lib().vaw_reduce_rows_batched_desc_bytes(self.n), device=device, dtype=torch.uint8)
+        self.uploaded = False
+
+    def launch(self, beta):
+        check(L.lib().vaw_reduce_rows_batched(self.n, C.cast(self.table, C.c_void_p), float(beta), self.desc.data_ptr(),
+                                              0 if self.uploaded else 1, stream_ptr()), "vaw_reduce_rows_batched")
+        self.uploaded = True
+
+
 def gate_bwd(dt, dres, y, gate, mod_ld, dy, dgate, dmod_ld, B, T, D, dy_colpart=0):
     ws = _row_ws(B, T, D)
     check(L.lib().vaw_gate_bwd(dt, dres, y, gate, mod_ld, dy, dgate, dmod_ld, dy_colpart or None, B, T, D, ws.data_ptr(),
@@ -475,6 +530,17 @@ def attn_fwd(dt, desc, q, k, v, o, lse):
 
 def attn_bwd(dt, desc, q, k, v, o, d_o, lse, delta, dq, dk, dv):
     check(L.lib().vaw_attn_bwd(dt, C.byref(desc), q, k, v, o, d_o, lse, delta, dq, dk, dv, stream_ptr()), "vaw_attn_bwd")
+
+
+def attn_bwd_colsum(dt, desc, q, k, v, o, d_o, lse, delta, dq, dk, dv, partial):
+    """attn_bwd that leaves the column sums of dq | dk | dv as partial rows in the ColsumPartial `partial` (the qkv bias
+    gradient, folded later).  False -- nothing launched -- when the kernel path in use cannot (call attn_bwd + colsum then)."""
+    rc = L.lib().vaw_attn_bwd_colsum(dt, C.byref(desc), q, k, v, o, d_o, lse, delta, dq, dk, dv, partial.buf.data_ptr(),
+                                     C.byref(partial.rows), stream_ptr())
+    if rc == -3:
+        return False
+    check(rc, "vaw_attn_bwd_colsum")
+    return True
 
 
 def timestep_embedding(t, dim, dtype=torch.float32, max_period=10000.0):
