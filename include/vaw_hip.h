@@ -110,10 +110,12 @@ typedef struct {
                             * order); other layouts / the generic kernel honour it with a separate pass.  Needs the workspace */
     float rowsum_a_beta;
     float* colsum_partial_out;  /* deferred form of colsum_out (which must then be NULL): the kernel leaves its per-row-tile partial
-                                 * column sums of C, [*colsum_rows_out][N] f32 (at most ceil(M/128) rows: size the buffer for that),
+                                 * column sums of C, [*colsum_rows_out][N] f32 (at most ceil(M/64) rows: size the buffer for that),
                                  * here and does NOT fold them; the caller folds many such buffers in one launch
                                  * (vaw_reduce_rows_batched).  No workspace needed for it */
-    int64_t* colsum_rows_out;   /* HOST address that receives the number of partial rows written (required with the above) */
+    int64_t* colsum_rows_out;   /* HOST address, in / out (required with the above): on entry the capacity of colsum_partial_out in
+                                 * rows (a launch that needs more fails with VAW_ERR_INVALID before anything runs), on return
+                                 * the number of partial rows written */
 } vaw_epilogue;
 
 /* C[M,N] = epilogue( alpha * op(A)[M,K] . op(B)[K,N] )
@@ -311,8 +313,8 @@ int vaw_attn_bwd(vaw_dtype dt, const vaw_attn_desc* d_host, const void* q, const
                  vaw_stream stream);
 /* vaw_attn_bwd that also leaves the column sums of dq | dk | dv behind as PARTIAL rows -- the bias gradient of the qkv Linear in
  * front of the attention (timm Attention, models/dit.py:126: db = sum over tokens of dqkv) without a second pass over dqkv:
- * colsum_partial [*rows_out][3*H*hd] f32 in packed-qkv column order [3][H][hd]; at most B*T/64 rows (size the buffer for
- * that); fold them with vaw_reduce_rows / vaw_reduce_rows_batched.  Only the bf16 MFMA kernels offer it (token-major or any
+ * colsum_partial [*rows_out][3*H*hd] f32 in packed-qkv column order [3][H][hd]; at most B*T/64 rows: *rows_out is in / out --
+ * on entry the capacity of the buffer in rows (checked), on return the rows written; fold them with vaw_reduce_rows / vaw_reduce_rows_batched.  Only the bf16 MFMA kernels offer it (token-major or any
  * layout they accept): VAW_ERR_UNSUPPORTED, nothing launched, otherwise -- use vaw_attn_bwd + vaw_colsum then. */
 int vaw_attn_bwd_colsum(vaw_dtype dt, const vaw_attn_desc* d, const void* q, const void* k, const void* v, const void* o,
                         const void* d_o, const float* lse, float* delta, void* dq, void* dk, void* dv, float* colsum_partial,

@@ -121,3 +121,125 @@ def test_data_parallel_wrapper_two_gloo_ranks():
         p.join(timeout=60)
     for rank, msg in results:
         assert msg == "ok", f"rank {rank}:\n{msg}"
+
+
+# ---- sharded optimizer (ZeRO-1) and the real DiT bucket layout, incl. the early adaLN bucket ---------------------------------
+def _adamw_torch(p, g, m, v, ema, shadow, lr, beta1, beta2, eps, wd, step, ema_decay, sumsq_t, clip, zero_grad, hyper=None):
+    """torch statement of vaw_adamw_ema_step for the CPU ranks of this test (the product has no CPU path: test stand-in only).
+    One IEEE operation per torch call (no alpha= / value= forms, which may or may not contract into an FMA depending on how a
+    slice falls on the vector width): the result of an element then cannot depend on how the buffer is cut into chunks."""
+    scale = 1.0
+    if clip:
+        scale = min(1.0, float(clip) / (float(sumsq_t.sqrt()) + 1e-6))
+    gg = g * scale
+    p.mul_(1 - lr * wd)
+    m.mul_(beta1).add_(gg * (1 - beta1))
+    v.mul_(beta2).add_((gg * gg) * (1 - beta2))
+    denom = (v.sqrt() / (1 - beta2 ** step) ** 0.5) + eps
+    p.sub_((m / denom) * (lr / (1 - beta1 ** step)))
+    if ema is not None:
+        ema.mul_(ema_decay).add_(p * (1 - ema_decay))
+    if shadow is not None:
+        shadow.copy_(p)
+
+
+def _sumsq_torch(g, out, accumulate=False):
+    out.copy_((out if accumulate else 0) + g.double().pow(2).sum().float())
+
+
+def _zero_worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, REPO)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+        import vaw_amd
+        from vaw_amd import ops
+        ops.adamw_ema_step, ops.sumsq = _adamw_torch, _sumsq_torch          # CPU stand-ins for the HIP kernels of the update
+        ops.ema_update = lambda ema, src, decay: ema.mul_(decay).add_(src * (1 - decay))
+        vaw_amd.dist_util.setup_dist()
+
+        def build():
+            torch.manual_seed(5)
+            m = vaw_amd.DiT(image_size=8, patch_size=2, in_channels=4, hidden_size=64, depth=4, num_heads=2, class_dropout_prob=0.0,
+                            num_classes=10, learn_sigma=False, compute_dtype="fp32")
+            with torch.no_grad():
+                for p in m.parameters():
+                    if p.requires_grad:
+                        p.add_(torch.randn(p.shape) * 0.05)
+            return m
+
+        def fake_backward(m, step):
+            """Every stage of the real DiT backward fires in its order (head, blocks L-1..0 with the early adaLN bucket half-way,
+            embedders); gradients are small integers that depend on rank, element and step: sums over ranks are exact."""
+            g = m.flat_grads()
+            n = g.numel()
+            g.copy_(((torch.arange(n) % 7) - 3 + rank + step).float())
+            m.attach_grads()
+            hook = m.grad_ready_hook
+            L = m.depth
+            hook(L + 1)
+            for l in reversed(range(L)):
+                hook(l + 1)
+                if l == m._ada_split_block():
+                    hook("ada_hi")
+            hook(0)
+
+        def run(shard, clip):
+            m = build()
+            ddp = vaw_amd.DistributedDataParallel(m, shard_optimizer=shard)
+            # the buckets partition the trainable range exactly, early adaLN bucket included
+            rngs = ddp.bucket_ranges()
+            assert rngs[0][0] == 0 and rngs[-1][1] == m._flat_n_train and all(a[1] == b[0] for a, b in zip(rngs, rngs[1:]))
+            assert any(isinstance(v, list) for v in ddp._ranges.values()), "expected the split adaLN stage"
+            opt = vaw_amd.FusedAdamW(m, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.01)
+            ema_model = build() if rank == 0 else None
+            if shard:
+                opt.attach_ema_sharded(0.9, ema_model)
+            elif rank == 0:
+                opt.attach_ema(ema_model, 0.9)
+            opt.max_grad_norm = clip
+            for step in range(3):
+                fake_backward(m, step)
+                opt.step()
+                opt.zero_grad()
+            if shard:
+                opt.consolidate()
+                opt.consolidate_ema(ema_model)
+            sd = opt.state_dict()
+            return m._flat.clone(), (ema_model._flat.clone() if rank == 0 else None), sd
+
+        for clip in (None, 2.5):
+            ref_p, ref_e, ref_sd = run(False, clip)
+            got_p, got_e, got_sd = run(True, clip)
+            assert torch.equal(ref_p, got_p), f"clip={clip}: parameters differ by {float((ref_p - got_p).abs().max())}"
+            if rank == 0:
+                assert torch.equal(ref_e, got_e), f"clip={clip}: EMA differs by {float((ref_e - got_e).abs().max())}"
+            for i, st in ref_sd["state"].items():
+                assert torch.equal(st["exp_avg"], got_sd["state"][i]["exp_avg"]) and torch.equal(st["exp_avg_sq"], got_sd["state"][i]["exp_avg_sq"])
+        # a sharded optimizer restored from a full state dict continues like the unsharded one
+        m = build()
+        ddp = vaw_amd.DistributedDataParallel(m, shard_optimizer=True)
+        opt = vaw_amd.FusedAdamW(m, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.01)
+        opt.load_state_dict(ref_sd)
+        assert opt.step_count == 3 and opt.exp_avg.numel() * world == m._flat_n_train
+        vaw_amd.dist_util.dist_barrier()
+        vaw_amd.dist_util.cleanup_dist()
+        q.put((rank, "ok"))
+    except Exception:
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_optimizer_equals_unsharded_on_the_dit_bucket_layout(world):
+    """ZeRO-1 (reduce-scatter -> AdamW + EMA on 1 / world of every bucket -> all-gather) reproduces the all-reduce + full
+    update bit for bit (integer gradients), with the REAL DiT stage bounds: head, blocks, the early adaLN bucket, embedders."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_zero_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in results:
+        assert msg == "ok", f"rank {rank}:\n{msg}"

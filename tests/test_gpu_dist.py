@@ -65,6 +65,12 @@ def _one_step(vaw_amd, net, model, x, y, t, noise, micro=1):
     torch.cuda.synchronize()
     grads = model.flat_grads().detach().cpu().clone()      # what the wrapper is responsible for: the averaged flat gradient
     opt.step()
+    if getattr(opt, "zero", None) is not None:             # sharded optimizer: every rank's f32 masters up to date again
+        opt.consolidate()
+        own = torch.zeros_like(grads, dtype=torch.bool)
+        for lo, hi in opt._chunks:
+            own[lo:hi] = True
+        grads = torch.where(own, grads, torch.full_like(grads, float("nan")))     # only this rank's chunks were reduced
     torch.cuda.synchronize()
     return torch.cat(mses), model._flat.detach().cpu().clone(), grads
 
@@ -81,7 +87,8 @@ def _worker(rank, world, port, q, kind, variant):
             model.ensure_flat()
             with torch.no_grad():
                 model._flat.add_(0.5)                      # ranks start different: the wrapper's broadcast must equalise them
-        net = vaw_amd.DistributedDataParallel(model, bucket_dtype="bf16" if variant == "bf16_buckets" else "f32")
+        net = vaw_amd.DistributedDataParallel(model, bucket_dtype="bf16" if variant == "bf16_buckets" else "f32",
+                                              shard_optimizer=variant == "zero")
         x, y, t, noise = (v[4 * rank:4 * rank + 4].to(dev) for v in _data(kind))
         mse, flat, grads = _one_step(vaw_amd, net, model, x, y, t, noise, micro=2 if variant == "no_sync" else 1)
         q.put((rank, mse.numpy(), flat.numpy(), grads.numpy(), None))      # by value: the worker exits before the parent reads
@@ -90,7 +97,8 @@ def _worker(rank, world, port, q, kind, variant):
         q.put((rank, None, None, None, traceback.format_exc()))
 
 
-@pytest.mark.parametrize("kind,variant", [("dit", "sync"), ("dit", "no_sync"), ("dit", "bf16_buckets"), ("unet", "sync"), ("unet", "no_sync")])
+@pytest.mark.parametrize("kind,variant", [("dit", "sync"), ("dit", "no_sync"), ("dit", "bf16_buckets"), ("unet", "sync"), ("unet", "no_sync"),
+                                          ("dit", "zero"), ("unet", "zero")])
 def test_two_rank_step_reproduces_single_rank_step(kind, variant):
     import vaw_amd
     dev = torch.device("cuda", 0)
@@ -115,7 +123,12 @@ def test_two_rank_step_reproduces_single_rank_step(kind, variant):
     # the averaged flat gradient itself: bitwise equal on both ranks, and equal to the single-rank gradient of the whole batch
     # within 1e-6 of the tensor's rms (f32 buckets: only the order of summation differs; bf16 buckets round each rank's
     # contribution to 8 bits on the wire: 2^-8 relative per element)
-    assert torch.equal(res[0][2], res[1][2])
+    if variant == "zero":      # reduce-scatter: each rank holds the averaged gradient of its own chunks (NaN elsewhere); together all
+        g0, g1 = res[0][2], res[1][2]
+        assert bool((g0.isnan() ^ g1.isnan()).all())
+        res[0] = (res[0][0], res[0][1], torch.where(g0.isnan(), g1, g0))
+    else:
+        assert torch.equal(res[0][2], res[1][2])
     rms = float(grads1.pow(2).mean().sqrt())
     gd = (res[0][2] - grads1).abs()
     if variant == "bf16_buckets":       # each rank's share and the wire sum are rounded to 8 significant bits

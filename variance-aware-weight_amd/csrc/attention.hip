@@ -246,6 +246,8 @@ extern "C" int vaw_attn_bwd_colsum(vaw_dtype dt, const vaw_attn_desc* d, const v
     int rc = check_desc(d, "attn_bwd_colsum");
     if (rc) return rc;
     VAW_CHECK_ARG(colsum_partial && rows_out, "attn_bwd_colsum: colsum_partial and rows_out are required");
+    VAW_CHECK_ARG(*rows_out >= (int64_t)d->B * (d->T / 64 > 0 ? d->T / 64 : 1), "attn_bwd_colsum: *rows_out states a capacity of %ld rows, up to %ld are written",
+                  (long)*rows_out, (long)((int64_t)d->B * (d->T / 64 > 0 ? d->T / 64 : 1)));
     if (!g_force_rowwise && vaw_attn_mfma_ok(dt, d, q, k, v, d_o) && (((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 7) == 0 && d->hd % 4 == 0)
         return vaw_attn_bwd_mfma(d, q, k, v, o, d_o, lse, delta, dq, dk, dv, (hipStream_t)stream, colsum_partial, rows_out);
     vaw_set_error("attn_bwd_colsum: only the bf16 MFMA attention kernels carry column sums");

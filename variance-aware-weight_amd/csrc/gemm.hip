@@ -798,6 +798,10 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
     const bool colsum_out = colsum_final || colsum_part;                  // "this launch carries column sums"
     float* const colsum_dst = colsum_part ? colsum_part : workspace;      // where the kernels leave their partial rows
     const float colsum_beta = ep ? ep->colsum_beta : 0.f;
+    // colsum_rows_out is in / out: the caller states the capacity of colsum_partial_out in rows, the call answers with the rows
+    // written -- checked BEFORE anything is launched (a kernel path that needs more rows than the buffer has is an error)
+    const int64_t colsum_cap = colsum_part ? *ep->colsum_rows_out : 0;
+#define CS_CAP_CHECK(R) VAW_CHECK_ARG(!colsum_part || (R) <= colsum_cap, "gemm: colsum_partial_out holds %ld rows, this launch writes %ld", (long)colsum_cap, (long)(R))
     auto fold_colsum = [&](int64_t R) -> int {
         if (colsum_part) { *ep->colsum_rows_out = R; return VAW_OK; }
         return vaw_reduce_rows(workspace, R, N, colsum_final, colsum_beta, stream);
@@ -843,15 +847,21 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
             }
             const int64_t rows64 = (M + 63) / 64;
             const bool cs_room = !colsum_out || colsum_part || workspace_floats >= rows64 * N;
+            // measured (tools/gemm_bench.py --m 2048 / 4096 / 8192 --tile sm, DiT-B/4 shapes): 1.2-1.8x faster than the 128- and
+            // 256-row kernels on the launches that give those less than one workgroup per CU (the 768-wide layers up to 4096
+            // rows: 16.0 -> 11.3, 39.4 -> 24.4, 30.2 -> 17.2, 34.2 -> 21.1 us at 2048 rows), slower on the wide ones (its 64-row
+            // tiles move twice the operand bytes per MFMA): taken only below one 128 x 128 tile per CU
+            const bool sm_few_tiles = ((M + 127) / 128) * ((N + 127) / 128) < 256;
             const bool sm_forced = g_gemm_tile >= 5 && g_gemm_tile <= 7;     // vaw_debug_gemm_tile: 5 always, 6 / 7 always with 64 / 128-column tiles
-            if (a_kmajor && ((M <= sm_max_m && g_gemm_tile < 0) || sm_forced) && !rowsum_out && cs_room && N % 8 == 0) {
+            if (a_kmajor && ((M <= sm_max_m && sm_few_tiles && g_gemm_tile < 0) || sm_forced) && !rowsum_out && cs_room && N % 8 == 0) {
                 // 64 x 128 tiles when they still give every CU a workgroup, 64 x 64 otherwise; ring depth by the LDS it leaves:
                 // 3 stages = two (64 x 128) or three (64 x 64) workgroups per CU for multi-round launches, 4 for single rounds
                 const int64_t t2 = rows64 * ((N + 127) / 128);
-                const int nb = g_gemm_tile == 6 ? 1 : g_gemm_tile == 7 ? 2 : sm_nb ? sm_nb : (t2 >= 256 ? 2 : 1);
+                const int nb = g_gemm_tile == 6 ? 1 : g_gemm_tile == 7 ? 2 : sm_nb ? sm_nb : (t2 >= 384 ? 2 : 1);
                 const int64_t tiles = rows64 * ((N + 64 * nb - 1) / (64 * nb));
                 const int stages = sm_st ? sm_st : (tiles > 256 ? 3 : 4);
                 EpiDev es = e;
+                CS_CAP_CHECK(rows64);
                 if (colsum_out) es.colpart = colsum_dst;
                 vaw_sm_launch(nb, stages, b_kmajor, M, N, K, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, es, s);
                 VAW_CHECK_LAUNCH("gemm_sm");
@@ -926,6 +936,7 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
                                                 colsum_out, workspace_floats, force)
                                   : P8Plan{false, 4, 1, 0};
             if (pl.use) {
+                CS_CAP_CHECK((M + 127) / 128);
                 EpiDev ep8 = e;
                 static int nt_off = -1;
                 // default: epilogue stores with the default cache policy (measured: nt costs 5-15 % on the f32 gated-residual and
@@ -954,6 +965,7 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
         const int64_t tiles_nb = (N + BIG_BN - 1) / BIG_BN, n_wgb = ((M + BIG_BM - 1) / BIG_BM) * tiles_nb;
         const bool use_big = bk_env == 0 && !fused_rowsum && (g_gemm_tile == 1 || (g_gemm_tile == -1 && big_tile_pays(M, N, K, n_wgb)));
         if (use_big) {
+            CS_CAP_CHECK((M + BIG_BM - 1) / BIG_BM);
             const int nkb = (int)(K / 32);
             int splitb = colsum_out ? 1 : pick_split(n_wgb * 2, K, M * N, workspace_floats, plain_f32);
             if (splitb > 1) {
@@ -986,6 +998,7 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
             if (colsum_out) return fold_colsum((M + BIG_BM - 1) / BIG_BM);
             return VAW_OK;
         }
+        CS_CAP_CHECK((M + BM - 1) / BM);
         if (bkt == 32) LAUNCH_FAST_BK(32);
         else LAUNCH_FAST_BK(64);
         if (split > 1 && !e.out_f32)
@@ -1012,6 +1025,7 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
         kchunk = ((K + split - 1) / split + GBK - 1) / GBK * GBK;
         split = (int)((K + kchunk - 1) / kchunk);
     }
+    CS_CAP_CHECK(1);
     dim3 grid(ceil_div(N, GBN), ceil_div(M, GBM), split);
 #define LAUNCH_GEN(T, AKv, BKv) \
     gemm_generic_kernel<T, AKv, BKv><<<grid, 256, 0, s>>>((const T*)A, lda, (const T*)B, ldb, K, kchunk, e)

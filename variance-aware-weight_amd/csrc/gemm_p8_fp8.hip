@@ -340,6 +340,8 @@ extern "C" int vaw_gemm_fp8(vaw_dtype a_format, int64_t M, int64_t N, int64_t K,
     float* const colsum_part = ep ? ep->colsum_partial_out : nullptr;       // deferred fold (vaw_reduce_rows_batched): see vaw_epilogue
     VAW_CHECK_ARG(!colsum_part || (!colsum_final && ep->colsum_rows_out), "gemm_fp8: colsum_partial_out excludes colsum_out and needs colsum_rows_out");
     const bool colsum_out = colsum_final || colsum_part;
+    VAW_CHECK_ARG(!colsum_part || *ep->colsum_rows_out >= (M + 127) / 128, "gemm_fp8: colsum_partial_out holds %ld rows, this launch writes %ld",
+                  (long)*ep->colsum_rows_out, (long)((M + 127) / 128));      // colsum_rows_out: capacity in, rows written out
     VAW_CHECK_ARG(!colsum_final || (workspace && workspace_floats >= ((M + 127) / 128) * N), "gemm_fp8: colsum_out needs a workspace");
     e.M = M; e.N = N; e.ldc = ldc; e.C = C; e.slab = workspace; e.nt_off = 1;
     e.scale_a = scale_a; e.scale_b = scale_b;

@@ -151,12 +151,12 @@ class _Workspace:
                 b.update(dy2=e(M, D), dDm=e(M, m.Dm), dy1=e(M, D), dqkv=e(M, 3 * D))
         self.wgrad_groups = {}
         # bias gradients: the kernels that produce dy leave partial column sums per block (gate backward: one row per sample;
-        # fc2's GELU' epilogue: one per 128 token rows; attention backward: one per sample and 64-token block); ONE batched fold
+        # fc2's GELU' epilogue: one per 64 or 128 token rows; attention backward: one per sample and 64-token block); ONE batched fold
         # per group of blocks turns them into the four bias gradients of every block (ops.ReduceGroup)
         self.bias_groups = {}
         for b in self.blk:
             b.update(cp_fc2=ops.ColsumPartial(B, D, dev), cp_proj=ops.ColsumPartial(B, D, dev),
-                     cp_fc1=ops.ColsumPartial((M + 127) // 128, m.Dm, dev), cp_qkv=ops.ColsumPartial(max(B, M // 64), 3 * D, dev))
+                     cp_fc1=ops.ColsumPartial((M + 63) // 64, m.Dm, dev), cp_qkv=ops.ColsumPartial(max(B, M // 64), 3 * D, dev))
             b["cp_fc2"].rows.value = b["cp_proj"].rows.value = B
         self.dyb = e(M, D)          # dy of a gated branch when the block keeps no buffer of its own (f32 / fp8 / per-layer wgrad modes)
         self.delta = e(B * m.num_heads * T, dtype=f32)

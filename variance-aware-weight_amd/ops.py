@@ -148,6 +148,7 @@ def gemm(dt, a_kmajor, b_kmajor, M, N, K, A, lda, B, ldb, Cp, ldc, *, bias=None,
                  rowadd or None, rows_per_batch, alpha, beta, 1 if out_f32 else 0, colsum_out or None, colsum_beta,
                  1 if resid_is_act else 0, rowsum_a_out or None, rowsum_a_beta)
     if colsum_partial is not None:
+        colsum_partial.rows.value = colsum_partial.buf.shape[0]           # in: capacity; out: rows written
         e.colsum_partial_out, e.colsum_rows_out = colsum_partial.buf.data_ptr(), C.pointer(colsum_partial.rows)
     tr = gemm_trace
     if tr is not None:
@@ -258,6 +259,7 @@ def gemm_fp8(M, N, K, A, lda, scale_a, B, ldb, scale_b, Cp, ldc, *, a_format=L.F
     e = Epilogue(bias or None, act, aux_in or None, aux_out or None, gate or None, gate_ld, resid or None, None, rows_per_batch,
                  alpha, 0.0, 1 if out_f32 else 0, colsum_out or None, colsum_beta, 0, None, 0.0)
     if colsum_partial is not None:
+        colsum_partial.rows.value = colsum_partial.buf.shape[0]           # in: capacity; out: rows written
         e.colsum_partial_out, e.colsum_rows_out = colsum_partial.buf.data_ptr(), C.pointer(colsum_partial.rows)
     tr = gemm_trace
     if tr is not None:
@@ -535,6 +537,7 @@ def attn_bwd(dt, desc, q, k, v, o, d_o, lse, delta, dq, dk, dv):
 def attn_bwd_colsum(dt, desc, q, k, v, o, d_o, lse, delta, dq, dk, dv, partial):
     """attn_bwd that leaves the column sums of dq | dk | dv as partial rows in the ColsumPartial `partial` (the qkv bias
     gradient, folded later).  False -- nothing launched -- when the kernel path in use cannot (call attn_bwd + colsum then)."""
+    partial.rows.value = partial.buf.shape[0]             # in: capacity; out: rows written
     rc = L.lib().vaw_attn_bwd_colsum(dt, C.byref(desc), q, k, v, o, d_o, lse, delta, dq, dk, dv, partial.buf.data_ptr(),
                                      C.byref(partial.rows), stream_ptr())
     if rc == -3:

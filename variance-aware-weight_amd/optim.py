@@ -24,6 +24,13 @@ class FusedAdamW(torch.optim.Optimizer):
         super().__init__(inner._flat_params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
         n = inner._flat_n_train
         dev = inner._flat.device
+        # ZeRO-1 (vaw_amd.DistributedDataParallel(..., shard_optimizer=True), wrapped BEFORE this optimizer is built): AdamW state
+        # and the EMA exist only for this rank's chunk of every gradient bucket, stored back to back in compact buffers
+        self.zero = getattr(inner, "_zero", None)
+        if self.zero is not None:
+            self._chunks = self.zero.owned_chunks()
+            n = sum(hi - lo for lo, hi in self._chunks)
+            self._ema_shard = self._ema_frozen = None
         self.exp_avg = torch.zeros(n, device=dev, dtype=torch.float32)
         self.exp_avg_sq = torch.zeros(n, device=dev, dtype=torch.float32)
         self._sumsq = torch.zeros(1, device=dev, dtype=torch.float32)
@@ -61,9 +68,107 @@ class FusedAdamW(torch.optim.Optimizer):
             raise ValueError("EMA model layout differs from the trained model")
         self.ema_model, self.ema_decay = e, float(decay)
 
+    def attach_ema_sharded(self, decay, ema_model=None):
+        """ZeRO-1: every rank averages its own chunks (compact f32 shard, started from the EMA model's weights when this rank
+        has one -- the reference keeps the EMA copy on rank 0 only, main.py:344 -- else from the trained weights);
+        consolidate_ema() writes the gathered average into an EMA model."""
+        assert self.zero is not None
+        import torch.distributed as dist
+        n = self.model._flat_n_train
+        full = self.model._flat[:n].clone()
+        if self.zero.rank == 0 and ema_model is not None:
+            e = getattr(ema_model, "module", ema_model)
+            e.ensure_flat()
+            full.copy_(e._flat[:n])
+        dist.broadcast(full, src=0, group=self.zero.pg)     # rank 0's copy is THE average (it may come from a checkpoint)
+        self._ema_shard = torch.cat([full[lo:hi] for lo, hi in self._chunks]).clone()
+        self.ema_decay = float(decay)
+        # frozen entries (pos_embed) are averaged too by the reference's ema() (tools/trainer.py:12-18: every state_dict entry);
+        # they are not sharded: the rank that holds an EMA model keeps doing that part itself
+        self._ema_frozen = None
+        if ema_model is not None:
+            e = getattr(ema_model, "module", ema_model)
+            if e._flat.numel() > n:
+                self._ema_frozen = e
+
+    def _step_sharded(self):
+        """reduce-scattered gradients -> AdamW (+EMA) on this rank's chunks only -> all-gather of the updated weights."""
+        m, z, grp = self.model, self.zero, self.param_groups[0]
+        g = m.flat_grads()
+        z.wait_gathers()
+        if self.device_hyper is None:
+            self.step_count += 1
+        clip = self.max_grad_norm
+        if clip:      # global norm: this rank's chunks hold 1 / world of the averaged gradient; the scalar is summed over ranks
+            for i, (lo, hi) in enumerate(self._chunks):
+                ops.sumsq(g[lo:hi], self._sumsq, accumulate=i > 0)
+            import torch.distributed as dist
+            dist.all_reduce(self._sumsq, group=z.pg)
+        shadow = m._flat_shadow
+        off = 0
+        for lo, hi in self._chunks:
+            k = hi - lo
+            ops.adamw_ema_step(m._flat[lo:hi], g[lo:hi], self.exp_avg[off:off + k], self.exp_avg_sq[off:off + k],
+                               None if self._ema_shard is None else self._ema_shard[off:off + k],
+                               None if shadow is None else shadow[lo:hi], grp["lr"], grp["betas"][0], grp["betas"][1], grp["eps"],
+                               grp["weight_decay"], self.step_count, self.ema_decay, self._sumsq if clip else None, clip, False,
+                               hyper=self.device_hyper)
+            off += k
+        # the weights the kernels read: the bf16 shadow in throughput mode (2 B per parameter on the wire; the f32 masters of
+        # other ranks' chunks go stale until consolidate()), the f32 parameters in parity mode
+        if shadow is not None:
+            z.all_gather_chunks(shadow)
+            self.master_stale = True
+        else:
+            z.all_gather_chunks(m._flat)
+        if self._ema_shard is not None and self._ema_frozen is not None:
+            n = m._flat_n_train
+            ops.ema_update(self._ema_frozen._flat[n:], m._flat[n:], self.ema_decay)
+        m.mark_shadow_fresh()
+        self.ema_done_in_step = self._ema_shard is not None
+
+    def consolidate(self):
+        """ZeRO-1: bring every rank's f32 master parameters up to date (before state_dict / checkpoints / evaluation in f32)."""
+        if self.zero is not None and getattr(self, "master_stale", False):
+            self.zero.wait_gathers()
+            self.zero.all_gather_chunks(self.model._flat, async_stream=False)
+            self.master_stale = False
+
+    def consolidate_ema(self, ema_model):
+        """ZeRO-1: gather the sharded average into `ema_model`'s trainable parameters (every rank that passes a model gets it)."""
+        import torch.distributed as dist
+        z = self.zero
+        e = getattr(ema_model, "module", ema_model) if ema_model is not None else None
+        full = torch.empty(self.model._flat_n_train, device=self.model._flat.device, dtype=torch.float32)
+        off = 0
+        for lo, hi in self._chunks:
+            full[lo:hi] = self._ema_shard[off:off + hi - lo]
+            off += hi - lo
+        z.wait_gathers()
+        z.all_gather_chunks(full, async_stream=False)
+        if e is not None:
+            e.ensure_flat()
+            e._flat[: full.numel()].copy_(full)
+            e.mark_weights_changed()
+
+    def _gathered_moments(self):
+        """Full-length exp_avg / exp_avg_sq (state_dict of a sharded optimizer)."""
+        outs = []
+        for shard in (self.exp_avg, self.exp_avg_sq):
+            full = torch.zeros(self.model._flat_n_train, device=shard.device, dtype=torch.float32)
+            off = 0
+            for lo, hi in self._chunks:
+                full[lo:hi] = shard[off:off + hi - lo]
+                off += hi - lo
+            self.zero.all_gather_chunks(full, async_stream=False)
+            outs.append(full)
+        return outs
+
     @torch.no_grad()
     def step(self, closure=None):
         assert closure is None
+        if self.zero is not None:
+            return self._step_sharded()
         m = self.model
         m.ensure_flat()
         if m._flat.data_ptr() != self._flat_ptr:
@@ -115,15 +220,32 @@ class FusedAdamW(torch.optim.Optimizer):
         grp["params"] = list(range(len(entries)))
         state = {}
         if self.step_count > 0:
+            # sharded: a collective -- every rank calls state_dict() and gets the full state
+            exp_avg, exp_avg_sq = self._gathered_moments() if self.zero is not None else (self.exp_avg, self.exp_avg_sq)
             for i, (n, p, trainable) in enumerate(entries):
                 if trainable:
                     state[i] = {"step": torch.tensor(float(self.step_count)),
-                                "exp_avg": self._moment_view(self.exp_avg, n, p).contiguous().clone(),
-                                "exp_avg_sq": self._moment_view(self.exp_avg_sq, n, p).contiguous().clone()}
+                                "exp_avg": self._moment_view(exp_avg, n, p).contiguous().clone(),
+                                "exp_avg_sq": self._moment_view(exp_avg_sq, n, p).contiguous().clone()}
         return {"state": state, "param_groups": [grp]}
 
     def load_state_dict(self, sd):
         self.model.ensure_flat()
+        if self.zero is not None:      # load into full-length buffers, then keep this rank's chunks
+            shards = (self.exp_avg, self.exp_avg_sq)
+            n = self.model._flat_n_train
+            self.exp_avg, self.exp_avg_sq = (torch.zeros(n, device=shards[0].device) for _ in range(2))
+            try:
+                self._load_state_dict_full(sd)
+                full = (self.exp_avg, self.exp_avg_sq)
+            finally:
+                self.exp_avg, self.exp_avg_sq = shards
+            for shard, f in zip(shards, full):
+                shard.copy_(torch.cat([f[lo:hi] for lo, hi in self._chunks]))
+            return
+        self._load_state_dict_full(sd)
+
+    def _load_state_dict_full(self, sd):
         flat = sd.get("vaw_flat")                      # round-1 private format
         if flat is not None:
             self.exp_avg.copy_(flat["exp_avg"])

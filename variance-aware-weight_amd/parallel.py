@@ -26,7 +26,8 @@ class DistributedDataParallel(nn.Module):
     gradient buffer before the optimizer reads it.  The sum itself is then taken in bf16 by RCCL: a throughput option, off
     in parity runs."""
 
-    def __init__(self, module, device_ids=None, output_device=None, process_group=None, broadcast=True, bucket_dtype="f32"):
+    def __init__(self, module, device_ids=None, output_device=None, process_group=None, broadcast=True, bucket_dtype="f32",
+                 shard_optimizer=False):
         super().__init__()
         if not isinstance(module, FlatModule):
             raise TypeError("vaw_amd.DistributedDataParallel wraps FlatModule denoisers (e.g. vaw_amd.DiT)")
@@ -51,6 +52,18 @@ class DistributedDataParallel(nn.Module):
             if getattr(module, "_flat_shadow", None) is not None:
                 module._shadow_version = None                            # the bf16 copy must follow the new weights
         self._ranges = self._stage_ranges()
+        # shard_optimizer (ZeRO-1; SURVEY.md §8(e), beyond the reference, off by default): every gradient bucket is REDUCE-SCATTERED
+        # instead of all-reduced -- rank r ends up with the averaged gradients of the r-th of `world` equal chunks of each bucket
+        # --, vaw_amd.FusedAdamW then updates only those chunks (AdamW state and EMA for 1 / world of the parameters per rank) and
+        # all-gathers the updated weights bucket by bucket: half the wire bytes of all-reduce + the optimizer's HBM pass divided
+        # by `world` (at 32 images per GPU the un-sharded AdamW + EMA pass is 13-15 % of the DiT-B/4 step)
+        self.shard_optimizer = bool(shard_optimizer) and self.world > 1
+        self.rank = dist.get_rank(process_group)
+        if self.shard_optimizer:
+            for lo, hi in self.bucket_ranges():
+                if (hi - lo) % (8 * self.world):
+                    raise ValueError(f"shard_optimizer: bucket [{lo}, {hi}) does not split into {self.world} chunks of whole 32-byte groups")
+            module._zero = self
         n_buckets = sum(len(r) if isinstance(r, list) else 1 for r in self._ranges.values())
         self._events = [torch.cuda.Event() for _ in range(n_buckets)] if self._cuda else []   # one per bucket, reused every step
         self._issued = 0
@@ -72,6 +85,18 @@ class DistributedDataParallel(nn.Module):
         if bounds is None:
             return {0: (0, m._flat_n_train)}
         return bounds()
+
+    def bucket_ranges(self):
+        """Every bucket [lo, hi) of the flat gradient buffer, ascending (a partition of [0, n_train))."""
+        out = []
+        for r in self._ranges.values():
+            out += [tuple(x) for x in (r if isinstance(r, list) else [r]) if x[1] > x[0]]
+        return sorted(out)
+
+    def owned_chunks(self, rank=None):
+        """shard_optimizer: the element ranges of the flat buffers this rank keeps optimizer state for (one chunk per bucket)."""
+        r = self.rank if rank is None else rank
+        return [(lo + r * ((hi - lo) // self.world), lo + (r + 1) * ((hi - lo) // self.world)) for lo, hi in self.bucket_ranges()]
 
     def forward(self, *args, **kwargs):
         if self._reserved_now or self._pending or self._issued:
@@ -124,12 +149,28 @@ class DistributedDataParallel(nn.Module):
         else:
             g.copy_(w.float() * scale)
 
+    def _reduce(self, g, buf, op):
+        """The bucket's collective.  -> (work, the f32 gradient range the result belongs to, the buffer it arrives in).
+        all-reduce: the whole bucket; shard_optimizer: reduce-scatter, this rank's chunk of the bucket only."""
+        if not self.shard_optimizer:
+            return dist.all_reduce(buf, op=op, group=self.pg, async_op=True), g, buf
+        c = g.numel() // self.world
+        g_out = g[self.rank * c:(self.rank + 1) * c]
+        if self._backend_avg:          # RCCL: in place (the output is this rank's slot of the input)
+            out = g_out if buf is g else buf[self.rank * c:(self.rank + 1) * c]
+        else:                          # gloo: separate output
+            out = torch.empty(c, device=buf.device, dtype=buf.dtype)
+        work = dist.reduce_scatter_tensor(out, buf, op=op, group=self.pg, async_op=True)
+        return work, g_out, out
+
     def _retire(self, entry):
         """Wait for one bucket's collective and put its result where the optimizer reads it (current stream)."""
         work, g, w = entry
         work.wait()
-        if w is not None:
+        if w is not None and w.dtype == torch.bfloat16:
             self._from_wire(w, g)
+        elif w is not None:                      # f32 result that arrived beside the gradient buffer (gloo reduce-scatter)
+            g.copy_(w if self._backend_avg else w / self.world)
         elif not self._backend_avg:
             g.div_(self.world)
 
@@ -159,13 +200,37 @@ class DistributedDataParallel(nn.Module):
                         self._retire(self._pending.pop(0))
                     self._comm.wait_event(ev)
                     buf = self._to_wire(g, lo, hi) if self._wire is not None else g
-                    work = dist.all_reduce(buf, op=op, group=self.pg, async_op=True)
+                    work, g_out, buf = self._reduce(g, buf, op)
             else:
                 buf = self._to_wire(g, lo, hi) if self._wire is not None else g
-                work = dist.all_reduce(buf, op=op, group=self.pg, async_op=True)
-            self._pending.append((work, g, buf if self._wire is not None else None))
+                work, g_out, buf = self._reduce(g, buf, op)
+            self._pending.append((work, g_out, buf if (self._wire is not None or buf is not g_out) else None))
         if stage == 0:
             self.finish()
+
+    def all_gather_chunks(self, flat, async_stream=True):
+        """shard_optimizer: every rank has rewritten its chunk of each bucket of `flat` (a full-length flat buffer: bf16 shadow
+        or f32 parameters); all-gather the buckets so that every rank holds all of it again.  On the GPU the collectives run on
+        the side stream behind the current one; call wait_gathers() before the buffer is read."""
+        def gather():
+            for lo, hi in self.bucket_ranges():
+                c = (hi - lo) // self.world
+                src = flat[lo + self.rank * c: lo + (self.rank + 1) * c]
+                if not self._backend_avg:
+                    src = src.clone()                 # gloo: no in-place form
+                dist.all_gather_into_tensor(flat[lo:hi], src, group=self.pg)
+        if self._cuda and async_stream:
+            self._comm.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._comm):
+                gather()
+            self._gathers_pending = True
+        else:
+            gather()
+
+    def wait_gathers(self):
+        if getattr(self, "_gathers_pending", False):
+            torch.cuda.current_stream().wait_stream(self._comm)
+            self._gathers_pending = False
 
     def finish(self):
         """Retire every outstanding bucket and make the compute stream wait for the side stream (end of backward)."""

@@ -70,7 +70,12 @@ class Trainer:
         if hasattr(inner, "host_dropout_rng"):
             inner.host_dropout_rng = bool(getattr(args, "cpu_rng", False))      # dropout masks from the CPU stream in parity runs
         self._fused = isinstance(optimizer, FusedAdamW)
-        if self._fused and ema_model is not None and dist_util.is_main_process():
+        self._zero = self._fused and getattr(optimizer, "zero", None) is not None
+        if self._zero:
+            # sharded optimizer: every rank averages its own chunks; rank 0's ema_model receives them on consolidate()
+            if getattr(args, "ema_decay", None) is not None:
+                optimizer.attach_ema_sharded(args.ema_decay, ema_model)
+        elif self._fused and ema_model is not None and dist_util.is_main_process():
             optimizer.attach_ema(ema_model, args.ema_decay)
         self.last_mse = None
         self._cpu_rng = bool(getattr(args, "cpu_rng", False))
@@ -130,7 +135,17 @@ class Trainer:
             else:
                 nn.utils.clip_grad_norm_(self.model.parameters(), self.args.grad_clip)
 
+    def consolidate(self):
+        """Sharded optimizer (ZeRO-1): gather the f32 master weights on every rank and the sharded EMA into rank 0's ema_model
+        -- call on EVERY rank before sampling / evaluating / saving.  No-op otherwise."""
+        if self._zero:
+            self.optimizer.consolidate()
+            if getattr(self.optimizer, "_ema_shard", None) is not None:
+                self.optimizer.consolidate_ema(self.ema_model)
+
     def _update_ema(self):
+        if self._zero:
+            return            # done inside the sharded update, on every rank
         if dist_util.is_main_process() and self.ema_model is not None:
             if self._fused and getattr(self.optimizer, "ema_done_in_step", False):
                 return

@@ -54,11 +54,18 @@ def _strip_module(sd):
 def save_checkpoint(args, step, model, optimizer, ema_model=None, scheduler=None):
     """{'model','optimizer','step','ema_model'} with the reference's state_dict keys (a wrapped model saves
     'module.'-prefixed keys, as torch DDP does).  'scheduler' is an addition the reference forgets."""
+    zero = getattr(optimizer, "zero", None)
+    opt_state = None
+    if zero is not None:       # sharded optimizer (ZeRO-1): collectives -- EVERY rank calls save_checkpoint; rank 0 writes the file
+        optimizer.consolidate()
+        if getattr(optimizer, "_ema_shard", None) is not None:
+            optimizer.consolidate_ema(ema_model if dist_util.is_main_process() else None)
+        opt_state = optimizer.state_dict()
     if not dist_util.is_main_process():
         return None
     d = os.path.join(args.logdir, "checkpoint")
     os.makedirs(d, exist_ok=True)
-    state = {"model": model.state_dict(), "optimizer": optimizer.state_dict(), "step": step}
+    state = {"model": model.state_dict(), "optimizer": opt_state if opt_state is not None else optimizer.state_dict(), "step": step}
     if ema_model is not None:
         state["ema_model"] = ema_model.state_dict()
     if scheduler is not None:
