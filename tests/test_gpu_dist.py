@@ -133,10 +133,11 @@ def test_two_rank_step_reproduces_single_rank_step(kind, variant):
     gd = (res[0][2] - grads1).abs()
     if variant == "bf16_buckets":       # each rank's share and the wire sum are rounded to 8 significant bits
         tol = 2.0 ** -7 * grads1.abs() + 2.0 ** -6 * rms
-    else:                               # order of summation only: 1e-6 of the tensor's rms (+ f32 rounding of large elements) ...
-        tol = 1e-6 * rms + 2e-6 * grads1.abs()
-    # ... for all but a handful of elements whose sum cancels (f32 rounding scales with sum |terms|, not with the result:
-    # measured 6 of 1.1 M elements of the DiT, the worst 1.7e-5 of the rms); those stay within 1e-4 of the rms
+    else:                               # order of summation only: 1e-5 of the tensor's rms (+ f32 rounding of large elements) ...
+        tol = 1e-5 * rms + 2e-6 * grads1.abs()
+    # ... for all but a handful of elements whose sum cancels (f32 rounding scales with sum |terms|, not with the result.
+    # Measured against 1e-6 of the rms: 6 of 1.1 M elements of the DiT beyond it, the worst 1.7e-5 of the rms; 467 of 0.8 M of
+    # the UNet, the worst 1.1e-5); everything stays within 1e-4 of the rms
     beyond = gd > tol
     assert float(beyond.float().mean()) < 1e-4, (float(gd.max()), rms, int(beyond.sum()))
     if variant != "bf16_buckets":

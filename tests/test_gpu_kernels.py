@@ -189,7 +189,7 @@ def _mk(M, N, K, a_k, b_k, dtype, seed, ints=False):
 
 
 @pytest.mark.parametrize("a_k,b_k", [(True, True), (True, False), (False, False), (False, True)])
-@pytest.mark.parametrize("mode", ["f32", "bf16_generic", "bf16_fast", "bf16_big", "bf16_p8_256", "bf16_p8_192", "bf16_sm64", "bf16_sm128"])
+@pytest.mark.parametrize("mode", ["f32", "bf16_generic", "bf16_fast", "bf16_big", "bf16_p8_256", "bf16_p8_192", "bf16_sm64", "bf16_sm128", "bf16_sm128x128"])
 def test_gemm_layouts_exact_integers(a_k, b_k, mode):
     """Small-integer operands are exact in bf16 and f32: any fragment-layout or swizzle error shows as a
     wrong integer, with asymmetric data on both sides (a symmetric operand would hide a transpose)."""
@@ -212,12 +212,12 @@ def test_gemm_layouts_exact_integers(a_k, b_k, mode):
         shapes = [(256, 384, 192), (200, 72, 128), (136, 200, 64), (520, 264, 256), (304, 776, 320), (64, 64, 64), (2048, 768, 768),
                   (1000, 3072, 128), (4096, 128, 3072)]
     lib().vaw_debug_force_generic_gemm(1 if mode == "bf16_generic" else 0)
-    lib().vaw_debug_gemm_tile({"bf16_fast": 0, "bf16_big": 1, "bf16_p8_256": 2, "bf16_p8_192": 3, "bf16_sm64": 6, "bf16_sm128": 7}.get(mode, -1))
+    lib().vaw_debug_gemm_tile({"bf16_fast": 0, "bf16_big": 1, "bf16_p8_256": 2, "bf16_p8_192": 3, "bf16_sm64": 6, "bf16_sm128": 7, "bf16_sm128x128": 8}.get(mode, -1))
     try:
         for (M, N, K) in shapes:
             A, B = _mk(M, N, K, a_k, b_k, dtype, seed=M + N + K, ints=True)
             Ad, Bd = A.to(DEV), B.to(DEV)
-            if mode in ("bf16_fast", "bf16_big", "bf16_p8_256", "bf16_p8_192", "bf16_sm64", "bf16_sm128"):
+            if mode in ("bf16_fast", "bf16_big", "bf16_p8_256", "bf16_p8_192", "bf16_sm64", "bf16_sm128", "bf16_sm128x128"):
                 assert lib().vaw_gemm_uses_bf16_mfma(BF16, M, N, K, ptr(Ad), Ad.shape[1], ptr(Bd), Bd.shape[1]) == 1
             got = ops.gemm_t(Ad, Bd, a_kmajor=a_k, b_kmajor=b_k, out_dtype=torch.float32).cpu()
             ref = _gemm_ref(A, B, a_k, b_k)
@@ -247,7 +247,7 @@ def test_gemm_bf16_fast_random_and_large_k(a_k, b_k, tile):
 
 
 @pytest.mark.parametrize("dtype,tile", [(torch.float32, -1), (torch.bfloat16, 0), (torch.bfloat16, 1), (torch.bfloat16, 2),
-                                        (torch.bfloat16, 3), (torch.bfloat16, 5)])
+                                        (torch.bfloat16, 3), (torch.bfloat16, 5), (torch.bfloat16, 8)])
 def test_gemm_epilogues(dtype, tile):
     lib().vaw_debug_gemm_tile(tile)
     try:

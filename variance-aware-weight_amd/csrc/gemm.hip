@@ -726,8 +726,8 @@ struct P8Plan {
     int ntw, split, grid;
 };
 P8Plan vaw_p8_plan(int64_t M, int64_t N, int64_t K, bool plain_f32, bool want_colsum, int64_t ws_floats, int force);
-void vaw_sm_launch(int nb, int stages, int b_kmajor, int64_t M, int64_t N, int64_t K, const bf16_t* a, int64_t lda, const bf16_t* b,
-                   int64_t ldb, const EpiDev& e, hipStream_t s);      // gemm_sm.hip
+void vaw_sm_launch(int mb, int nb, int stages, int b_kmajor, int64_t M, int64_t N, int64_t K, const bf16_t* a, int64_t lda,
+                   const bf16_t* b, int64_t ldb, const EpiDev& e, hipStream_t s);      // gemm_sm.hip
 bool vaw_p8_conv(int mode, const bf16_t* act, const bf16_t* act2, const bf16_t* w, void* out, int B, int H, int W, int Ci, int Co,
                  EpiDev e, float* workspace, int64_t workspace_floats, int force, hipStream_t s, float* bias_grad, float bias_beta,
                  int* bias_done);
@@ -839,9 +839,10 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
         // small M (strong-scaling batches: a few thousand token rows): 64-row tiles with a deep LDS-DMA ring (gemm_sm.hip)
         // -- the launches the 128- and 256-row kernels can only give a quarter of the chip, one exposed memory latency per K step
         {
-            static int sm_max_m = -1, sm_nb = 0, sm_st = 0;
+            static int sm_max_m = -1, sm_nb = 0, sm_st = 0, sm_wide_m = 0;
             if (sm_max_m < 0) {
                 const char* v = getenv("VAW_SM_MAX_M"); sm_max_m = v ? atoi(v) : 4096;
+                v = getenv("VAW_SM_WIDE_M"); sm_wide_m = v ? atoi(v) : 0;        // 128 x 128 tiles for the wide launches up to this M (0 = off)
                 v = getenv("VAW_SM_NB"); sm_nb = v ? atoi(v) : 0;
                 v = getenv("VAW_SM_STAGES"); sm_st = v ? atoi(v) : 0;
             }
@@ -851,21 +852,28 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
             // 256-row kernels on the launches that give those less than one workgroup per CU (the 768-wide layers up to 4096
             // rows: 16.0 -> 11.3, 39.4 -> 24.4, 30.2 -> 17.2, 34.2 -> 21.1 us at 2048 rows), slower on the wide ones (its 64-row
             // tiles move twice the operand bytes per MFMA): taken only below one 128 x 128 tile per CU
-            const bool sm_few_tiles = ((M + 127) / 128) * ((N + 127) / 128) < 256;
-            const bool sm_forced = g_gemm_tile >= 5 && g_gemm_tile <= 7;     // vaw_debug_gemm_tile: 5 always, 6 / 7 always with 64 / 128-column tiles
-            if (a_kmajor && ((M <= sm_max_m && sm_few_tiles && g_gemm_tile < 0) || sm_forced) && !rowsum_out && cs_room && N % 8 == 0) {
+            // (and only for the K of the blocks' Linear layers: the long-K launches -- adaLN's input gradient, K = 6 L D -- keep
+            //  their split-K path: 161 us on 48 workgroups here against 40 + 38 us split)
+            const bool sm_few_tiles = ((M + 127) / 128) * ((N + 127) / 128) < 256 && K <= 4096;
+            // wide layers at small M (fc1, fc2's GELU' input gradient, qkv at 2048-4096 rows: 128-288 items of the larger kernels):
+            // 128 x 128 tiles on the same ring
+            const bool sm_wide = !sm_few_tiles && M <= sm_wide_m && K <= 4096 && ((M + 127) / 128) * ((N + 127) / 128) <= 1024;
+            const bool sm_forced = g_gemm_tile >= 5 && g_gemm_tile <= 8;     // vaw_debug_gemm_tile: 5 always, 6 / 7 / 8 always with 64 x 64 / 64 x 128 / 128 x 128 tiles
+            if (a_kmajor && ((M <= sm_max_m && (sm_few_tiles || sm_wide) && g_gemm_tile < 0) || sm_forced) && !rowsum_out && cs_room && N % 8 == 0) {
                 // 64 x 128 tiles when they still give every CU a workgroup, 64 x 64 otherwise; ring depth by the LDS it leaves:
                 // 3 stages = two (64 x 128) or three (64 x 64) workgroups per CU for multi-round launches, 4 for single rounds
                 const int64_t t2 = rows64 * ((N + 127) / 128);
-                const int nb = g_gemm_tile == 6 ? 1 : g_gemm_tile == 7 ? 2 : sm_nb ? sm_nb : (t2 >= 384 ? 2 : 1);
-                const int64_t tiles = rows64 * ((N + 64 * nb - 1) / (64 * nb));
+                const int mb = g_gemm_tile == 8 ? 2 : (g_gemm_tile >= 5 ? 1 : (sm_wide && !sm_few_tiles) ? 2 : 1);
+                const int nb = mb == 2 ? 2 : g_gemm_tile == 6 ? 1 : g_gemm_tile == 7 ? 2 : sm_nb ? sm_nb : (t2 >= 384 ? 2 : 1);
+                const int64_t rows_t = (M + 64 * mb - 1) / (64 * mb);
+                const int64_t tiles = rows_t * ((N + 64 * nb - 1) / (64 * nb));
                 const int stages = sm_st ? sm_st : (tiles > 256 ? 3 : 4);
                 EpiDev es = e;
-                CS_CAP_CHECK(rows64);
+                CS_CAP_CHECK(rows_t);
                 if (colsum_out) es.colpart = colsum_dst;
-                vaw_sm_launch(nb, stages, b_kmajor, M, N, K, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, es, s);
+                vaw_sm_launch(mb, nb, stages, b_kmajor, M, N, K, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, es, s);
                 VAW_CHECK_LAUNCH("gemm_sm");
-                if (colsum_out) return fold_colsum(rows64);
+                if (colsum_out) return fold_colsum(rows_t);
                 return VAW_OK;
             }
         }

@@ -15,18 +15,22 @@
 // grouped persistent launch (K = tokens is long there and all layers together fill the chip).
 #include "gemm_p8_kernel.h"
 
-template <int NB> struct SmCfg {
+template <int NB, int MB = 1> struct SmCfg {
+    static constexpr int BM = 64 * MB;
     static constexpr int BN = 64 * NB;
-    static constexpr int stage_bytes = (1 + NB) * P8_PART;     // A part (64 rows) + NB B parts
-    static constexpr int pieces = 2 * (1 + NB);                // DMA instructions per wave and K tile
+    static constexpr int stage_bytes = (MB + NB) * P8_PART;    // MB A parts (64 rows each) + NB B parts
+    static constexpr int pieces = 2 * (MB + NB);               // DMA instructions per wave and K tile
 };
 
-template <bool BKM, int NB, int STAGES>
+// MB = 2 (128-row tiles, wave tile 64 x 32 NB): the wide launches of a small batch (fc1 / fc2's GELU' at 2048-4096 rows: 128 items
+// of the persistent kernel, half the chip) as 128 x 128 tiles with the same deep ring.
+template <bool BKM, int NB, int STAGES, int MB = 1>
 __global__ void __launch_bounds__(256)
 gemm_sm_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb, int nk, int tiles_m, int tiles_n,
                EpiDev e) {
-    using Cfg = SmCfg<NB>;
-    constexpr int NT = 2 * NB;                                  // 16-column MFMA tiles per wave (wave tile 32 x 32 NB)
+    using Cfg = SmCfg<NB, MB>;
+    constexpr int NT = 2 * NB;                                  // 16-column MFMA tiles per wave (wave tile 32 MB x 32 NB)
+    constexpr int MT = 2 * MB;                                  // 16-row MFMA tiles per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [STAGES][A part | B parts]
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -39,17 +43,18 @@ gemm_sm_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
         tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
     }
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-    const int64_t m0 = (int64_t)tm * 64, n0 = (int64_t)tn * Cfg::BN;
-    const int mvalid = e.M - m0 < 64 ? (int)(e.M - m0) : 64;
+    const int64_t m0 = (int64_t)tm * Cfg::BM, n0 = (int64_t)tn * Cfg::BN;
+    const int mvalid = e.M - m0 < Cfg::BM ? (int)(e.M - m0) : Cfg::BM;
     const int nvalid = e.N - n0 < Cfg::BN ? (int)(e.N - n0) : Cfg::BN;
 
     // ---- DMA stream: per-lane byte offsets fixed for the tile, a scalar offset walks K ----
     const __amdgpu_buffer_rsrc_t rs_a = epi_rsrc(A + m0 * lda);
     const __amdgpu_buffer_rsrc_t rs_b = epi_rsrc(BKM ? B + n0 * ldb : B + n0);
-    unsigned off_a[2], off_b[NB][2];
+    unsigned off_a[MB][2], off_b[NB][2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        off_a[h] = p8_src_off<true>(false, 0, wid + 4 * h, lane, lda, mvalid);
+#pragma unroll
+        for (int p = 0; p < MB; ++p) off_a[p][h] = p8_src_off<true>(false, p, wid + 4 * h, lane, lda, mvalid);
 #pragma unroll
         for (int p = 0; p < NB; ++p) off_b[p][h] = p8_src_off<BKM>(false, p, wid + 4 * h, lane, ldb, nvalid);
     }
@@ -60,9 +65,10 @@ gemm_sm_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
         char* dst = smem + (iss % STAGES) * Cfg::stage_bytes;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            p8_dma16(rs_a, dst + (wid + 4 * h) * 1024, off_a[h], so_a);
 #pragma unroll
-            for (int p = 0; p < NB; ++p) p8_dma16(rs_b, dst + (1 + p) * P8_PART + (wid + 4 * h) * 1024, off_b[p][h], so_b);
+            for (int p = 0; p < MB; ++p) p8_dma16(rs_a, dst + p * P8_PART + (wid + 4 * h) * 1024, off_a[p][h], so_a);
+#pragma unroll
+            for (int p = 0; p < NB; ++p) p8_dma16(rs_b, dst + (MB + p) * P8_PART + (wid + 4 * h) * 1024, off_b[p][h], so_b);
         }
         so_a += step_a;
         so_b += step_b;
@@ -72,9 +78,9 @@ gemm_sm_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
     for (int s = 0; s < STAGES - 1; ++s)
         if (iss < nk) issue();
 
-    f32x4 acc[2][NT];
+    f32x4 acc[MT][NT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
 
@@ -85,16 +91,19 @@ gemm_sm_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
         __builtin_amdgcn_s_barrier();          // every wave's pieces of tile kt are in; everyone has finished reading tile kt - 1
         if (iss < nk) issue();                 // ... so its stage takes tile kt + STAGES - 1
         const char* st = smem + (kt % STAGES) * Cfg::stage_bytes;
-        bf16x8 af[2][2], bfr[2][NT];
+        bf16x8 af[2][MT], bfr[2][NT];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int n = wc * (16 * NT) + 16 * j;
-                bfr[s][j] = p8_frag<BKM>(st + (1 + (n >> 6)) * P8_PART, n & 63, s, lane);
+                bfr[s][j] = p8_frag<BKM>(st + (MB + (n >> 6)) * P8_PART, n & 63, s, lane);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[s][i] = p8_frag<true>(st, 32 * wr + 16 * i, s, lane);
+            for (int i = 0; i < MT; ++i) {
+                const int m = wr * (16 * MT) + 16 * i;
+                af[s][i] = p8_frag<true>(st + (m >> 6) * P8_PART, m & 63, s, lane);
+            }
         }
         if (!BKM) {        // transposing reads are inline asm: wait for them by hand (rule 18)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -103,7 +112,7 @@ gemm_sm_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[s][j], af[s][i], acc[i][j], 0, 0, 0);
     }
@@ -119,15 +128,15 @@ gemm_sm_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
         if (col >= nvalid) continue;                                    // N % 8 == 0: four columns are in or out together
         const f32x4 bj = e.bias ? load4(e.bias + n0 + col) : f32x4{0, 0, 0, 0};
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = 32 * wr + 16 * i + lr;
+        for (int i = 0; i < MT; ++i) {
+            const int row = wr * (16 * MT) + 16 * i + lr;
             if (row >= mvalid) continue;
             f32x4 v = acc[i][j];
             epi_row4(e, (unsigned)(m0 + row), n0 + col, v, bj);          // v comes back as stored
             cs[j] += v;
         }
     }
-    if (e.colpart) {       // column sums of this 64-row tile: 16 rows by shuffles, then the two wave rows through LDS, fixed order
+    if (e.colpart) {       // column sums of this tile (one partial row per tile row): 16 rows by shuffles, then the two wave rows through LDS, fixed order
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();                                                 // the ring is dead: reuse it
         float* sc = reinterpret_cast<float*>(smem);                      // [2 wave rows][BN]
@@ -146,24 +155,25 @@ gemm_sm_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
     }
 }
 
-template <bool BKM, int NB, int STAGES>
+template <bool BKM, int NB, int STAGES, int MB>
 static void sm_launch_one(const bf16_t* a, int64_t lda, const bf16_t* b, int64_t ldb, int nk, int tiles_m, int tiles_n, const EpiDev& e,
                           hipStream_t s) {
     static bool attr_done = false;
-    const int lds = STAGES * SmCfg<NB>::stage_bytes;
+    const int lds = STAGES * SmCfg<NB, MB>::stage_bytes;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gemm_sm_kernel<BKM, NB, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm_sm_kernel<BKM, NB, STAGES, MB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
-    gemm_sm_kernel<BKM, NB, STAGES><<<tiles_m * tiles_n, 256, lds, s>>>(a, lda, b, ldb, nk, tiles_m, tiles_n, e);
+    gemm_sm_kernel<BKM, NB, STAGES, MB><<<tiles_m * tiles_n, 256, lds, s>>>(a, lda, b, ldb, nk, tiles_m, tiles_n, e);
 }
 
-// nb = 1 | 2 (tile 64 x 64 | 64 x 128), stages = 3 | 4.  A k-major; b_kmajor selects the B layout.
-void vaw_sm_launch(int nb, int stages, int b_kmajor, int64_t M, int64_t N, int64_t K, const bf16_t* a, int64_t lda, const bf16_t* b,
-                   int64_t ldb, const EpiDev& e, hipStream_t s) {
-    const int tiles_m = (int)((M + 63) / 64), tiles_n = (int)((N + 64 * nb - 1) / (64 * nb)), nk = (int)(K / 64);
-#define SM_GO(BKv, NBv, STv) sm_launch_one<BKv, NBv, STv>(a, lda, b, ldb, nk, tiles_m, tiles_n, e, s)
-#define SM_GO_B(NBv, STv) do { if (b_kmajor) SM_GO(true, NBv, STv); else SM_GO(false, NBv, STv); } while (0)
-    if (nb == 1) { if (stages == 3) SM_GO_B(1, 3); else SM_GO_B(1, 4); }
-    else { if (stages == 3) SM_GO_B(2, 3); else SM_GO_B(2, 4); }
+// mb x nb = tile (64 mb) x (64 nb): 1 x 1, 1 x 2 or 2 x 2; stages = 3 | 4.  A k-major; b_kmajor selects the B layout.
+void vaw_sm_launch(int mb, int nb, int stages, int b_kmajor, int64_t M, int64_t N, int64_t K, const bf16_t* a, int64_t lda,
+                   const bf16_t* b, int64_t ldb, const EpiDev& e, hipStream_t s) {
+    const int tiles_m = (int)((M + 64 * mb - 1) / (64 * mb)), tiles_n = (int)((N + 64 * nb - 1) / (64 * nb)), nk = (int)(K / 64);
+#define SM_GO(BKv, NBv, STv, MBv) sm_launch_one<BKv, NBv, STv, MBv>(a, lda, b, ldb, nk, tiles_m, tiles_n, e, s)
+#define SM_GO_B(NBv, STv, MBv) do { if (b_kmajor) SM_GO(true, NBv, STv, MBv); else SM_GO(false, NBv, STv, MBv); } while (0)
+    if (mb == 2) { if (stages == 3) SM_GO_B(2, 3, 2); else SM_GO_B(2, 4, 2); }
+    else if (nb == 1) { if (stages == 3) SM_GO_B(1, 3, 1); else SM_GO_B(1, 4, 1); }
+    else { if (stages == 3) SM_GO_B(2, 3, 1); else SM_GO_B(2, 4, 1); }
 }
