@@ -63,6 +63,39 @@ __device__ __forceinline__ void stage_block(const bf16_t* __restrict__ g, int64_
     }
 }
 
+// Register-staged variant of stage_block (cdna_hip_programming.md T14, "async-STAGE split"): blk_prefetch ISSUES the global
+// loads of a 64-row block into registers (3 x 16 bytes per thread for the 96-wide images) and returns at once; blk_commit writes
+// them into the LDS image later, after the barrier that frees it.  The kernels that stream key / query blocks issue the loads
+// of block i + 1 before they compute on block i: with one image per operand (3 workgroups per CU stay resident) every block
+// used to cost a full memory latency behind DMA_WAIT_SYNC -- a workgroup of the DiT-XL/2 forward was resident for 25 us to do
+// 1.5 us of MFMAs.  Channels hd .. HD-1 are written as zeros; the pad chunk of the 96-wide pitch is never read.
+template <int HD> struct BlkRegs {
+    static constexpr int N = (64 * (HD / 8) + 255) / 256;          // 16-byte chunks per thread
+    bf16x8 v[N];
+};
+template <int HD>
+__device__ __forceinline__ void blk_prefetch(BlkRegs<HD>& r, const bf16_t* __restrict__ g, int64_t stride_t, int hd) {
+    constexpr int CPR = HD / 8;
+#pragma unroll
+    for (int i = 0; i < BlkRegs<HD>::N; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        const int row = idx / CPR, chunk = idx - row * CPR;
+        const bool live = (64 * CPR % 256 == 0 || idx < 64 * CPR) && chunk * 8 < hd;
+        r.v[i] = live ? *reinterpret_cast<const bf16x8*>(g + (int64_t)row * stride_t + chunk * 8)
+                      : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+}
+template <int HD>
+__device__ __forceinline__ void blk_commit(const BlkRegs<HD>& r, char* img) {
+    constexpr int CPR = HD / 8;
+#pragma unroll
+    for (int i = 0; i < BlkRegs<HD>::N; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        const int row = idx / CPR, chunk = idx - row * CPR;
+        if (64 * CPR % 256 == 0 || idx < 64 * CPR) *reinterpret_cast<bf16x8*>(img + img_off<HD>(row, chunk)) = r.v[i];
+    }
+}
+
 // 16 rows x 32 k (k = channel), rows r0.., k-step s: the natural A (or B) fragment
 template <int HD>
 __device__ __forceinline__ bf16x8 frag_rows(const char* img, int r0, int s, int lane) {
@@ -157,6 +190,7 @@ attn_fwd_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __rest
     bf16x8 qf[QG][KS];
     f32x4 ot[QG][DT];
     float m[QG], l[QG];
+    const float c2 = a.scale * 1.4426950408889634f;              // scores to the base-2 exponent domain
 #pragma unroll
     for (int u = 0; u < QG; ++u) {
         m[u] = -INFINITY;
@@ -164,9 +198,13 @@ attn_fwd_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __rest
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) ot[u][dt] = f32x4{0, 0, 0, 0};
     }
+    BlkRegs<HD> kr, vr;                                           // !DB: the NEXT key block, in flight in registers
     if (DB) {
         stage_block<HD>(k + base, a.q_st, kv, wid, lane, a.hd);
         stage_block<HD>(v + base, a.q_st, kv + IMG, wid, lane, a.hd);
+    } else {
+        blk_prefetch<HD>(kr, k + base, a.q_st, a.hd);
+        blk_prefetch<HD>(vr, v + base, a.q_st, a.hd);
     }
     for (int kb = 0, buf = 0; kb < a.T; kb += 64, buf ^= (DB ? 1 : 0)) {
         const char* kimg = kv + buf * 2 * IMG;
@@ -179,9 +217,13 @@ attn_fwd_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __rest
             }
         } else {
             __syncthreads();                                 // previous block's reads of the K / V images are done
-            stage_block<HD>(k + base + (int64_t)kb * a.q_st, a.q_st, kv, wid, lane, a.hd);
-            stage_block<HD>(v + base + (int64_t)kb * a.q_st, a.q_st, kv + IMG, wid, lane, a.hd);
-            DMA_WAIT_SYNC();
+            blk_commit<HD>(kr, kv);
+            blk_commit<HD>(vr, kv + IMG);
+            DMA_WAIT_SYNC();                                 // (the Q images' LDS-DMA, first block; then a plain barrier)
+            if (kb + 64 < a.T) {                             // the next block's loads fly while this one is computed
+                blk_prefetch<HD>(kr, k + base + (int64_t)(kb + 64) * a.q_st, a.q_st, a.hd);
+                blk_prefetch<HD>(vr, v + base + (int64_t)(kb + 64) * a.q_st, a.q_st, a.hd);
+            }
         }
         if (kb == 0) {
 #pragma unroll
@@ -213,20 +255,26 @@ attn_fwd_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __rest
         }
 #pragma unroll
         for (int u = 0; u < QG; ++u) {
-            const float m_new = fmaxf(m[u], group_max(bm[u]) * a.scale);
-            const float alpha = __expf(m[u] - m_new);            // first block: exp(-inf) = 0 on l = 0, ot = 0
+            // base-2 softmax: p = exp2(s c - m), c = scale log2(e) -- one fma + v_exp_f32 per score.  The running maximum only
+            // moves when the block's maximum exceeds it by more than 2^6 (cdna_hip_programming.md T13: p stays <= 64, exact in
+            // f32 and at bf16's relative precision); when no query of the wave moved it, the 4 DT-register rescale of O is skipped
+            float m_new = fmaxf(m[u], group_max(bm[u]) * c2);
+            if (m_new - m[u] <= 6.f) m_new = m[u];               // (first block: m = -inf -> always taken over)
+            const float alpha = __builtin_amdgcn_exp2f(m[u] - m_new);   // exp2(-inf) = 0 on l = 0, ot = 0; 1 when the maximum stayed
             float ps = 0.f;
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    st[u][jt][r] = __expf(st[u][jt][r] * a.scale - m_new);
+                    st[u][jt][r] = __builtin_amdgcn_exp2f(st[u][jt][r] * c2 - m_new);
                     ps += st[u][jt][r];
                 }
             l[u] = l[u] * alpha + group_sum(ps);
             m[u] = m_new;
+            if (!__all(alpha == 1.f)) {
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) ot[u][dt] *= alpha;
+                for (int dt = 0; dt < DT; ++dt) ot[u][dt] *= alpha;
+            }
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -249,7 +297,7 @@ attn_fwd_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __rest
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
             if (16 * dt + 4 * (lane >> 4) < a.hd) store4(orow + 16 * dt, ot[u][dt] * inv);
-        if ((lane >> 4) == 0) lse[(int64_t)bh * a.T + qi] = m[u] + __logf(l[u]);
+        if ((lane >> 4) == 0) lse[(int64_t)bh * a.T + qi] = m[u] * 0.6931471805599453f + __logf(l[u]);   // back to the natural log
     }
 }
 
@@ -269,6 +317,7 @@ attn_bwd_dq_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __r
     char* gimg = qimg + G * IMG;             // G images
     char* kimg = gimg + G * IMG;
     char* vimg = kimg + IMG;
+    const float c2 = a.scale * 1.4426950408889634f;              // scores to the base-2 exponent domain
     const int lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
@@ -295,7 +344,7 @@ attn_bwd_dq_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __r
             t += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
         }
         dl[u] = group_sum(t);
-        li_lse[u] = lse[(int64_t)bh * a.T + qi[u]];
+        li_lse[u] = lse[(int64_t)bh * a.T + qi[u]] * 1.4426950408889634f;      // base-2 domain: p = exp2(s c2 - lse2), one fma + v_exp_f32
         if (g == 0) delta_out[(int64_t)bh * a.T + qi[u]] = dl[u];
     }
     bf16x8 qf[G][KS], gf[G][KS];
@@ -304,11 +353,18 @@ attn_bwd_dq_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __r
     for (int u = 0; u < G; ++u)
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) acc[u][dt] = f32x4{0, 0, 0, 0};
+    BlkRegs<HD> kr, vr;                                           // the NEXT key block, in flight in registers
+    blk_prefetch<HD>(kr, k + base, a.q_st, a.hd);
+    blk_prefetch<HD>(vr, v + base, a.q_st, a.hd);
     for (int kb = 0; kb < a.T; kb += 64) {
         __syncthreads();
-        stage_block<HD>(k + base + (int64_t)kb * a.q_st, a.q_st, kimg, wid, lane, a.hd);
-        stage_block<HD>(v + base + (int64_t)kb * a.q_st, a.q_st, vimg, wid, lane, a.hd);
-        DMA_WAIT_SYNC();
+        blk_commit<HD>(kr, kimg);
+        blk_commit<HD>(vr, vimg);
+        DMA_WAIT_SYNC();                                     // (the Q / dO images' LDS-DMA, first block; then a plain barrier)
+        if (kb + 64 < a.T) {
+            blk_prefetch<HD>(kr, k + base + (int64_t)(kb + 64) * a.q_st, a.q_st, a.hd);
+            blk_prefetch<HD>(vr, v + base + (int64_t)(kb + 64) * a.q_st, a.q_st, a.hd);
+        }
         if (kb == 0) {
 #pragma unroll
             for (int u = 0; u < G; ++u)
@@ -336,7 +392,7 @@ attn_bwd_dq_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __r
 #pragma unroll
             for (int u = 0; u < G; ++u)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ds[u][jt][r] = a.scale * __expf(c[u][r] * a.scale - li_lse[u]) * (d[u][r] - dl[u]);
+                for (int r = 0; r < 4; ++r) ds[u][jt][r] = a.scale * __builtin_amdgcn_exp2f(c[u][r] * c2 - li_lse[u]) * (d[u][r] - dl[u]);
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -390,6 +446,7 @@ attn_bwd_dkv_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __
     char* gimg = qimg + IMG;
     float* lse_s = reinterpret_cast<float*>(gimg + IMG);
     float* del_s = lse_s + 64;
+    const float c2 = a.scale * 1.4426950408889634f;
     const int lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
@@ -406,15 +463,31 @@ attn_bwd_dkv_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __
     for (int u = 0; u < G; ++u)
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) av[u][dt] = ak[u][dt] = f32x4{0, 0, 0, 0};
+    BlkRegs<HD> qr, gr;                                           // the NEXT query block (Q, dO, lse, delta), in flight in registers
+    float lse_r = 0.f, del_r = 0.f;
+    blk_prefetch<HD>(qr, q + base, a.q_st, a.hd);
+    blk_prefetch<HD>(gr, d_o + obase, a.o_st, a.hd);
+    if (threadIdx.x < 64) {
+        lse_r = lse[(int64_t)bh * a.T + threadIdx.x];
+        del_r = delta[(int64_t)bh * a.T + threadIdx.x];
+    }
     for (int ib = 0; ib < a.T; ib += 64) {
         __syncthreads();
-        stage_block<HD>(q + base + (int64_t)ib * a.q_st, a.q_st, qimg, wid, lane, a.hd);
-        stage_block<HD>(d_o + obase + (int64_t)ib * a.o_st, a.o_st, gimg, wid, lane, a.hd);
+        blk_commit<HD>(qr, qimg);
+        blk_commit<HD>(gr, gimg);
         if (threadIdx.x < 64) {
-            lse_s[threadIdx.x] = lse[(int64_t)bh * a.T + ib + threadIdx.x];
-            del_s[threadIdx.x] = delta[(int64_t)bh * a.T + ib + threadIdx.x];
+            lse_s[threadIdx.x] = lse_r * 1.4426950408889634f;                 // base-2 domain
+            del_s[threadIdx.x] = del_r;
         }
-        DMA_WAIT_SYNC();
+        DMA_WAIT_SYNC();                                     // (the K / V images' LDS-DMA, first block; then a plain barrier)
+        if (ib + 64 < a.T) {
+            blk_prefetch<HD>(qr, q + base + (int64_t)(ib + 64) * a.q_st, a.q_st, a.hd);
+            blk_prefetch<HD>(gr, d_o + obase + (int64_t)(ib + 64) * a.o_st, a.o_st, a.hd);
+            if (threadIdx.x < 64) {
+                lse_r = lse[(int64_t)bh * a.T + ib + 64 + threadIdx.x];
+                del_r = delta[(int64_t)bh * a.T + ib + 64 + threadIdx.x];
+            }
+        }
         if (ib == 0) {
 #pragma unroll
             for (int u = 0; u < G; ++u)
@@ -445,7 +518,7 @@ attn_bwd_dkv_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __
                 const float ls = lse_s[i], de = del_s[i];
 #pragma unroll
                 for (int u = 0; u < G; ++u) {
-                    const float pr = __expf(c[u][r] * a.scale - ls);
+                    const float pr = __builtin_amdgcn_exp2f(c[u][r] * c2 - ls);
                     p[u][it][r] = pr;
                     ds[u][it][r] = a.scale * pr * (d[u][r] - de);
                 }
@@ -542,7 +615,8 @@ attn_bwd_t64_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __
         }
         dl = group_sum(dl);
     }
-    const float li_lse = lse[(int64_t)bh * 64 + qi];
+    const float c2 = a.scale * 1.4426950408889634f;
+    const float li_lse = lse[(int64_t)bh * 64 + qi] * 1.4426950408889634f;             // base-2 domain
     if (g == 0) {
         delta_out[(int64_t)bh * 64 + qi] = dl;
         lse_s[qi] = li_lse;
@@ -569,7 +643,7 @@ attn_bwd_t64_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __
                 d = MFMA(frag_rows<HD>(vimg, 16 * jt, s, lane), gf[s], d);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ds[jt][r] = a.scale * __expf(c[r] * a.scale - li_lse) * (d[r] - dl);
+            for (int r = 0; r < 4; ++r) ds[jt][r] = a.scale * __builtin_amdgcn_exp2f(c[r] * c2 - li_lse) * (d[r] - dl);
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -609,7 +683,7 @@ attn_bwd_t64_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = 16 * it + 4 * g + r;
-                const float pr = __expf(c[r] * a.scale - lse_s[i]);
+                const float pr = __builtin_amdgcn_exp2f(c[r] * c2 - lse_s[i]);
                 p[it][r] = pr;
                 ds[it][r] = a.scale * pr * (d[r] - del_s[i]);
             }
