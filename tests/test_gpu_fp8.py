@@ -239,3 +239,53 @@ def test_row_kernels_with_fp8_output_match_the_quantiser(fmt):
     assert torch.equal(fb.q, fa.q) and torch.equal(fb.qt, fa.qt)
     assert float(st[1, 1]) == float(st[0, 1])
     assert torch.equal(dg1[:, :D], dg2[:, :D]) and torch.equal(cp1, cp2)
+
+
+@pytest.mark.parametrize("R,C", [(192, 128), (256, 384), (1024, 1152), (64, 256)])
+def test_fp8_transpose_kernels(R, C):
+    """vaw_fp8_transpose: qt[c][r] = q[r][c] for any bytes; R % 128 == 0 takes the 128 x 128-tile kernel (16 bytes per lane in and
+    out), other multiples of 64 the 64-row one."""
+    g = torch.Generator().manual_seed(R + C)
+    q = torch.randint(0, 256, (R, C), generator=g, dtype=torch.uint8).to(DEV)
+    qt = torch.zeros(C, R, dtype=torch.uint8, device=DEV)
+    ops.check(vaw_amd._lib.lib().vaw_fp8_transpose(ptr(q), R, C, C, ptr(qt), R, vaw_amd._lib.stream_ptr()), "vaw_fp8_transpose")
+    assert torch.equal(qt, q.t())
+
+
+@pytest.mark.parametrize("fmt", ["e4m3", "e5m2"])
+@pytest.mark.parametrize("B,T,D", [(4, 64, 256), (2, 128, 1152)])
+def test_ln_bwd_gate_fp8_matches_the_pair(fmt, B, T, D):
+    """vaw_ln_modulate_bwd_gate_fp8 = vaw_ln_modulate_bwd followed by vaw_gate_bwd_fp8 on its dx: bytes, running max, dx and every
+    per-sample sum bitwise equal (D = 1152: the 512-thread variant with the rows of a sample cut into chunks)."""
+    code, E, FMAX = FMT[fmt]
+    dev = torch.device(DEV)
+    M = B * T
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(M, D, generator=g) * 2 + 0.5).to(DEV)
+    mod = (torch.randn(B, 6 * D, generator=g) * 0.5).to(DEV)
+    dout = torch.randn(M, D, generator=g).bfloat16().to(DEV)
+    dres = torch.randn(M, D, generator=g).to(DEV)
+    y = torch.randn(M, D, generator=g).bfloat16().to(DEV)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    out = torch.empty(M, D, device=DEV, dtype=torch.bfloat16)
+    BF = vaw_amd._lib.BF16
+    ops.ln_modulate_fwd(BF, ptr(x), ptr(mod) + 4 * 3 * D, ptr(mod) + 4 * 4 * D, 6 * D, ptr(out), ptr(mean), ptr(rstd), B, T, D)
+
+    def run(fused):
+        st = ops.fp8_states([code], dev)
+        st[:, 0] = 0.02
+        f = ops.Fp8(M, D, dev, fmt=code, state=st[0])
+        dmod = torch.zeros(B, 6 * D, device=DEV)
+        dx, part = torch.empty(M, D, device=DEV), torch.empty(B, D, device=DEV)
+        a = (ptr(dout), ptr(x), ptr(mean), ptr(rstd), ptr(mod) + 4 * 4 * D, 6 * D, ptr(dres), ptr(dx), ptr(dmod) + 4 * 3 * D,
+             ptr(dmod) + 4 * 4 * D, 6 * D)
+        if fused:
+            ops.ln_modulate_bwd_gate_fp8(*a, ptr(y), ptr(mod) + 4 * 5 * D, f, ptr(dmod) + 4 * 5 * D, B, T, D, ptr(part))
+        else:
+            ops.ln_modulate_bwd(BF, *a, B, T, D)
+            ops.gate_bwd_fp8(ptr(dx), ptr(y), ptr(mod) + 4 * 5 * D, 6 * D, f, ptr(dmod) + 4 * 5 * D, 6 * D, B, T, D, ptr(part))
+        f.transpose_from_q()
+        torch.cuda.synchronize()
+        return dx, dmod, part, f.qt.clone(), st.clone()
+    for u, v in zip(run(False), run(True)):
+        assert torch.equal(u, v)

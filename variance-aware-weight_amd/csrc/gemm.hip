@@ -952,6 +952,9 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
                 // output from L2 / MALL anyway); VAW_P8_NT=1 switches the non-temporal hint on
                 if (nt_off < 0) { const char* v = getenv("VAW_P8_NT"); nt_off = (v && atoi(v) == 1) ? 0 : 1; }
                 ep8.nt_off = nt_off;
+                static int nt_aux = -1;
+                if (nt_aux < 0) { const char* v = getenv("VAW_P8_NT_AUX"); nt_aux = (v && atoi(v) == 0) ? 0 : 1; }      // default on: -0.5 % on the DiT-B/4 step (13.89 -> 13.83, 13.95 -> 13.88 ms, one box)
+                ep8.nt_aux = nt_aux;
                 ep8.colpart = colsum_out ? colsum_dst : nullptr;
                 ep8.rowpart = nullptr;
                 vaw_p8_launch(pl, a_kmajor, b_kmajor, M, N, K, a, lda, b, ldb, ep8, s);

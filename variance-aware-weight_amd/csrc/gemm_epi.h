@@ -21,6 +21,7 @@ struct EpiDev {
     const float* scale_a;   // fp8 operands: device scalars (per-tensor dequantisation scales) multiplied into alpha, or NULL
     const float* scale_b;
     int nt_off;       // 1 (default): gemm_p8 epilogue stores use the default cache policy; 0 (VAW_P8_NT=1): non-temporal
+    int nt_aux;       // 1 (default; VAW_P8_NT_AUX=0 switches off): the aux_out stores alone are non-temporal (a tensor only the backward pass re-reads)
     int debug;        // measurement only (VAW_GEMM_DEBUG): 1 = skip the epilogue, 2 = skip the K loop (ablations 3-5 of DESIGN.md §5 lived here)
     int direct_epi;   // 1: register-direct epilogue (default), 0: LDS-staged (VAW_GEMM_EPI=0; always for fused column sums)
     float* rowpart;   // mn-major A only (CONV 3 / plain weight gradients): [n_split][M] f32 partial row sums of A = dy^T
@@ -266,7 +267,7 @@ __device__ __forceinline__ void epi_apply8(const EpiDev& e, __amdgpu_buffer_rsrc
     if (K::aux_out(e)) {
         const bf16x8 r = {(bf16_t)v0[0], (bf16_t)v0[1], (bf16_t)v0[2], (bf16_t)v0[3],
                           (bf16_t)v1[0], (bf16_t)v1[1], (bf16_t)v1[2], (bf16_t)v1[3]};
-        buf_store16(rs_aux, ok ? 2u * (unsigned)loc : EPI_OOB, r, !e.nt_off);
+        buf_store16(rs_aux, ok ? 2u * (unsigned)loc : EPI_OOB, r, !e.nt_off || e.nt_aux);
         v0 = f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
         v1 = f32x4{(float)r[4], (float)r[5], (float)r[6], (float)r[7]};
     }

@@ -53,6 +53,11 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 #ifndef P8_LATE_AT
 #define P8_LATE_AT 2
 #endif
+// P8_PH2 = 1: the plain k-major-A launches (forward / input gradients of the Linear layers) run TWO phases of 2 x 16 NTW / 4 MFMAs
+// per K tile instead of four of half that: the same DMA stream and LDS images, half the barriers and waits per MFMA
+#ifndef P8_PH2
+#define P8_PH2 0
+#endif
 #define P8_BM 256
 #define P8_PART 8192
 #define P8_EPI_BYTES 32768
@@ -409,7 +414,8 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
         const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
         while (__builtin_amdgcn_s_memrealtime() - t0 < (uint64_t)team_delay) __builtin_amdgcn_s_sleep(16);
     }
-    P8_WAIT(7);
+    constexpr bool PH2 = P8_PH2 != 0 && CONV == 0 && AK && F8 == 0 && !GRP;
+    if (PH2) P8_WAIT(6); else P8_WAIT(7);          // (PH2's first phase also reads A part 1)
     __builtin_amdgcn_s_barrier();
 
     int stage = 0;
@@ -498,6 +504,58 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
                 _Pragma("unroll") for (int u = 0; u < NTW; ++u) asm volatile("" : "+v"(acc[2 * (j) + t][u]));        \
         }                                                                                                             \
     } while (0)
+            if constexpr (PH2) {
+                // ---- two phases per K tile.  Phase A: B fragments of the whole K tile, A quarters 0 and 1, the stream's pieces
+                // NTW .. LS-1 of the NEXT K tile (its A parts); phase B: A quarters 2 and 3, pieces 0 .. 3 of the K tile after
+                // (B parts (+ A part 0)).  Counted waits (pieces younger than the last one the next phase reads): end of A -- the
+                // whole next set = LS; end of B -- the last two A parts of the next set + the four just issued = 6.
+                // Every wave waits for ITS fragment reads before the barrier: the other wave row issues DMA into the parts they
+                // came from right behind that barrier (in the four-phase schedule a whole phase lies between).
+                bf16x8 af4[2][4];
+                auto load_a2 = [&](int h) {
+#pragma unroll
+                    for (int jq = 0; jq < 2; ++jq)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+#pragma unroll
+                            for (int s = 0; s < 2; ++s)
+                                af4[s][2 * jq + t] = p8_frag<AK>(st + (2 * h + jq) * P8_PART, wr * 32 + 16 * t, s, lane_k);
+                };
+#define P8_MMA2(h)                                                                                                    \
+    do {                                                                                                              \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+        __builtin_amdgcn_s_setprio(1);                                                                                \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                                 \
+            _Pragma("unroll") for (int i4 = 0; i4 < 4; ++i4)                                                          \
+                _Pragma("unroll") for (int u = 0; u < NTW; ++u)                                                       \
+                    acc[4 * (h) + i4][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[s][u], af4[s][i4], acc[4 * (h) + i4][u], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                                \
+    } while (0)
+#pragma unroll
+                for (int u = 0; u < NTW; ++u) {
+                    const int n = wn0 + 16 * u;
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) bfr[s][u] = p8_frag<BKM>(st + Cfg::a_bytes + (n >> 6) * P8_PART, n & 63, s, lane_k);
+                }
+                load_a2(0);
+                issue_ph1();
+                issue_ph2();
+                if (LS == 8) P8_WAIT(8); else P8_WAIT(7);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                P8_MMA2(0);
+                __builtin_amdgcn_s_barrier();
+                load_a2(1);
+                issue_ph3();
+                issue_ph4();
+                P8_WAIT(6);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                P8_MMA2(1);
+                __builtin_amdgcn_s_barrier();
+                continue;
+            }
             // ---- phase 1: B fragments of the whole K tile + A quarter 0
 #pragma unroll
             for (int u = 0; u < NTW; ++u) {

@@ -67,7 +67,13 @@ ln_modulate_fwd_kernel(const float* __restrict__ x, const float* __restrict__ sh
             }
         }
     }
-    if (q_out) fp8_amax_commit(am, q_state + 1, lane);
+    if (q_out) {          // one look at the running max per WORKGROUP (the four waves' maxima meet in LDS)
+        __shared__ float wmax[4];
+        am = wave_max(am);
+        if (lane == 0) wmax[threadIdx.x >> 6] = am;
+        __syncthreads();
+        if (threadIdx.x < 64) fp8_amax_commit(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])), q_state + 1, lane);
+    }
 }
 
 // One block per sample; NW waves stride over that sample's T rows.
@@ -247,14 +253,14 @@ __global__ void row_bwd_finish_kernel(const float* __restrict__ part, int NC, in
 static int pick_nv(int D) { return (D + 255) / 256; }
 // chunks per sample so that small batches still fill the chip: aim at >= 256 workgroups (one per CU; at B >= 256 the
 // single 1024-thread workgroup per sample already runs at 4.5 TB/s and the extra fold launch only costs), >= 8 rows per chunk
-static int pick_chunks(int B, int Tt, bool have_ws) {
+static int pick_chunks(int B, int Tt, bool have_ws, int target_wgs = 256) {
     if (!have_ws) return 1;
-    int nc = (256 + B - 1) / B;
+    int nc = (target_wgs + B - 1) / B;
     const int max_nc = Tt / 8 > 0 ? Tt / 8 : 1;
     if (nc > max_nc) nc = max_nc;
     return nc < 1 ? 1 : nc;
 }
-extern "C" int64_t vaw_row_bwd_workspace_floats(int B, int T, int D) { return (int64_t)pick_chunks(B, T, true) * B * 4 * D; }
+extern "C" int64_t vaw_row_bwd_workspace_floats(int B, int T, int D) { return (int64_t)pick_chunks(B, T, true, 512) * B * 4 * D; }
 
 static int pick_block(int Tt, int max_waves = 16) {
     int nw = Tt < max_waves ? Tt : max_waves;
@@ -343,11 +349,13 @@ extern "C" int vaw_ln_modulate_bwd_gate(vaw_dtype dt, const void* dout, const fl
                   "ln_modulate_bwd_gate: need D%%4==0, D<=2048, mod_ld%%4==0 (D=%d)", D);
     VAW_CHECK_ARG(y_next && gate_next && dy_next && dgate_next, "ln_modulate_bwd_gate: the gate operands are required");
     hipStream_t s = (hipStream_t)stream;
-    int nc = pick_chunks(B, T, workspace != nullptr);
+    const int nv = pick_nv(D);
+    // wide rows (D > 768: four accumulator sets need 176-190 registers) run 512-thread workgroups, two per CU: cut the samples
+    // into enough chunks for 512 of them (DiT-XL/2 at 128 images: 200 us with 256 workgroups at 3.2 TB/s)
+    int nc = pick_chunks(B, T, workspace != nullptr, nv > 3 ? 512 : 256);
     if (nc > 1 && workspace_floats < (int64_t)nc * B * 4 * D) nc = 1;
     const int rpc = (T + nc - 1) / nc;
     float* part = nc > 1 ? workspace : nullptr;
-    const int nv = pick_nv(D);
     const int block = pick_block(rpc, nv > 3 ? 8 : 16);
     const size_t lds = 6 * (size_t)D * sizeof(float);
     dim3 grid(B, nc);
@@ -374,11 +382,13 @@ extern "C" int vaw_ln_modulate_bwd_gate_fp8(const void* dout, const float* x, co
     VAW_CHECK_ARG(y_next && gate_next && dy_q && q_state && dgate_next, "ln_modulate_bwd_gate_fp8: the gate operands are required");
     VAW_CHECK_ARG(q_format == VAW_FP8 || q_format == VAW_BF8, "ln_modulate_bwd_gate_fp8: q_format");
     hipStream_t s = (hipStream_t)stream;
-    int nc = pick_chunks(B, T, workspace != nullptr);
+    const int nv = pick_nv(D);
+    // wide rows (D > 768: four accumulator sets need 176-190 registers) run 512-thread workgroups, two per CU: cut the samples
+    // into enough chunks for 512 of them (DiT-XL/2 at 128 images: 200 us with 256 workgroups at 3.2 TB/s)
+    int nc = pick_chunks(B, T, workspace != nullptr, nv > 3 ? 512 : 256);
     if (nc > 1 && workspace_floats < (int64_t)nc * B * 4 * D) nc = 1;
     const int rpc = (T + nc - 1) / nc;
     float* part = nc > 1 ? workspace : nullptr;
-    const int nv = pick_nv(D);
     const int block = pick_block(rpc, nv > 3 ? 8 : 16);
     const size_t lds = 6 * (size_t)D * sizeof(float);
     dim3 grid(B, nc);
