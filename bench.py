@@ -321,10 +321,15 @@ def main():
                     help="strong (default): global batch fixed, batch // N per GPU (reference main.py:166-180), plus a weak pass "
                          "reported as the field 'weak' when N > 1; weak: only the batch-per-GPU-fixed measurement")
     ap.add_argument("--bucket-dtype", default="bf16", choices=["bf16", "f32"], help="gradient all-reduce buckets on the wire")
+    ap.add_argument("--no-shard-optimizer", action="store_true",
+                    help="N > 1: plain all-reduce + full AdamW/EMA on every rank (reference DDP semantics) instead of the default "
+                         "ZeRO-1 split (reduce-scatter, AdamW + EMA on 1/N of every bucket, all-gather of the bf16 weights)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-trace", action="store_true", help="skip the extra (untimed) steps that bracket GEMM launches with HIP events")
     ap.add_argument("--fp32", action="store_true", help="parity-mode kernels (not the headline number)")
     ap.add_argument("--graph", action="store_true", help="capture the step into one hipGraph (Trainer args.hip_graph); implies --no-trace")
+    ap.add_argument("--no-graph", action="store_true", help="never capture (default: the Trainer decides -- args.hip_graph='auto' -- on one GPU: "
+                                                            "a launch-bound step is captured, a GPU-bound one stays eager)")
     a = ap.parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(a.gpus)
@@ -354,13 +359,14 @@ def main():
         vaw_amd.dist_util.setup_dist(backend="gloo" if rehearse else None, device_index=local)
     if a.graph:
         a.no_trace = True
-    args = workload_args(wl, parallel=parallel, amp=not a.fp32, hip_graph=a.graph)
+    args = workload_args(wl, parallel=parallel, amp=not a.fp32, hip_graph=True if a.graph else False if (a.no_graph or parallel) else "auto")
     model, ema_model = build(vaw_amd, wl, args, device, rank)
     if a.fp32:
         model.set_compute_dtype("fp32")
     elif wl.get("fp8"):
         model.set_compute_dtype("fp8")
-    net = vaw_amd.DistributedDataParallel(model, bucket_dtype=a.bucket_dtype) if parallel else model
+    shard = parallel and not a.no_shard_optimizer and not a.fp32
+    net = vaw_amd.DistributedDataParallel(model, bucket_dtype=a.bucket_dtype, shard_optimizer=shard) if parallel else model
     opt = vaw_amd.FusedAdamW(model, lr=args.lr, betas=(0.9, 0.95), weight_decay=0.0, eps=1e-8)
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=vaw_amd.get_lr_lambda(args))
     diff = vaw_amd.GaussianDiffusion(args=args, betas=vaw_amd.get_named_beta_schedule("cosine", 1000),
@@ -400,6 +406,8 @@ def main():
     # roofline of the dominant kernel: extra steps AFTER the timed region (the HIP-event brackets fence the launch stream and
     # cost ~3 % of a step, so the timed steps carry none), at the batch of the headline measurement
     trace = None
+    if getattr(run.tr, "_graph", None) is not None:
+        a.no_trace = True                    # the step replays a captured graph: there are no launches to bracket with events
     if not a.no_trace and rank == 0:
         trace = vaw_amd.ops.GemmTrace()
     traced_steps = 3
@@ -427,7 +435,8 @@ def main():
                           "global_batch": main_res["global_batch"], "per_gpu_batch": main_res["per_gpu_batch"],
                           "parallelism": f"dp{world}", "weight_type": args.weight_type, "last_loss": main_res["last_loss"],
                           "grad_bucket_dtype": a.bucket_dtype if parallel else None,
-                          "ddp_reserved_cus": net.reserved_cus if parallel else None}}
+                          "ddp_reserved_cus": net.reserved_cus if parallel else None, "optimizer_sharded": bool(shard),
+                          "hip_graph": bool(getattr(run.tr, "_graph", None) is not None)}}
         if weak_res is not None:
             rec["weak"] = dict(weak_res, scaling="weak", note=f"same process, {B} images per GPU")
         if wl["gflop_per_img"]:

@@ -153,3 +153,60 @@ def test_two_rank_step_reproduces_single_rank_step(kind, variant):
         d = (res[0][1] - flat1).abs()
         off = d > 2e-6 + 1e-4 * flat1.abs()
         assert float(off.float().mean()) < 1e-4 and float(d.max()) < 2.1e-3, (int(off.sum()), float(d.max()))
+
+
+def _zero_bf16_worker(rank, world, port, q, shard):
+    try:
+        sys.path.insert(0, REPO)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+        import vaw_amd
+        vaw_amd.dist_util.setup_dist(backend="gloo", device_index=0)
+        dev = torch.device("cuda", 0)
+        model = _build(vaw_amd, dev, "dit")
+        model.set_compute_dtype("bf16")
+        net = vaw_amd.DistributedDataParallel(model, shard_optimizer=shard)
+        diff = vaw_amd.GaussianDiffusion(args=base_args(), betas=vaw_amd.get_named_beta_schedule("cosine", 1000),
+                                         model_mean_type=vaw_amd.ModelMeanType.EPSILON, model_var_type=vaw_amd.ModelVarType.FIXED_LARGE,
+                                         loss_type=vaw_amd.LossType.MSE, rescale_timesteps=True)
+        opt = vaw_amd.FusedAdamW(model, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.0, eps=1e-8)
+        x, y, t, noise = (v[4 * rank:4 * rank + 4].to(dev) for v in _data("dit"))
+        mses = []
+        for _ in range(3):
+            terms = diff.training_losses(net, x, None, t=t, model_kwargs={"y": y}, noise=noise)
+            terms["loss"].mean().backward()
+            opt.step()
+            opt.zero_grad()
+            mses.append(terms["mse"].detach().cpu().numpy())
+        if shard:
+            opt.consolidate()
+        torch.cuda.synchronize()
+        q.put((rank, mses, model._flat.detach().cpu().numpy(), None))
+        vaw_amd.dist_util.cleanup_dist()
+    except Exception:
+        q.put((rank, None, None, traceback.format_exc()))
+
+
+def test_sharded_optimizer_bf16_mode_matches_unsharded_bitwise():
+    """bf16 compute: the sharded optimizer all-gathers the bf16 shadow plus the few parameters the kernels read as f32 (biases,
+    embedding rows).  Three steps sharded == three steps with all-reduce + full update, bit for bit (losses of every step on
+    both ranks, and the consolidated f32 masters)."""
+    out = {}
+    for shard in (False, True):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_zero_bf16_worker, args=(r, 2, port, q, shard)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = {}
+        for _ in range(2):
+            rank, mses, flat, err = q.get(timeout=300)
+            assert err is None, err
+            res[rank] = (mses, flat)
+        for p in procs:
+            p.join(timeout=60)
+        out[shard] = res
+    for rank in (0, 1):
+        for a, b in zip(out[False][rank][0], out[True][rank][0]):
+            assert (a == b).all(), (rank, a, b)
+        assert (out[False][rank][1] == out[True][rank][1]).all()

@@ -118,6 +118,7 @@ class FusedAdamW(torch.optim.Optimizer):
         # other ranks' chunks go stale until consolidate()), the f32 parameters in parity mode
         if shadow is not None:
             z.all_gather_chunks(shadow)
+            self._sync_f32_read_params()
             self.master_stale = True
         else:
             z.all_gather_chunks(m._flat)
@@ -126,6 +127,31 @@ class FusedAdamW(torch.optim.Optimizer):
             ops.ema_update(self._ema_frozen._flat[n:], m._flat[n:], self.ema_decay)
         m.mark_shadow_fresh()
         self.ema_done_in_step = self._ema_shard is not None
+
+    def _sync_f32_read_params(self):
+        """bf16 mode gathers only the bf16 shadow, but some parameters are read by the kernels as f32 straight from the master
+        buffer: every bias / norm vector (GEMM and conv epilogues, GroupNorm) and the embedding tables (label rows added in f32).
+        They are small (DiT-B: 0.95 M of 130 M elements): each rank contributes the elements it owns, zeros elsewhere, and one
+        all-reduce(sum) hands everybody the exact f32 values."""
+        import torch.distributed as dist
+        m, z = self.model, self.zero
+        hot = getattr(self, "_hot", None)
+        if hot is None:
+            emb = {n + ".weight" for n, mod in m.named_modules() if isinstance(mod, torch.nn.Embedding)}
+            idx = [torch.arange(o, o + k) for n, p in zip(m._flat_names, m._flat_params) if (p.dim() == 1 or n in emb)
+                   for o, k in [m._flat_offsets[n]]]
+            idx = torch.cat(idx) if idx else torch.zeros(0, dtype=torch.long)
+            own = torch.zeros(idx.numel(), dtype=torch.bool)
+            for lo, hi in self._chunks:
+                own |= (idx >= lo) & (idx < hi)
+            dev = m._flat.device
+            hot = self._hot = (idx.to(dev), own.to(dev))
+        idx, own = hot
+        if idx.numel() == 0:
+            return
+        vals = torch.where(own, m._flat[idx], torch.zeros((), device=idx.device))
+        dist.all_reduce(vals, group=z.pg)
+        m._flat[idx] = vals
 
     def consolidate(self):
         """ZeRO-1: bring every rank's f32 master parameters up to date (before state_dict / checkpoints / evaluation in f32)."""

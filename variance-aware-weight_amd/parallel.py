@@ -63,7 +63,7 @@ class DistributedDataParallel(nn.Module):
             for lo, hi in self.bucket_ranges():
                 if (hi - lo) % (8 * self.world):
                     raise ValueError(f"shard_optimizer: bucket [{lo}, {hi}) does not split into {self.world} chunks of whole 32-byte groups")
-            module._zero = self
+            object.__setattr__(module, "_zero", self)       # (not a child module: the wrapper contains the module, not the reverse)
         n_buckets = sum(len(r) if isinstance(r, list) else 1 for r in self._ranges.values())
         self._events = [torch.cuda.Event() for _ in range(n_buckets)] if self._cuda else []   # one per bucket, reused every step
         self._issued = 0

@@ -91,16 +91,24 @@ class Trainer:
                 raise ValueError("args.schedule_sampler updates its history on the host every step: not with args.hip_graph")
         # hipGraph mode
         self._graph, self._graph_calls, self._gin, self._gout = None, 0, None, None
-        self._use_graph = bool(getattr(args, "hip_graph", False))
+        # args.hip_graph: True | False | "auto".  "auto" captures the step only when it is LAUNCH-bound (the host needs about as long
+        # to enqueue the step's kernels as the GPU needs to run them: the CIFAR-shaped UNet's ~800 five-microsecond kernels,
+        # 10.6 -> 8.1 ms) and the admission check below passes; a GPU-bound step (DiT-B/4 at any batch: +-0.5 %) stays eager
+        hg = getattr(args, "hip_graph", False)
+        self._graph_auto = hg == "auto"
+        self._use_graph = bool(hg)
         if self._use_graph:
             why = ("needs vaw_amd.FusedAdamW" if not self._fused else "not with DDP (args.parallel)" if args.parallel else
                    "not with grad_accumulation > 1" if max(1, args.grad_accumulation) > 1 else
                    "not with args.cpu_rng" if self._cpu_rng else "needs a CUDA device" if torch.device(device).type != "cuda" else
                    "the model draws its label-drop mask on the host every step (UNet drop_label_prob > 0)"
                    if getattr(inner, "host_rng_in_forward", False) else None)
-            if why:
+            if why and self._graph_auto:
+                self._use_graph = False              # "auto" quietly stays eager where a graph cannot be taken
+            elif why:
                 raise ValueError(f"args.hip_graph: {why}")
-            optimizer.enable_device_hyper()
+            else:
+                optimizer.enable_device_hyper()
 
     def _get_next_batch(self):
         try:
@@ -172,7 +180,24 @@ class Trainer:
         self.optimizer.prepare_step()                     # host: step count, {lr, bc1, bc2} -> device
         self._graph_calls += 1
         if self._graph is None and self._graph_calls <= 2:
-            total, mse = self._graph_body(images, labels)   # eager warm-up: lazy initialisation, workspaces, scratch
+            if self._graph_auto and self._graph_calls == 2:
+                # second warm-up step: host enqueue time against GPU time decides whether replaying a graph can pay
+                import time
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                e0.record()
+                total, mse = self._graph_body(images, labels)
+                e1.record()
+                host_ms = 1e3 * (time.perf_counter() - t0)
+                torch.cuda.synchronize()
+                self.graph_decision = dict(host_ms=host_ms, gpu_ms=e0.elapsed_time(e1))
+                if host_ms < 0.7 * self.graph_decision["gpu_ms"]:
+                    self._graph_calls = -(1 << 60)       # GPU-bound: never capture (the eager body keeps running)
+            else:
+                total, mse = self._graph_body(images, labels)   # eager warm-up: lazy initialisation, workspaces, scratch
+        elif self._graph_calls < 0:
+            total, mse = self._graph_body(images, labels)
         else:
             if self._graph is None:
                 self._gin = (images.clone(), None if labels is None else labels.clone())
