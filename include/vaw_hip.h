@@ -173,6 +173,19 @@ int vaw_fp8_quantize(vaw_dtype src_dt, vaw_dtype dst_format, const void* src, in
 int vaw_fp8_quantize_delayed(vaw_dtype src_dt, vaw_dtype dst_format, const void* src, int64_t R, int64_t C, int64_t ld, void* q,
                              int64_t ldq, void* qt, int64_t ldt, float* state, vaw_stream stream);
 int vaw_fp8_scale_update(float* states, int64_t n, vaw_stream stream);
+/* vaw_fp8_quantize_delayed for MANY f32 tensors in one launch (e4m3): the once-per-step re-quantisation of all Linear weights from
+ * their f32 masters (the reference's autocast casts the same weights to bf16 on every use, tools/trainer.py:104-108).  jobs: host
+ * array; desc_dev: device buffer of vaw_fp8_quantize_batched_desc_bytes(n_jobs) bytes, written when upload != 0 (addresses are
+ * static between steps).  Bytes, transposed copies and running maxima equal the per-tensor calls'. */
+typedef struct {
+    const float* src;      /* f32 [R][C], row stride ld */
+    void* q;               /* e4m3 bytes [R][C], row stride ldq */
+    void* qt;              /* e4m3 bytes [C][R], row stride ldt, or NULL */
+    float* state;          /* the tensor's delayed-scaling state (4 floats) */
+    int64_t R, C, ld, ldq, ldt;
+} vaw_fp8_quant_job;
+int64_t vaw_fp8_quantize_batched_desc_bytes(int n_jobs);
+int vaw_fp8_quantize_delayed_batched(int n_jobs, const vaw_fp8_quant_job* jobs, void* desc_dev, int upload, vaw_stream stream);
 /* C[M,N] = epilogue(alpha * *scale_a * *scale_b * A[M,K] . B[N,K]^T): A bytes of a_format (VAW_FP8 | VAW_BF8), B e4m3 bytes,
  * both k-major (K % 128 == 0, row strides multiples of 16), f32 accumulation on v_mfma_scale_f32_16x16x128_f8f6f4 with unit
  * block scales; C and the epilogue operands as for vaw_gemm with dt = VAW_BF16 (bf16 C / aux, or f32 C with out_f32).

@@ -289,3 +289,24 @@ def test_ln_bwd_gate_fp8_matches_the_pair(fmt, B, T, D):
         return dx, dmod, part, f.qt.clone(), st.clone()
     for u, v in zip(run(False), run(True)):
         assert torch.equal(u, v)
+
+
+def test_fp8_quantize_batched_matches_per_tensor_calls():
+    """vaw_fp8_quantize_delayed_batched (all Linear weights of a step in one launch) == one vaw_fp8_quantize_delayed per tensor:
+    bytes, transposed copies and running maxima."""
+    dev = torch.device(DEV)
+    shapes = [(1152, 1152), (3456, 1152), (200, 72), (64, 4608)]
+    g = torch.Generator().manual_seed(4)
+    srcs = [(torch.randn(R, C, generator=g) * (0.02 * (i + 1))).to(DEV) for i, (R, C) in enumerate(shapes)]
+    st_a, st_b = ops.fp8_states([FP8] * len(shapes), dev), ops.fp8_states([FP8] * len(shapes), dev)
+    st_a[:, 0] = st_b[:, 0] = 1e-4
+    fa = [ops.Fp8(R, C, dev, state=st_a[i]) for i, (R, C) in enumerate(shapes)]
+    fb = [ops.Fp8(R, C, dev, state=st_b[i]) for i, (R, C) in enumerate(shapes)]
+    for f, x in zip(fa, srcs):
+        f.quantize(x, delayed=True)
+    grp = ops.Fp8QuantGroup([(ptr(x), f) for x, f in zip(srcs, fb)], dev)
+    grp.launch()
+    torch.cuda.synchronize()
+    for a, b in zip(fa, fb):
+        assert torch.equal(a.q, b.q) and torch.equal(a.qt, b.qt)
+    assert torch.equal(st_a, st_b)

@@ -83,6 +83,7 @@ _PROTOS = {
     "vaw_fp8_quantize": [_i, _i, _p, _l, _l, _l, _p, _l, _p, _l, _p, _p, _l, _p],
     "vaw_fp8_quantize_delayed": [_i, _i, _p, _l, _l, _l, _p, _l, _p, _l, _p, _p],
     "vaw_fp8_scale_update": [_p, _l, _p],
+    "vaw_fp8_quantize_delayed_batched": [_i, _p, _p, _i, _p],
     "vaw_gemm_fp8": [_i, _l, _l, _l, _p, _l, _p, _p, _l, _p, _p, _l, C.POINTER(Epilogue), _p, _i, _p, _l, _p],
     "vaw_fp8_transpose": [_p, _l, _l, _l, _p, _l, _p],
     "vaw_ln_modulate_fwd_fp8": [_p, _p, _p, _l, _p, _p, _i, _p, _p, _i, _i, _i, _f, _p],
@@ -122,6 +123,8 @@ def lib():
         L.vaw_wgrad_grouped_desc_bytes.restype = _l
         L.vaw_reduce_rows_batched_desc_bytes.argtypes = [_i]
         L.vaw_reduce_rows_batched_desc_bytes.restype = _l
+        L.vaw_fp8_quantize_batched_desc_bytes.argtypes = [_i]
+        L.vaw_fp8_quantize_batched_desc_bytes.restype = _l
         L.vaw_fp8_quantize_workspace_floats.argtypes = []
         L.vaw_fp8_quantize_workspace_floats.restype = _l
         L.vaw_sumsq_workspace_floats.argtypes = []
@@ -144,7 +147,7 @@ def exported_symbols():
     return sorted(list(_PROTOS) + ["vaw_version", "vaw_last_error_string", "vaw_colsum_workspace_floats",
                                    "vaw_sumsq_workspace_floats", "vaw_groupnorm_workspace_floats", "vaw_wgrad_grouped_desc_bytes",
                                    "vaw_conv3x3_wgrad_small_workspace_floats", "vaw_row_bwd_workspace_floats",
-                                   "vaw_fp8_quantize_workspace_floats", "vaw_p8_set_reserved_cus", "vaw_reduce_rows_batched_desc_bytes"])
+                                   "vaw_fp8_quantize_workspace_floats", "vaw_p8_set_reserved_cus", "vaw_reduce_rows_batched_desc_bytes", "vaw_fp8_quantize_batched_desc_bytes"])
 
 
 def check(rc, what):

@@ -943,7 +943,11 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
                                   ? vaw_p8_plan(M, N, K, plain_f32 || (plain_bf16 && !rowsum_out && K >= 2048 && workspace != nullptr),
                                                 colsum_out, workspace_floats, force)
                                   : P8Plan{false, 4, 1, 0};
-            if (pl.use) {
+            // small M (strong-scaling batches): a persistent launch that gives only half the CUs an item loses to the 128 x 128
+            // kernel's 2-3 workgroups per CU (fc1 forward at 2048 rows: 28.7 vs 22.0 us, fc2's GELU' input gradient 29.7 vs 26.5)
+            const bool p8_half_empty = force < 0 && M <= 4096 && pl.use && pl.grid < 200 &&
+                                       ((M + 255) / 256) * ((N + 64 * pl.ntw - 1) / (64 * pl.ntw)) * pl.split < 200;
+            if (pl.use && !p8_half_empty) {
                 CS_CAP_CHECK((M + 127) / 128);
                 EpiDev ep8 = e;
                 static int nt_off = -1;

@@ -69,13 +69,14 @@ __device__ __forceinline__ unsigned fp8_pack4(f32x4 v) {
 // tensor's max |x| is folded into *amax_acc with an integer atomic max on the float's bits (non-negative floats order like
 // unsigned integers; max is order-independent, so the result does not depend on scheduling).
 template <typename T, bool E5M2>
-__global__ void fp8_quantize_kernel(const T* __restrict__ x, int64_t R, int64_t C, int64_t ld, unsigned char* __restrict__ q, int64_t ldq,
-                                    unsigned char* __restrict__ qt, int64_t ldt, const float* __restrict__ scale, float* __restrict__ amax_acc) {
+__device__ __forceinline__ void fp8_quantize_tile(const T* __restrict__ x, int64_t R, int64_t C, int64_t ld, unsigned char* __restrict__ q, int64_t ldq,
+                                                  unsigned char* __restrict__ qt, int64_t ldt, const float* __restrict__ scale,
+                                                  float* __restrict__ amax_acc, int bx, int by) {
     __shared__ unsigned char tile[64][68];
     __shared__ float sh[4];
     const float inv = 1.f / scale[0];
     const float fmax_ = E5M2 ? 57344.f : 448.f;
-    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+    const int64_t r0 = (int64_t)by * 64, c0 = (int64_t)bx * 64;
     const int tr = threadIdx.x >> 4, tc = (threadIdx.x & 15) * 4;              // 16 rows x 16 groups of 4 columns per pass
     float am = 0.f;
 #pragma unroll
@@ -122,6 +123,33 @@ __global__ void fp8_quantize_kernel(const T* __restrict__ x, int64_t R, int64_t 
                 for (int j = 0; j < 4 && r0 + tc + j < R; ++j) qt[(c0 + c) * ldt + r0 + tc + j] = tile[tc + j][c];
         }
     }
+}
+
+template <typename T, bool E5M2>
+__global__ void fp8_quantize_kernel(const T* __restrict__ x, int64_t R, int64_t C, int64_t ld, unsigned char* __restrict__ q, int64_t ldq,
+                                    unsigned char* __restrict__ qt, int64_t ldt, const float* __restrict__ scale, float* __restrict__ amax_acc) {
+    fp8_quantize_tile<T, E5M2>(x, R, C, ld, q, ldq, qt, ldt, scale, amax_acc, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// MANY f32 tensors in one launch (delayed scaling, e4m3): the weights of every Linear layer of the blocks are re-quantised from
+// their f32 masters once per optimizer step -- 112 tensors for DiT-XL, each an 18-microsecond launch of its own before (2 ms of
+// the fp8 step; the tensors are 1-5 M elements: latency-, not bandwidth-bound).  Job j owns workgroups [block0_j, block0_{j+1}).
+struct QuantJobDev {
+    const float* src;
+    unsigned char *q, *qt;
+    float* state;
+    int64_t R, C, ld, ldq, ldt;
+    int block0, tiles_x;
+};
+__global__ void fp8_quantize_batched_kernel(const QuantJobDev* __restrict__ jobs, int n_jobs) {
+    int lo = 0, hi = n_jobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const QuantJobDev jb = jobs[lo];
+    const int t = (int)blockIdx.x - jb.block0;
+    fp8_quantize_tile<float, false>(jb.src, jb.R, jb.C, jb.ld, jb.q, jb.ldq, jb.qt, jb.ldt, jb.state, jb.state + 1, t % jb.tiles_x, t / jb.tiles_x);
 }
 
 // The training step's shapes (bf16 source, R % 64 == 0, C % 128 == 0, both copies wanted, 16-byte aligned rows): 64 x 128
@@ -348,6 +376,32 @@ extern "C" int vaw_fp8_quantize_delayed(vaw_dtype src_dt, vaw_dtype dst_format, 
     if (src_dt == VAW_F32) { if (e5) QUANT_D(float, true); else QUANT_D(float, false); }
     else { if (e5) QUANT_D(bf16_t, true); else QUANT_D(bf16_t, false); }
     VAW_CHECK_LAUNCH("fp8_quantize_delayed");
+    return VAW_OK;
+}
+
+extern "C" int64_t vaw_fp8_quantize_batched_desc_bytes(int n_jobs) { return (int64_t)n_jobs * (int64_t)sizeof(QuantJobDev); }
+
+extern "C" int vaw_fp8_quantize_delayed_batched(int n_jobs, const vaw_fp8_quant_job* jobs, void* desc_dev, int upload, vaw_stream stream) {
+    VAW_CHECK_ARG(n_jobs > 0 && n_jobs <= 4096 && jobs && desc_dev, "fp8_quantize_delayed_batched: bad arguments");
+    static thread_local QuantJobDev host[4096];
+    int64_t blocks = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const vaw_fp8_quant_job& q = jobs[j];
+        VAW_CHECK_ARG(q.src && q.q && q.state && q.R > 0 && q.C > 0 && q.C % 4 == 0 && q.ld >= q.C && q.ld % 4 == 0 && q.ldq >= q.C && q.ldq % 4 == 0 &&
+                      (!q.qt || (q.ldt >= q.R && q.ldt % 4 == 0)), "fp8_quantize_delayed_batched: job %d: sizes (C, ld, ldq, ldt multiples of 4)", j);
+        VAW_CHECK_ARG(((uintptr_t)q.src & 15) == 0 && (((uintptr_t)q.q | (uintptr_t)q.qt | (uintptr_t)q.state) & 3) == 0, "fp8_quantize_delayed_batched: job %d: alignment", j);
+        const int tx = (int)((q.C + 63) / 64), ty = (int)((q.R + 63) / 64);
+        host[j] = QuantJobDev{q.src, (unsigned char*)q.q, (unsigned char*)q.qt, q.state, q.R, q.C, q.ld, q.ldq, q.ldt, (int)blocks, tx};
+        blocks += (int64_t)tx * ty;
+        VAW_CHECK_ARG(blocks < (1 << 30), "fp8_quantize_delayed_batched: too many tiles");
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (upload) {
+        const hipError_t rc = hipMemcpyAsync(desc_dev, host, sizeof(QuantJobDev) * n_jobs, hipMemcpyHostToDevice, s);
+        VAW_CHECK_ARG(rc == hipSuccess, "fp8_quantize_delayed_batched: descriptor upload failed: %s", hipGetErrorString(rc));
+    }
+    fp8_quantize_batched_kernel<<<(unsigned)blocks, 256, 0, s>>>((const QuantJobDev*)desc_dev, n_jobs);
+    VAW_CHECK_LAUNCH("fp8_quantize_delayed_batched");
     return VAW_OK;
 }
 

@@ -220,7 +220,7 @@ class DiT(FlatModule):
         # byte-identical to quantising the bf16 tensor, which is then never written or read
         self.fp8_fuse_epilogue = os.environ.get("VAW_FP8_FUSE", "1") != "0"
         self.fp8_fuse_rows = os.environ.get("VAW_FP8_FUSE_ROWS", "1") != "0"      # ... and LN-modulate / gate backward their outputs
-        self._fp8_w, self._fp8_epoch, self._fp8_wstates = {}, None, None
+        self._fp8_w, self._fp8_epoch, self._fp8_wstates, self._fp8_wgroup = {}, None, None, None
         self.set_compute_dtype(compute_dtype)
         self._anchor = torch.zeros(1, requires_grad=True)
         self._ws, self._ws_cur = {}, None
@@ -266,7 +266,7 @@ class DiT(FlatModule):
         self.compute_dtype = name
         self._dt = F32 if name == "fp32" else BF16
         self._fp8 = name == "fp8"
-        self._fp8_w, self._fp8_epoch, self._fp8_wstates = {}, None, None
+        self._fp8_w, self._fp8_epoch, self._fp8_wstates, self._fp8_wgroup = {}, None, None, None
         self._ws = {}
 
     def _flat_groups(self):
@@ -371,10 +371,18 @@ class DiT(FlatModule):
             return
         dev = self._flat.device
         if self._fp8_wstates is None or self._fp8_wstates.device != dev:
-            self._fp8_wstates, self._fp8_w = ops.fp8_states([L.FP8] * (4 * self.depth), dev, self.fp8_margin), {}
+            self._fp8_wstates, self._fp8_w, self._fp8_wgroup = ops.fp8_states([L.FP8] * (4 * self.depth), dev, self.fp8_margin), {}, None
         delayed = self.fp8_scaling == "delayed" and bool(self._fp8_w)
         if delayed:
             ops.fp8_scale_update(self._fp8_wstates)
+            grp = getattr(self, "_fp8_wgroup", None)
+            if grp is None or grp[0] != self._flat.data_ptr():
+                pairs = [(self._p32(f"blocks.{l}.{nm}weight"), self._fp8_w[f"blocks.{l}.{nm}weight"])
+                         for l in range(self.depth) for nm, _, _ in self._FP8_LINEARS]
+                grp = self._fp8_wgroup = (self._flat.data_ptr(), ops.Fp8QuantGroup(pairs, dev))
+            grp[1].launch()          # all 4 L weight matrices in one launch
+            self._fp8_epoch = epoch
+            return
         i = 0
         for l in range(self.depth):
             for nm, nf, kf in self._FP8_LINEARS:
@@ -383,7 +391,7 @@ class DiT(FlatModule):
                 f = self._fp8_w.get(name)
                 if f is None:
                     f = self._fp8_w[name] = ops.Fp8(N, K, dev, state=self._fp8_wstates[i])
-                f.quantize(self._p32(name), src_dt=F32, delayed=delayed)
+                f.quantize(self._p32(name), src_dt=F32, delayed=False)
                 i += 1
         self._fp8_epoch = epoch
 

@@ -112,7 +112,7 @@ class FlatModule(nn.Module):
         import copy
         skip = {"_flat", "_flat_grad", "_flat_shadow", "_flat_params"}
         # per-batch workspaces / tapes / descriptors hold activations of the source model: the copy starts with none
-        fresh = {"_ws": dict, "_ws_cur": lambda: None, "_adesc": lambda: None, "_tape": list, "_fp8_w": dict, "_fp8_epoch": lambda: None, "_fp8_wstates": lambda: None, "_zero": lambda: None, "grad_ready_hook": lambda: None}
+        fresh = {"_ws": dict, "_ws_cur": lambda: None, "_adesc": lambda: None, "_tape": list, "_fp8_w": dict, "_fp8_epoch": lambda: None, "_fp8_wstates": lambda: None, "_fp8_wgroup": lambda: None, "_zero": lambda: None, "grad_ready_hook": lambda: None}
         for k, v in self.__dict__.items():
             new.__dict__[k] = None if k in skip else fresh[k]() if k in fresh else copy.deepcopy(v, memo)
         new._flat_dirty = True

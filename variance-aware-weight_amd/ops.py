@@ -239,6 +239,32 @@ class Fp8:
         return self.q.view(torch.float8_e5m2 if self.fmt == L.BF8 else torch.float8_e4m3fn).float() * self.scale
 
 
+class Fp8QuantJob(C.Structure):
+    """vaw_fp8_quant_job of include/vaw_hip.h."""
+    _fields_ = [("src", C.c_void_p), ("q", C.c_void_p), ("qt", C.c_void_p), ("state", C.c_void_p), ("R", C.c_int64), ("C", C.c_int64),
+                ("ld", C.c_int64), ("ldq", C.c_int64), ("ldt", C.c_int64)]
+
+
+class Fp8QuantGroup:
+    """Delayed-scaling e4m3 quantisation of many f32 tensors (src address, Fp8 with q and qt) in ONE launch
+    (vaw_fp8_quantize_delayed_batched); the addresses stay put between steps, so the device table is uploaded once."""
+
+    def __init__(self, pairs, device):
+        jobs = [Fp8QuantJob(src, f.q.data_ptr(), ptr(f.qt), f.state.data_ptr(), f.R, f.C, f.C, f.C, f.R) for src, f in pairs]
+        self.n = len(jobs)
+        self.table = (Fp8QuantJob * self.n)(*jobs)
+        self.fp8s = [f for _, f in pairs]
+        self.desc = torch.empty(L.lib().vaw_fp8_quantize_batched_desc_bytes(self.n), device=device, dtype=torch.uint8)
+        self.uploaded = False
+
+    def launch(self):
+        check(L.lib().vaw_fp8_quantize_delayed_batched(self.n, C.cast(self.table, C.c_void_p), self.desc.data_ptr(),
+                                                       0 if self.uploaded else 1, stream_ptr()), "vaw_fp8_quantize_delayed_batched")
+        self.uploaded = True
+        for f in self.fp8s:
+            f.last_q = f.q.data_ptr()
+
+
 _q_scratch = {}
 
 
