@@ -406,8 +406,9 @@ def main():
     # roofline of the dominant kernel: extra steps AFTER the timed region (the HIP-event brackets fence the launch stream and
     # cost ~3 % of a step, so the timed steps carry none), at the batch of the headline measurement
     trace = None
-    if getattr(run.tr, "_graph", None) is not None:
-        a.no_trace = True                    # the step replays a captured graph: there are no launches to bracket with events
+    graph_timed = getattr(run.tr, "_graph", None) is not None
+    if graph_timed and not a.no_trace:
+        run.tr.eager_from_now_on()           # the timed steps replayed a captured graph: the traced ones launch kernel by kernel
     if not a.no_trace and rank == 0:
         trace = vaw_amd.ops.GemmTrace()
     traced_steps = 3
@@ -436,7 +437,7 @@ def main():
                           "parallelism": f"dp{world}", "weight_type": args.weight_type, "last_loss": main_res["last_loss"],
                           "grad_bucket_dtype": a.bucket_dtype if parallel else None,
                           "ddp_reserved_cus": net.reserved_cus if parallel else None, "optimizer_sharded": bool(shard),
-                          "hip_graph": bool(getattr(run.tr, "_graph", None) is not None)}}
+                          "hip_graph": bool(graph_timed)}}
         if weak_res is not None:
             rec["weak"] = dict(weak_res, scaling="weak", note=f"same process, {B} images per GPU")
         if wl["gflop_per_img"]:

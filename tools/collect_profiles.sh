@@ -15,18 +15,18 @@ for wl in $WLS; do
   base=${TAG}_${wl}_bs${BS[$wl]}_${dt}
   d=gpurun_out/prof_$wl; rm -rf $d
   echo "== $wl: kernel stats"
-  timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $d -o p -- python3 bench.py --workload $wl ${FLAGS[$wl]} --no-cpu-baseline > $d.log 2>&1 || { tail -5 $d.log; exit 1; }
+  timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $d -o p -- python3 bench.py --workload $wl ${FLAGS[$wl]} --no-cpu-baseline --no-graph > $d.log 2>&1 || { tail -5 $d.log; exit 1; }
   cp $d/p_kernel_stats.csv $OUT/${base}_kernel_stats.csv
   grep '^{"metric"' $d.log | tail -1 > $OUT/${base}_bench_under_rocprof.json
   if [ $wl = dit_b4 ] || [ $wl = dit_xl2_fp8 ] || [ $wl = unet64 ] || [ "$PMC_ALL" = 1 ]; then
     echo "== $wl: PMC passes"
     for c in FETCH_SIZE WRITE_SIZE; do
       rm -rf gpurun_out/pmc_$c
-      timeout -k 10 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_$c -o c -- python3 bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline --no-trace > gpurun_out/pmc_$c.log 2>&1 || { tail -5 gpurun_out/pmc_$c.log; exit 1; }
+      timeout -k 10 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_$c -o c -- python3 bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline --no-trace --no-graph > gpurun_out/pmc_$c.log 2>&1 || { tail -5 gpurun_out/pmc_$c.log; exit 1; }
     done
     python3 tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE/c_counter_collection.csv gpurun_out/pmc_WRITE_SIZE/c_counter_collection.csv $OUT/${base}_hbm_traffic.json gemm_ || exit 1
     rm -rf gpurun_out/pmc_mfma
-    timeout -k 10 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc_mfma -o c -- python3 bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline --no-trace > gpurun_out/pmc_mfma.log 2>&1 || { tail -5 gpurun_out/pmc_mfma.log; exit 1; }
+    timeout -k 10 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc_mfma -o c -- python3 bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline --no-trace --no-graph > gpurun_out/pmc_mfma.log 2>&1 || { tail -5 gpurun_out/pmc_mfma.log; exit 1; }
     python3 tools/pmc_mfma.py gpurun_out/pmc_mfma/c_counter_collection.csv $OUT/${base}_mfma_pmc.json || exit 1
     rm -rf gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/pmc_mfma
   fi

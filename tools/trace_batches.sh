@@ -7,7 +7,7 @@ OUT=gpurun_out/profiles; mkdir -p $OUT
 export TMPDIR=/tmp
 for b in "$@"; do
   d=gpurun_out/prof_b$b; rm -rf $d
-  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $d -o p -- python3 bench.py --batch $b --steps 20 --warmup 5 --no-cpu-baseline $EXTRA > $d.log 2>&1 || { tail -5 $d.log; exit 1; }
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $d -o p -- python3 bench.py --batch $b --steps 20 --warmup 5 --no-cpu-baseline --no-graph $EXTRA > $d.log 2>&1 || { tail -5 $d.log; exit 1; }
   cp $d/p_kernel_stats.csv $OUT/${TAG}_dit_b4_bs${b}_bf16_kernel_stats.csv
   grep '^{"metric"' $d.log | tail -1 > $OUT/${TAG}_dit_b4_bs${b}_bf16_bench_under_rocprof.json
   rm -rf $d

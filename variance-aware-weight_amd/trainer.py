@@ -173,6 +173,12 @@ class Trainer:
         # pure KL / RESCALED_KL objectives carry no "mse" term (reference tools/trainer.py:116 guards the same way)
         return loss.detach(), (loss_dict["mse"].detach().mean() if "mse" in loss_dict else torch.zeros_like(loss.detach()))
 
+    def eager_from_now_on(self):
+        """Drop a captured graph: later steps launch their kernels one by one again (bench.py brackets them with HIP events)."""
+        if self._use_graph:
+            self._graph, self._gin, self._gout = None, None, None
+            self._graph_calls = -(1 << 60)
+
     def _train_step_graph(self, step):
         a = self.args
         self.model.train()
