@@ -585,7 +585,7 @@ attn_bwd_t64_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __
                   const bf16_t* __restrict__ o, const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                   float* __restrict__ delta_out, bf16_t* __restrict__ dq, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv,
                   float* __restrict__ cs_part = nullptr, int64_t cs_ld = 0) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 images of 64 x HD bf16 + lse / delta + column-sum scratch [3][4][HD] f32
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 images of 64 x HD bf16 (reused as output staging) + lse / delta
     constexpr int KS = HD / 32, DT = HD / 16;
     char* qimg = smem;
     char* gimg = qimg + Img<HD>::BYTES;
@@ -593,7 +593,6 @@ attn_bwd_t64_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __
     char* vimg = kimg + Img<HD>::BYTES;
     float* lse_s = reinterpret_cast<float*>(vimg + Img<HD>::BYTES);
     float* del_s = lse_s + 64;
-    float* cs = del_s + 64;
     const int lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
@@ -623,6 +622,22 @@ attn_bwd_t64_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __
         del_s[qi] = dl;
     }
     DMA_WAIT_SYNC();
+    // Output staging (r3): dq, dk, dv leave through LDS as whole rows -- a lane of an accumulator tile owns 4 bf16 of one row, so
+    // direct stores write 32-byte pieces of 16 rows per instruction; staged, eight lanes write one 128-byte row with 16 bytes each
+    // -- and their column sums (the qkv bias gradient) are taken from the staged tiles by 3 hd threads in a fixed row order
+    // instead of by 192 shuffles per wave.  Tile layout: [64 rows][2 HD bytes], 16-byte chunk c of row r at c ^ (r & 7) (HD 96:
+    // the 208-byte pitch of the images, no XOR); dq is staged over the K (and V) image once every wave holds its phase-2
+    // fragments, dk / dv over the Q / dO images after phase 2.
+    auto st_off = [](int r, int c16) { return HD == 96 ? r * 208 + 16 * c16 : r * (2 * HD) + ((c16 ^ (r & (HD / 8 < 8 ? HD / 8 - 1 : 7))) << 4); };
+    auto stage_tile = [&](char* dst, const f32x4 (&acc)[DT]) {     // this wave's 16 rows: lane (li, g) -> row 16 wid + li, columns 16 dt + 4 g ..
+        const int r = 16 * wid + li;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const bf16x4 w = {(bf16_t)acc[dt][0], (bf16_t)acc[dt][1], (bf16_t)acc[dt][2], (bf16_t)acc[dt][3]};
+            *reinterpret_cast<bf16x4*>(dst + st_off(r, 2 * dt + (g >> 1)) + 8 * (g & 1)) = w;
+        }
+    };
+    f32x4 acc[DT];
     // ---- phase 1: dQ of this wave's 16 queries ----
     {
         bf16x8 qf[KS], gf[KS];
@@ -631,7 +646,7 @@ attn_bwd_t64_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __
             qf[s] = frag_rows<HD>(qimg, 16 * wid, s, lane);
             gf[s] = frag_rows<HD>(gimg, 16 * wid, s, lane);
         }
-        f32x4 ds[4], acc[DT];
+        f32x4 ds[4];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) acc[dt] = f32x4{0, 0, 0, 0};
 #pragma unroll
@@ -651,17 +666,9 @@ attn_bwd_t64_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) acc[dt] = MFMA(frag_cols_perm<HD>(kimg, 16 * dt, 32 * s2, lane), sf, acc[dt]);
         }
-        bf16_t* row = dq + base + (int64_t)qi * a.q_st + 4 * g;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-            if (16 * dt + 4 * g < a.hd) store4(row + 16 * dt, acc[dt]);
-        if (cs_part) {
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) acc[dt] = as_stored_bf16(acc[dt]);
-            attn_cs_wave<DT>(acc, cs + wid * HD, lane);
-        }
     }
-    // ---- phase 2: dK, dV of this wave's 16 keys (all four images stay as staged; lse_s / del_s were written before the sync) ----
+    // ---- phase 2: dK, dV of this wave's 16 keys (lse_s / del_s were written before the sync) ----
+    f32x4 av[DT], ak[DT];
     {
         bf16x8 kf[KS], vf[KS];
 #pragma unroll
@@ -669,7 +676,9 @@ attn_bwd_t64_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __
             kf[s] = frag_rows<HD>(kimg, 16 * wid, s, lane);
             vf[s] = frag_rows<HD>(vimg, 16 * wid, s, lane);
         }
-        f32x4 p[4], ds[4], av[DT], ak[DT];
+        __syncthreads();                  // nobody reads the K / V images any more: dq is staged over them
+        stage_tile(kimg, acc);
+        f32x4 p[4], ds[4];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) av[dt] = ak[dt] = f32x4{0, 0, 0, 0};
 #pragma unroll
@@ -698,23 +707,34 @@ attn_bwd_t64_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __
                 ak[dt] = MFMA(frag_cols_perm<HD>(qimg, 16 * dt, 32 * s2, lane), sf, ak[dt]);
             }
         }
-        const int64_t off = base + (int64_t)(16 * wid + li) * a.q_st + 4 * g;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            if (16 * dt + 4 * g >= a.hd) continue;
-            store4(dv + off + 16 * dt, av[dt]);
-            store4(dk + off + 16 * dt, ak[dt]);
-        }
-        if (cs_part) {
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) { ak[dt] = as_stored_bf16(ak[dt]); av[dt] = as_stored_bf16(av[dt]); }
-            attn_cs_wave<DT>(ak, cs + 4 * HD + wid * HD, lane);
-            attn_cs_wave<DT>(av, cs + 8 * HD + wid * HD, lane);
-        }
     }
-    if (cs_part) {     // this (sample, head)'s column sums of dq | dk | dv -> its columns of the sample's partial row [3 H hd]
-        __syncthreads();
-        attn_cs_commit<HD>(cs, 3, 0, a.hd, a.H * a.hd, h, cs_part + (int64_t)b * cs_ld);
+    __syncthreads();                      // nobody reads the Q / dO images any more
+    stage_tile(qimg, ak);
+    stage_tile(gimg, av);
+    __syncthreads();
+    // whole rows out: tile 0 = dq (staged at kimg), 1 = dk (qimg), 2 = dv (gimg); 16 bytes per thread and access
+    constexpr int CPR = HD / 8;
+#pragma unroll
+    for (int i = 0; i < (3 * 64 * CPR + 255) / 256; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        if ((3 * 64 * CPR) % 256 != 0 && idx >= 3 * 64 * CPR) break;
+        const int tile = idx / (64 * CPR), rem = idx - tile * (64 * CPR), r = rem / CPR, c16 = rem - r * CPR;
+        if (8 * c16 >= a.hd) continue;
+        const char* src = (tile == 0 ? kimg : tile == 1 ? qimg : gimg) + st_off(r, c16);
+        bf16_t* dst = (tile == 0 ? dq : tile == 1 ? dk : dv) + base + (int64_t)r * a.q_st + 8 * c16;
+        *reinterpret_cast<bf16x8*>(dst) = *reinterpret_cast<const bf16x8*>(src);
+    }
+    if (cs_part) {     // this (sample, head)'s column sums of dq | dk | dv (as stored, rows in ascending order) -> its columns of the
+                       // sample's partial row [3 H hd]
+        for (int t = threadIdx.x; t < 3 * HD; t += 256) {
+            const int tile = t / HD, c = t - tile * HD;
+            if (c >= a.hd) continue;
+            const char* src = (tile == 0 ? kimg : tile == 1 ? qimg : gimg) + 2 * (c & 7);
+            float sum = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < 64; ++r) sum += (float)*reinterpret_cast<const bf16_t*>(src + st_off(r, c >> 3));
+            cs_part[(int64_t)b * cs_ld + tile * (a.H * a.hd) + h * a.hd + c] = sum;
+        }
     }
 }
 
@@ -792,7 +812,7 @@ int vaw_attn_bwd_mfma(const vaw_attn_desc* d, const void* q, const void* k, cons
     dim3 grid(d->T / 64, d->B * d->H);
     if (d->T == 64) {      // single block of queries and keys: one fused launch
         DISPATCH_HD(d->hd,
-            const int lds = 4 * Img<HD>::BYTES + 2 * 64 * 4 + 12 * HD * 4;
+            const int lds = 4 * Img<HD>::BYTES + 2 * 64 * 4;
             (void)hipFuncSetAttribute((const void*)attn_bwd_t64_mfma<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             attn_bwd_t64_mfma<HD><<<d->B * d->H, 256, lds, s>>>(a, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o,
                                                               (const bf16_t*)d_o, lse, delta, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, cs_part, cs_ld);
