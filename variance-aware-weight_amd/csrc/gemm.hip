@@ -841,7 +841,7 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
         {
             static int sm_max_m = -1, sm_nb = 0, sm_st = 0, sm_wide_m = 0;
             if (sm_max_m < 0) {
-                const char* v = getenv("VAW_SM_MAX_M"); sm_max_m = v ? atoi(v) : 4096;
+                const char* v = getenv("VAW_SM_MAX_M"); sm_max_m = v ? atoi(v) : 8192;
                 v = getenv("VAW_SM_WIDE_M"); sm_wide_m = v ? atoi(v) : 0;        // 128 x 128 tiles for the wide launches up to this M (0 = off)
                 v = getenv("VAW_SM_NB"); sm_nb = v ? atoi(v) : 0;
                 v = getenv("VAW_SM_STAGES"); sm_st = v ? atoi(v) : 0;
@@ -854,7 +854,11 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
             // tiles move twice the operand bytes per MFMA): taken only below one 128 x 128 tile per CU
             // (and only for the K of the blocks' Linear layers: the long-K launches -- adaLN's input gradient, K = 6 L D -- keep
             //  their split-K path: 161 us on 48 workgroups here against 40 + 38 us split)
-            const bool sm_few_tiles = ((M + 127) / 128) * ((N + 127) / 128) < 256 && K <= 4096;
+            // With the LDS-staged epilogue (round 3, late) the ring kernel wins on every 768-wide layer up to 4096 rows, and up to
+            // 8192 rows on those with K = 768 (proj: 33.2 -> 24.4, 23.3 -> 17.9 us) and on fc2's forward (K = 3072: 72.7 -> 61.2 with
+            // 128-column tiles); the wide layers (N >= 2304) tie at 2048 rows and lose above: they keep the other kernels
+            const bool sm_few_tiles = N <= 1024 && K <= 4096 &&
+                                      (M <= 4096 || (M <= 8192 && (K <= 1024 || b_kmajor)));
             // wide layers at small M (fc1, fc2's GELU' input gradient, qkv at 2048-4096 rows: 128-288 items of the larger kernels):
             // 128 x 128 tiles on the same ring
             const bool sm_wide = !sm_few_tiles && M <= sm_wide_m && K <= 4096 && ((M + 127) / 128) * ((N + 127) / 128) <= 1024;
@@ -862,9 +866,8 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
             if (a_kmajor && ((M <= sm_max_m && (sm_few_tiles || sm_wide) && g_gemm_tile < 0) || sm_forced) && !rowsum_out && cs_room && N % 8 == 0) {
                 // 64 x 128 tiles when they still give every CU a workgroup, 64 x 64 otherwise; ring depth by the LDS it leaves:
                 // 3 stages = two (64 x 128) or three (64 x 64) workgroups per CU for multi-round launches, 4 for single rounds
-                const int64_t t2 = rows64 * ((N + 127) / 128);
                 const int mb = g_gemm_tile == 8 ? 2 : (g_gemm_tile >= 5 ? 1 : (sm_wide && !sm_few_tiles) ? 2 : 1);
-                const int nb = mb == 2 ? 2 : g_gemm_tile == 6 ? 1 : g_gemm_tile == 7 ? 2 : sm_nb ? sm_nb : (t2 >= 384 ? 2 : 1);
+                const int nb = mb == 2 ? 2 : g_gemm_tile == 6 ? 1 : g_gemm_tile == 7 ? 2 : sm_nb ? sm_nb : ((M >= 4096 && K >= 2048) ? 2 : 1);
                 const int64_t rows_t = (M + 64 * mb - 1) / (64 * mb);
                 const int64_t tiles = rows_t * ((N + 64 * nb - 1) / (64 * nb));
                 const int stages = sm_st ? sm_st : (tiles > 256 ? 3 : 4);

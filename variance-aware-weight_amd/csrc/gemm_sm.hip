@@ -9,8 +9,8 @@
 //     s_waitcnt vmcnt(N) and a raw s_barrier per K tile: STAGES - 1 K tiles stay in flight, so the loop streams at the DMA
 //     rate of the CU instead of paying a latency per step (cdna_hip_programming.md "Pipelining across barriers");
 //   * LDS images, swizzles and fragment reads are those of the persistent kernel (8 KiB parts of 64 rows x 128 B, p8_frag);
-//   * register-direct epilogue (the accumulators are held transposed: a lane owns 4 consecutive columns of a row) with the row
-//     epilogue of gemm_epi.h, column sums of the output (the next bias gradient) folded per 64-row tile in a fixed order.
+//   * LDS-staged epilogue (accumulators -> f32 image over the dead ring -> 8 consecutive columns per thread, 16-byte accesses) with
+//     the row epilogue of gemm_epi.h, column sums of the output (the next bias gradient) folded per tile row in a fixed order.
 // Layouts: A k-major ([M][K]); B k-major ([N][K], forward) or mn-major ([K][N], input gradients).  Weight gradients keep the
 // grouped persistent launch (K = tokens is long there and all layers together fill the chip).
 #include "gemm_p8_kernel.h"
@@ -117,41 +117,53 @@ gemm_sm_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
                 for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[s][j], af[s][i], acc[i][j], 0, 0, 0);
     }
 
-    // ---- epilogue: lane (lr = lane & 15, g = lane >> 4) owns row lr of each 16-row tile and columns 4 g .. 4 g + 3 of each 16-column tile
+    // ---- epilogue: accumulators -> f32 staging image in LDS (the ring is dead), then every thread owns 8 consecutive columns of one
+    // row per pass: 16-byte loads and stores of whole row segments (a lane of an accumulator tile owns 4 columns of a row: written
+    // directly, a wave instruction touches 32-byte pieces of 16 rows -- 1.5-2x slower on bf16 outputs, gemm.hip measured the same)
     const int lr = lane & 15, g4 = 4 * (lane >> 4);
-    f32x4 cs[NT];
+    constexpr int LD = Cfg::BN + 4;                                   // f32 row pitch: conflict-free for the 4-column accumulator writes
+    float* cs = reinterpret_cast<float*>(smem);
+    __syncthreads();                                                  // every wave has left the K loop (its last wait was vmcnt(0))
 #pragma unroll
-    for (int j = 0; j < NT; ++j) cs[j] = f32x4{0, 0, 0, 0};
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int col = wc * (16 * NT) + 16 * j + g4;
-        if (col >= nvalid) continue;                                    // N % 8 == 0: four columns are in or out together
-        const f32x4 bj = e.bias ? load4(e.bias + n0 + col) : f32x4{0, 0, 0, 0};
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int row = wr * (16 * MT) + 16 * i + lr;
-            if (row >= mvalid) continue;
-            f32x4 v = acc[i][j];
-            epi_row4(e, (unsigned)(m0 + row), n0 + col, v, bj);          // v comes back as stored
-            cs[j] += v;
-        }
+        for (int j = 0; j < NT; ++j)
+            store4(cs + (wr * (16 * MT) + 16 * i + lr) * LD + wc * (16 * NT) + 16 * j + g4, acc[i][j]);
+    __syncthreads();
+    constexpr int CG = Cfg::BN / 8, RP = 256 / CG;                    // column groups of 8; rows per pass
+    const int c8 = (threadIdx.x % CG) * 8, r0 = threadIdx.x / CG;
+    const bool col_ok = c8 < nvalid;                                  // N % 8 == 0: a group is in or out as a whole
+    f32x4 b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
+    if (e.bias && col_ok) {
+        b0 = load4(e.bias + n0 + c8);
+        b1 = load4(e.bias + n0 + c8 + 4);
     }
-    if (e.colpart) {       // column sums of this tile (one partial row per tile row): 16 rows by shuffles, then the two wave rows through LDS, fixed order
-        __builtin_amdgcn_s_waitcnt(0);
-        __syncthreads();                                                 // the ring is dead: reuse it
-        float* sc = reinterpret_cast<float*>(smem);                      // [2 wave rows][BN]
+    f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
+    for (int pass = 0; pass < Cfg::BM / RP; ++pass) {
+        const int row = pass * RP + r0;
+        if (!col_ok || row >= mvalid) continue;
+        f32x4 v0 = load4(cs + row * LD + c8), v1 = load4(cs + row * LD + c8 + 4);
+        epi_row8(e, (unsigned)(m0 + row), n0 + c8, v0, v1, b0, b1);   // v0 / v1 come back as stored
+        s0 += v0;
+        s1 += v1;
+    }
+    if (e.colpart) {       // column sums of this tile: the RP row-threads of a column group -- in-wave by shuffles, the four waves via LDS
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float t = cs[j][c];
-                t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
-                cs[j][c] = t;
-            }
-            if (lr == 0) store4(sc + wr * Cfg::BN + wc * (16 * NT) + 16 * j + g4, cs[j]);
+        for (int j = 0; j < 4; ++j) {
+            if (CG == 8) { s0[j] += __shfl_xor(s0[j], 8, 64); s1[j] += __shfl_xor(s1[j], 8, 64); }
+            s0[j] += __shfl_xor(s0[j], 16, 64); s0[j] += __shfl_xor(s0[j], 32, 64);
+            s1[j] += __shfl_xor(s1[j], 16, 64); s1[j] += __shfl_xor(s1[j], 32, 64);
+        }
+        __syncthreads();                                              // the staging image has been read
+        float* cp = reinterpret_cast<float*>(smem);                    // [4 waves][BN]
+        if (lane < CG) {
+            store4(cp + wid * Cfg::BN + c8, s0);
+            store4(cp + wid * Cfg::BN + c8 + 4, s1);
         }
         __syncthreads();
-        for (int c = threadIdx.x; c < nvalid; c += 256) e.colpart[(int64_t)tm * e.N + n0 + c] = sc[c] + sc[Cfg::BN + c];
+        for (int c = threadIdx.x; c < nvalid; c += 256)
+            e.colpart[(int64_t)tm * e.N + n0 + c] = ((cp[c] + cp[Cfg::BN + c]) + cp[2 * Cfg::BN + c]) + cp[3 * Cfg::BN + c];
     }
 }
 
