@@ -96,6 +96,34 @@ __device__ __forceinline__ void blk_commit(const BlkRegs<HD>& r, char* img) {
     }
 }
 
+// Output staging: gradients / outputs leave through LDS as whole rows.  A lane of an accumulator tile owns 4 bf16 of one row, so a
+// direct store instruction writes 32-byte pieces of 16 rows; staged over a dead operand image, eight lanes write one 128-byte row
+// with 16 bytes each (T = 64 backward: 53.8 -> 43.5 us).  Tile layout: [rows][2 HD bytes] (HD 96: the images' 208-byte pitch), 16-byte
+// chunk c of row r at c ^ (r & 7).
+template <int HD>
+__device__ __forceinline__ int out_off(int r, int c16) {
+    return HD == 96 ? r * 208 + 16 * c16 : r * (2 * HD) + ((c16 ^ (r & (HD / 8 < 8 ? HD / 8 - 1 : 7))) << 4);
+}
+// this wave's 16 rows r16 .. r16 + 15 of a staged tile: lane (li, g) -> row r16 + li, columns 16 dt + 4 g ..
+template <int HD, int DT>
+__device__ __forceinline__ void out_stage16(char* dst, int r16, const f32x4 (&acc)[DT], int lane) {
+    const int r = r16 + (lane & 15), g = lane >> 4;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        const bf16x4 w = {(bf16_t)acc[dt][0], (bf16_t)acc[dt][1], (bf16_t)acc[dt][2], (bf16_t)acc[dt][3]};
+        *reinterpret_cast<bf16x4*>(dst + out_off<HD>(r, 2 * dt + (g >> 1)) + 8 * (g & 1)) = w;
+    }
+}
+// all 256 threads: `rows` staged rows -> global rows g + r * stride, 16 bytes per access, channels < hd only
+template <int HD>
+__device__ __forceinline__ void out_flush(const char* src, int rows, bf16_t* __restrict__ g, int64_t stride, int hd) {
+    constexpr int CPR = HD / 8;
+    for (int idx = threadIdx.x; idx < rows * CPR; idx += 256) {
+        const int r = idx / CPR, c16 = idx - r * CPR;
+        if (8 * c16 < hd) *reinterpret_cast<bf16x8*>(g + (int64_t)r * stride + 8 * c16) = *reinterpret_cast<const bf16x8*>(src + out_off<HD>(r, c16));
+    }
+}
+
 // 16 rows x 32 k (k = channel), rows r0.., k-step s: the natural A (or B) fragment
 template <int HD>
 __device__ __forceinline__ bf16x8 frag_rows(const char* img, int r0, int s, int lane) {
@@ -289,16 +317,18 @@ attn_fwd_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __rest
             }
         }
     }
+    __syncthreads();                                              // every wave is done with the Q / K / V images: O is staged over Q
 #pragma unroll
     for (int u = 0; u < QG; ++u) {
         const float inv = 1.f / l[u];
-        const int qi = qb + 16 * (QG * wid + u) + (lane & 15);
-        bf16_t* orow = o + b * a.o_sb + h * a.o_sh + (int64_t)qi * a.o_st + 4 * (lane >> 4);
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-            if (16 * dt + 4 * (lane >> 4) < a.hd) store4(orow + 16 * dt, ot[u][dt] * inv);
+        for (int dt = 0; dt < DT; ++dt) ot[u][dt] *= inv;
+        out_stage16<HD, DT>(qimg, 16 * (QG * wid + u), ot[u], lane);
+        const int qi = qb + 16 * (QG * wid + u) + (lane & 15);
         if ((lane >> 4) == 0) lse[(int64_t)bh * a.T + qi] = m[u] * 0.6931471805599453f + __logf(l[u]);   // back to the natural log
     }
+    __syncthreads();
+    out_flush<HD>(qimg, 64 * QG, o + b * a.o_sb + h * a.o_sh + (int64_t)qb * a.o_st, a.o_st, a.hd);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -407,16 +437,13 @@ attn_bwd_dq_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __r
             }
         }
     }
+    __syncthreads();                                              // the Q / dO images are dead (their fragments sit in registers): dq over Q
 #pragma unroll
-    for (int u = 0; u < G; ++u) {
-        bf16_t* row = dq + base + (int64_t)qi[u] * a.q_st + 4 * g;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-            if (16 * dt + 4 * g < a.hd) store4(row + 16 * dt, acc[u][dt]);
-    }
+    for (int u = 0; u < G; ++u) out_stage16<HD, DT>(qimg, 64 * u + 16 * wid, acc[u], lane);
+    __syncthreads();
+    out_flush<HD>(qimg, 64 * G, dq + base + (int64_t)qb * a.q_st, a.q_st, a.hd);
     if (cs_part) {     // per-(sample, query block) column sums of dq -> cs_part[b * gridDim.x + block][0 * H hd + h hd + c]
-        __syncthreads();                          // the K / V images are free now: reuse the first one as scratch
-        float* cs = reinterpret_cast<float*>(smem);
+        float* cs = reinterpret_cast<float*>(gimg);                   // (the dO images are dead too; the staged dq tile sits in the Q images)
         f32x4 t[DT];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {         // groups folded in order, each value rounded as stored
@@ -447,7 +474,7 @@ attn_bwd_dkv_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __
     float* lse_s = reinterpret_cast<float*>(gimg + IMG);
     float* del_s = lse_s + 64;
     const float c2 = a.scale * 1.4426950408889634f;
-    const int lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
+    const int lane = threadIdx.x & 63, g = lane >> 4;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
     const int jb = blockIdx.x * 64 * G;
@@ -543,19 +570,17 @@ attn_bwd_dkv_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __
             }
         }
     }
+    __syncthreads();                                              // the K / V images are dead (fragments in registers): dk over K, dv over V
 #pragma unroll
     for (int u = 0; u < G; ++u) {
-        const int64_t off = base + (int64_t)(jb + 64 * u + 16 * wid + li) * a.q_st + 4 * g;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            if (16 * dt + 4 * g >= a.hd) continue;
-            store4(dv + off + 16 * dt, av[u][dt]);
-            store4(dk + off + 16 * dt, ak[u][dt]);
-        }
+        out_stage16<HD, DT>(kimg, 64 * u + 16 * wid, ak[u], lane);
+        out_stage16<HD, DT>(vimg, 64 * u + 16 * wid, av[u], lane);
     }
+    __syncthreads();
+    out_flush<HD>(kimg, 64 * G, dk + base + (int64_t)jb * a.q_st, a.q_st, a.hd);
+    out_flush<HD>(vimg, 64 * G, dv + base + (int64_t)jb * a.q_st, a.q_st, a.hd);
     if (cs_part) {     // per-(sample, key block) column sums of dk | dv -> columns H hd + h hd + c and 2 H hd + h hd + c
-        __syncthreads();                          // the Q / dO images are free now
-        float* cs = reinterpret_cast<float*>(qimg);                    // [2][4 waves][HD] floats <= 2 images
+        float* cs = reinterpret_cast<float*>(qimg);                    // [2][4 waves][HD] floats <= 2 images (Q / dO: dead after the last block's barrier above)
         f32x4 tk[DT], tv[DT];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
