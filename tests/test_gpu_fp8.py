@@ -279,8 +279,11 @@ def test_ln_bwd_gate_fp8_matches_the_pair(fmt, B, T, D):
         dx, part = torch.empty(M, D, device=DEV), torch.empty(B, D, device=DEV)
         a = (ptr(dout), ptr(x), ptr(mean), ptr(rstd), ptr(mod) + 4 * 4 * D, 6 * D, ptr(dres), ptr(dx), ptr(dmod) + 4 * 3 * D,
              ptr(dmod) + 4 * 4 * D, 6 * D)
-        if fused:
-            ops.ln_modulate_bwd_gate_fp8(*a, ptr(y), ptr(mod) + 4 * 5 * D, f, ptr(dmod) + 4 * 5 * D, B, T, D, ptr(part))
+        if fused:       # the C entry point itself (ops.ln_modulate_bwd_gate_fp8 sends rows wider than 768 to the pair)
+            ws = ops._row_ws(B, T, D)
+            ops.check(vaw_amd._lib.lib().vaw_ln_modulate_bwd_gate_fp8(*a, ptr(y), ptr(mod) + 4 * 5 * D, f.epilogue_target(2), f.state.data_ptr(),
+                                                                     f.fmt, ptr(dmod) + 4 * 5 * D, ptr(part), B, T, D, ws.data_ptr(), ws.numel(),
+                                                                     vaw_amd._lib.stream_ptr()), "vaw_ln_modulate_bwd_gate_fp8")
         else:
             ops.ln_modulate_bwd(BF, *a, B, T, D)
             ops.gate_bwd_fp8(ptr(dx), ptr(y), ptr(mod) + 4 * 5 * D, 6 * D, f, ptr(dmod) + 4 * 5 * D, 6 * D, B, T, D, ptr(part))

@@ -465,8 +465,10 @@ def test_ln_modulate_bwd_fused_with_gate_bwd_is_bitwise_the_pair(dtype, B, T, D)
         dx, dy, part = torch.empty(B * T, D, device=DEV), torch.empty(B * T, D, device=DEV, dtype=dtype), torch.empty(B, D, device=DEV)
         a = (dt, ptr(dout), ptr(x), ptr(mean), ptr(rstd), ptr(mod) + 4 * 4 * D, 6 * D, ptr(dres), ptr(dx), ptr(dmod) + 4 * 3 * D,
              ptr(dmod) + 4 * 4 * D, 6 * D)
-        if fused:
-            ops.ln_modulate_bwd_gate(*a, ptr(y), ptr(mod) + 4 * 5 * D, ptr(dy), ptr(dmod) + 4 * 5 * D, B, T, D, ptr(part))
+        if fused:       # the C entry point itself (ops.ln_modulate_bwd_gate sends rows wider than 768 to the pair)
+            ws = ops._row_ws(B, T, D)
+            ops.check(lib().vaw_ln_modulate_bwd_gate(*a, ptr(y), ptr(mod) + 4 * 5 * D, ptr(dy), ptr(dmod) + 4 * 5 * D, ptr(part), B, T, D,
+                                                     ws.data_ptr(), ws.numel(), stream_ptr()), "vaw_ln_modulate_bwd_gate")
         else:
             ops.ln_modulate_bwd(*a, B, T, D)
             ops.gate_bwd(dt, ptr(dx), ptr(y), ptr(mod) + 4 * 5 * D, 6 * D, ptr(dy), ptr(dmod) + 4 * 5 * D, 6 * D, B, T, D, ptr(part))
