@@ -327,6 +327,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-trace", action="store_true", help="skip the extra (untimed) steps that bracket GEMM launches with HIP events")
     ap.add_argument("--fp32", action="store_true", help="parity-mode kernels (not the headline number)")
+    ap.add_argument("--shape-table", default=None, metavar="FILE", help="also write the traced launches per (variant, M, N, K): launches, total us, TFLOP/s")
     ap.add_argument("--graph", action="store_true", help="capture the step into one hipGraph (Trainer args.hip_graph); implies --no-trace")
     ap.add_argument("--no-graph", action="store_true", help="never capture (default: the Trainer decides -- args.hip_graph='auto' -- on one GPU: "
                                                             "a launch-bound step is captured, a GPU-bound one stays eager)")
@@ -444,6 +445,11 @@ def main():
             rec["config"]["step_mfma_util_vs_2.5PF"] = round(ips / world * wl["gflop_per_img"] / 1e3 / BF16_MFMA_PEAK_TFLOPS, 4)
         if trace is not None:
             summ = trace.summarize()
+            if a.shape_table:
+                with open(a.shape_table, "w") as fh:
+                    for name, shape, n, t_ms, flop in trace.by_shape():
+                        fh.write(f"{name:24s} {str(shape):28s} {n / traced_steps:7.1f}/step {1e3 * t_ms / n:9.1f} us  {flop / t_ms / 1e9 if t_ms > 0 else 0:8.1f} TFLOP/s"
+                                 f"  {t_ms / traced_steps:8.3f} ms/step\n")
             f8 = bool(wl.get("fp8")) and not a.fp32
             fast = {k: v for k, v in summ.items() if k.startswith("fp8_mfma" if f8 else "bf16_mfma")}
             if fast:

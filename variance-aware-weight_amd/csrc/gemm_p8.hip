@@ -111,6 +111,8 @@ void vaw_p8_launch(const P8Plan& pl, int a_kmajor, int b_kmajor, int64_t M, int6
     else if (e.act == 0 && e.gate && e.resid && !e.resid_act && e.aux_out && !e.rowadd && e.out_f32 && e.beta == 0.f && !e.colpart)
         L.epi = P8_GATE;
     else if (e.act == 0 && !e.aux_out && !e.gate && !e.resid && !e.rowadd && e.beta == 0.f) L.epi = P8_STORE;
+    else if (a_kmajor && b_kmajor && e.act == 0 && !e.aux_out && !e.gate && e.resid && e.resid_act && !e.rowadd && bf16_out && e.beta == 0.f && !e.colpart)
+        L.epi = P8_RESID;           // 1x1 convs with a fused skip add (UNet attention proj_out): P8_ANY ran them at 2.6x the time of the plain store
     else L.epi = P8_ANY;
     if (a_kmajor && b_kmajor) p8_launch_fwd(L, e, s);
     else if (a_kmajor && !b_kmajor) p8_launch_dgrad(L, e, s);

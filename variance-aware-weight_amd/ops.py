@@ -372,7 +372,7 @@ def conv3x3(dt, mode, act, act2, w, out, B, H, W, Ci, Co, *, bias=None, resid=No
         e1.record()
         M = B * H * W
         nb = 2 * M * (Ci + Co) + (2 if mode != 2 else 4 * (2 if beta else 1)) * 9 * Ci * Co + ((2 * M * Co) if (mode == 0 and resid) else 0)
-        tr.add(1, mode != 2, mode == 0, *((M, Co, 9 * Ci) if mode == 0 else (M, Ci, 9 * Co) if mode == 1 else (Co, 9 * Ci, M)), e0, e1, float(nb))
+        tr.add(1, mode != 2, mode == 0, *((M, Co, 9 * Ci) if mode == 0 else (M, Ci, 9 * Co) if mode == 1 else (Co, 9 * Ci, M)), e0, e1, float(nb), tag=f"conv{H}x{W}")
     return True
 
 
@@ -388,17 +388,31 @@ class GemmTrace:
     def events(self):
         return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
-    def add(self, mfma, ak, bk, M, N, K, e0, e1, nbytes=0.0):
-        self.rows.append((mfma, ak, bk, 2.0 * M * N * K, e0, e1, nbytes))
+    def add(self, mfma, ak, bk, M, N, K, e0, e1, nbytes=0.0, tag="gemm"):
+        self.rows.append((mfma, ak, bk, 2.0 * M * N * K, e0, e1, nbytes, (tag, int(M), int(N), int(K))))
 
     def add_flop(self, mfma, ak, bk, flop, e0, e1, nbytes=0.0):
-        self.rows.append((mfma, ak, bk, flop, e0, e1, nbytes))
+        self.rows.append((mfma, ak, bk, flop, e0, e1, nbytes, None))
+
+    @staticmethod
+    def _name(mfma, ak, bk):
+        return ("fp8_mfma" if mfma == 2 else "bf16_mfma" if mfma else "generic_f32mfma") + ("/fwd" if ak and bk else "/dgrad" if ak else "/wgrad")
+
+    def by_shape(self):
+        """-> [(variant, (M, N, K) or None, launches, ms, flop)] sorted by time, after a device synchronize (bench.py --shape-table)."""
+        acc = {}
+        for mfma, ak, bk, flop, e0, e1, nbytes, shape in self.rows:
+            d = acc.setdefault((self._name(mfma, ak, bk), shape), [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += e0.elapsed_time(e1)
+            d[2] += flop
+        return sorted(((k[0], k[1], v[0], v[1], v[2]) for k, v in acc.items()), key=lambda r: -r[3])
 
     def summarize(self):
         """-> {variant: {launches, flop, ms}} after a device synchronize."""
         out = {}
-        for mfma, ak, bk, flop, e0, e1, nbytes in self.rows:
-            name = ("fp8_mfma" if mfma == 2 else "bf16_mfma" if mfma else "generic_f32mfma") + ("/fwd" if ak and bk else "/dgrad" if ak else "/wgrad")
+        for mfma, ak, bk, flop, e0, e1, nbytes, _shape in self.rows:
+            name = self._name(mfma, ak, bk)
             d = out.setdefault(name, {"launches": 0, "flop": 0.0, "ms": 0.0, "bytes": 0.0})
             d["launches"] += 1
             d["flop"] += flop
