@@ -190,6 +190,11 @@ def _zero_worker(rank, world, port, q):
             rngs = ddp.bucket_ranges()
             assert rngs[0][0] == 0 and rngs[-1][1] == m._flat_n_train and all(a[1] == b[0] for a, b in zip(rngs, rngs[1:]))
             assert any(isinstance(v, list) for v in ddp._ranges.values()), "expected the split adaLN stage"
+            # the sharded optimizer's all-gathers go out in FORWARD order (embedders + adaLN first, blocks ascending, head last)
+            # and cover exactly the buckets
+            st = ddp.gather_stages()
+            assert [k for k, _ in st] == [0, "ada_hi"] + list(range(1, m.depth + 2))
+            assert sorted(r for _, rs in st for r in rs) == rngs
             opt = vaw_amd.FusedAdamW(m, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.01)
             ema_model = build() if rank == 0 else None
             if shard:

@@ -15,6 +15,7 @@ from vaw_amd import ops  # noqa: E402
 from vaw_amd._lib import BF16, ptr  # noqa: E402
 
 SHAPES = {  # (B, H, Ci, Co)
+    "small": [(128, 8, 384, 384), (128, 8, 768, 384), (128, 16, 384, 384), (64, 8, 384, 384), (32, 16, 384, 384)],
     "unet64": [(128, 64, 192, 192), (128, 32, 192, 384), (128, 32, 384, 384), (128, 16, 384, 384), (128, 8, 384, 384),
                (128, 16, 768, 384), (128, 32, 768, 384), (128, 64, 576, 192), (128, 64, 384, 192)],
     "adm64": [(256, 64, 192, 192), (256, 32, 192, 384), (256, 32, 384, 384), (256, 16, 384, 576), (256, 16, 576, 576),

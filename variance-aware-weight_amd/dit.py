@@ -325,6 +325,15 @@ class DiT(FlatModule):
         return out, None
 
     # ---- engine ----------------------------------------------------------------------------
+    stagewise_weight_waits = True      # parallel.DistributedDataParallel (sharded optimizer): forward asks for its weights per stage
+
+    def _need(self, stage):
+        """The gathered weights of gradient stage `stage` (grad_stage_bounds) are about to be read: with a sharded optimizer the
+        all-gather that brings them may still be in flight on the collective stream."""
+        z = getattr(self, "_zero", None)
+        if z is not None:
+            z.wait_stage(stage)
+
     def _w(self, name):
         """device address of a parameter in the dtype the kernels read (bf16 shadow or f32 master)."""
         o, _ = self._flat_offsets[name]
@@ -411,6 +420,7 @@ class DiT(FlatModule):
             y = torch.where(drop, ye.num_classes, y)
         ws.y = y.contiguous()
         # conditioning vector c = t_emb + y_emb, then every block's modulation in one GEMM
+        self._need(0)
         L.check(lib.vaw_timestep_embedding(dt, ptr(tf), ptr(ws.tfreq), B, 256, 10000.0, st), "timestep_embedding")
         ops.gemm(dt, 1, 1, B, D, 256, ptr(ws.tfreq), 256, self._w("t_embedder.mlp.0.weight"), 256, ptr(ws.h1), D,
                  bias=self._p32("t_embedder.mlp.0.bias"), out_f32=True)
@@ -420,6 +430,7 @@ class DiT(FlatModule):
         L.check(lib.vaw_add_embedding(ptr(ws.temb), self._p32("y_embedder.embedding_table.weight"), ptr(ws.y), ptr(ws.c),
                                       B, D, ye.embedding_table.num_embeddings, st), "add_embedding")
         L.check(lib.vaw_silu_fwd(dt, ptr(ws.c), ptr(ws.cs), B * D, st), "silu")
+        self._need("ada_hi")
         ops.gemm(dt, 1, 1, B, ld, D, ptr(ws.cs), D, self._w("blocks.0.adaLN_modulation.1.weight"), D, ptr(ws.mod), ld,
                  bias=self._p32("blocks.0.adaLN_modulation.1.bias"), out_f32=True)
         # tokens
@@ -431,6 +442,7 @@ class DiT(FlatModule):
             b, pre = ws.blk[l], f"blocks.{l}."
             mo = mod + 4 * (6 * l * D)
             xin, xmid, xout = ptr(ws.xres[2 * l]), ptr(ws.xres[2 * l + 1]), ptr(ws.xres[2 * l + 2])
+            self._need(l + 1)
             fuse_rows = ws.fp8 and ws.d_fwd and self.fp8_fuse_epilogue and self.fp8_fuse_rows and M % 64 == 0 and D % 128 == 0    # LN writes fp8 itself
             if fuse_rows:
                 ops.ln_modulate_fwd_fp8(xin, mo, mo + 4 * D, ld, b["f_xm"], ptr(b["mean1"]), ptr(b["rstd1"]), B, T, D)
@@ -452,6 +464,7 @@ class DiT(FlatModule):
             self._linear_fwd(ws, b, "f_a", None if fuse_a else b["a"], pre + "mlp.fc2.", M, D, Dm, xout, D, aux_out=ptr(b["y2"]),
                              gate=mo + 4 * 5 * D, gate_ld=ld, resid=xmid, rows_per_batch=T, out_f32=True)
         mo = mod + 4 * (6 * Lyr * D)
+        self._need(Lyr + 1)
         ops.ln_modulate_fwd(dt, ptr(ws.xres[2 * Lyr]), mo, mo + 4 * D, ld, ptr(ws.xf), ptr(ws.meanf), ptr(ws.rstdf), B, T, D)
         ops.gemm(dt, 1, 1, M, self.No, D, ptr(ws.xf), D, self._w("final_layer.linear.weight"), D, ptr(ws.otok), self.No,
                  bias=self._p32("final_layer.linear.bias"), out_f32=True)

@@ -116,16 +116,24 @@ class FusedAdamW(torch.optim.Optimizer):
             off += k
         # the weights the kernels read: the bf16 shadow in throughput mode (2 B per parameter on the wire; the f32 masters of
         # other ranks' chunks go stale until consolidate()), the f32 parameters in parity mode
-        if shadow is not None:
-            z.all_gather_chunks(shadow)
+        if shadow is not None and not getattr(m, "_fp8", False):
+            # (the small f32 all-reduce first: collectives of one group run in issue order, and the forward that follows waits
+            # for this one at once but for the gathered buckets only as it reaches them)
             self._sync_f32_read_params()
+            z.all_gather_chunks(shadow)
             self.master_stale = True
         else:
+            # f32 parity mode, and fp8 mode (whose e4m3 weight copies are quantised from the f32 masters)
             z.all_gather_chunks(m._flat)
+            if shadow is not None:
+                z.wait_gathers()                  # (the bf16 shadow is re-cast from the gathered masters by the next forward)
         if self._ema_shard is not None and self._ema_frozen is not None:
             n = m._flat_n_train
             ops.ema_update(self._ema_frozen._flat[n:], m._flat[n:], self.ema_decay)
-        m.mark_shadow_fresh()
+        if shadow is None or not getattr(m, "_fp8", False):
+            m.mark_shadow_fresh()
+        else:
+            m.mark_weights_changed()
         self.ema_done_in_step = self._ema_shard is not None
 
     def _sync_f32_read_params(self):

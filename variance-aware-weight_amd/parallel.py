@@ -75,7 +75,9 @@ class DistributedDataParallel(nn.Module):
         import os
         explicit = "VAW_DDP_RESERVE_CUS" in os.environ        # (set explicitly it also applies to a gloo rehearsal: tests)
         self._reserve = int(os.environ.get("VAW_DDP_RESERVE_CUS", "64")) if (self._cuda and (self._backend_avg or explicit)) else 0
-        self._reserved_now = False
+        self._reserved_now = False            # ... for the reduce-scatters / all-reduces of a backward in flight
+        self._reserved_gather = False         # ... for the all-gathers of the sharded optimizer that overlap the next forward
+        self._gather_events, self._gather_waiting = {}, []
         module.grad_ready_hook = self._on_stage
 
     # stage -> (start, end) element range of the flat gradient buffer that is final once `stage` fires
@@ -101,7 +103,13 @@ class DistributedDataParallel(nn.Module):
     def forward(self, *args, **kwargs):
         if self._reserved_now or self._pending or self._issued:
             self._abandon()          # a backward that raised never reached finish(): do not run the next step on its leftovers
+        if self._gather_waiting and not getattr(self.module, "stagewise_weight_waits", False):
+            self.wait_gathers()      # the module does not ask for its weights stage by stage (wait_stage): all of them, now
         return self.module(*args, **kwargs)
+
+    def _apply_reservation(self):
+        from . import _lib
+        _lib.lib().vaw_p8_set_reserved_cus(self._reserve if (self._reserved_now or self._reserved_gather) else 0)
 
     @property
     def reserved_cus(self):
@@ -117,9 +125,8 @@ class DistributedDataParallel(nn.Module):
                 pass
         self._pending, self._issued = [], 0
         if self._reserved_now:
-            from . import _lib
-            _lib.lib().vaw_p8_set_reserved_cus(0)
             self._reserved_now = False
+            self._apply_reservation()
 
     @contextmanager
     def no_sync(self):
@@ -186,9 +193,8 @@ class DistributedDataParallel(nn.Module):
                 continue
             g = self.module.flat_grads()[lo:hi]
             if self._reserve and not self._reserved_now:
-                from . import _lib
-                _lib.lib().vaw_p8_set_reserved_cus(self._reserve)
                 self._reserved_now = True
+                self._apply_reservation()
             if self._cuda:
                 ev = self._events[self._issued % len(self._events)]
                 self._issued += 1
@@ -208,29 +214,71 @@ class DistributedDataParallel(nn.Module):
         if stage == 0:
             self.finish()
 
+    def gather_stages(self):
+        """[(stage, [bucket ranges])] in the order a FORWARD pass first reads the parameters: stage 0 (embedders; DiT: + the
+        packed adaLN matrix, whose late rows are stage "ada_hi") -> the stages in ascending order (DiT: block l is stage l + 1,
+        the head depth + 1; UNet: middle_block 2, decoder 3)."""
+        keys = sorted((k for k in self._ranges if isinstance(k, int)))
+        named = [k for k in self._ranges if not isinstance(k, int)]
+        order = keys[:1] + named + keys[1:] if keys and keys[0] == 0 else named + keys
+        out = []
+        for k in order:
+            r = self._ranges[k]
+            rs = [tuple(x) for x in (r if isinstance(r, list) else [r]) if x[1] > x[0]]
+            if rs:
+                out.append((k, sorted(rs)))
+        return out
+
     def all_gather_chunks(self, flat, async_stream=True):
         """shard_optimizer: every rank has rewritten its chunk of each bucket of `flat` (a full-length flat buffer: bf16 shadow
         or f32 parameters); all-gather the buckets so that every rank holds all of it again.  On the GPU the collectives run on
-        the side stream behind the current one; call wait_gathers() before the buffer is read."""
-        def gather():
-            for lo, hi in self.bucket_ranges():
-                c = (hi - lo) // self.world
-                src = flat[lo + self.rank * c: lo + (self.rank + 1) * c]
-                if not self._backend_avg:
-                    src = src.clone()                 # gloo: no in-place form
-                dist.all_gather_into_tensor(flat[lo:hi], src, group=self.pg)
+        the side stream behind the current one, stage by stage in the order the next forward reads the weights, each stage with
+        its own event: a module that sets `stagewise_weight_waits` calls wait_stage(k) right before its first read of stage k
+        (vaw_amd.DiT: only the embedder / adaLN stage is waited for at the start of the step, the blocks' weights arrive under
+        the forward of the blocks before them); everybody else gets wait_gathers() from forward().  Synchronous otherwise."""
+        def gather(record):
+            for k, rngs in self.gather_stages():
+                for lo, hi in rngs:
+                    c = (hi - lo) // self.world
+                    src = flat[lo + self.rank * c: lo + (self.rank + 1) * c]
+                    if not self._backend_avg:
+                        src = src.clone()                 # gloo: no in-place form
+                    dist.all_gather_into_tensor(flat[lo:hi], src, group=self.pg)
+                if record:
+                    ev = self._gather_events.get(k)
+                    if ev is None:
+                        ev = self._gather_events[k] = torch.cuda.Event()
+                    ev.record()
+                    self._gather_waiting.append(k)
         if self._cuda and async_stream:
+            self.wait_gathers()                           # (a second gather before anybody read the first: keep the events simple)
             self._comm.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._comm):
-                gather()
-            self._gathers_pending = True
+                gather(True)
+            if self._reserve and not self._reserved_gather:
+                self._reserved_gather = True              # RCCL's kernels run beside the forward now: leave them their CUs
+                self._apply_reservation()
         else:
-            gather()
+            gather(False)
+
+    def wait_stage(self, stage):
+        """The current stream waits until the gathered weights of `stage` (and of every stage gathered before it) have arrived."""
+        if stage in self._gather_waiting:
+            torch.cuda.current_stream().wait_event(self._gather_events[stage])
+            del self._gather_waiting[: self._gather_waiting.index(stage) + 1]
+            if not self._gather_waiting:
+                self._gathers_done()
 
     def wait_gathers(self):
-        if getattr(self, "_gathers_pending", False):
+        if self._gather_waiting:
             torch.cuda.current_stream().wait_stream(self._comm)
-            self._gathers_pending = False
+            self._gather_waiting = []
+            self._gathers_done()
+
+    def _gathers_done(self):
+        if self._reserved_gather:
+            self._reserved_gather = False
+            self._apply_reservation()
 
     def finish(self):
         """Retire every outstanding bucket and make the compute stream wait for the side stream (end of backward)."""
@@ -246,6 +294,5 @@ class DistributedDataParallel(nn.Module):
         self._pending = []
         self._issued = 0
         if self._reserved_now:
-            from . import _lib
-            _lib.lib().vaw_p8_set_reserved_cus(0)
             self._reserved_now = False
+            self._apply_reservation()
