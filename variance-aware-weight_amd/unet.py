@@ -587,6 +587,9 @@ class UNetModel(FlatModule):
 
     def _forward_body(self, x, t, y, need_dx):
         self.ensure_flat()
+        z = getattr(self, "_zero", None)
+        if z is not None:
+            z.wait_gathers()         # sharded optimizer: the gathered weights may still be arriving on the collective stream
         dt, lib, st = self._dt, L.lib(), L.stream_ptr()
         self._adt = L.TORCH_DTYPE[dt]
         if dt == BF16:
