@@ -58,6 +58,13 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 #ifndef P8_PH2
 #define P8_PH2 0
 #endif
+// steps the epilogue's operand loads (residual, GELU' argument, gate) run ahead of their use
+// (0 = by epilogue kind: 3 for the GELU' input gradient, whose one 16-byte operand per step is the cheapest to hold, 2 otherwise.
+//  Measured on the DiT-B/4 launches, one box, interleaved: depth 1 -> 2 -> 3: GELU' input gradient 111.0 -> 104.7 -> 102.4 us,
+//  gated fc2 forward 99.4 -> 99.7 -> 97.0, step 13.42 -> 13.33 -> 13.37 ms; depth 3 spills 8 bytes in the 256-column gated kernel)
+#ifndef P8_EPI_PD
+#define P8_EPI_PD 0
+#endif
 #define P8_BM 256
 #define P8_PART 8192
 #define P8_EPI_BYTES 32768
@@ -693,13 +700,39 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
         const int64_t mrow0 = m0 + wr * 128 + rd_row;
         const unsigned rpb = (unsigned)ei.rpb;
         unsigned smp = 0, rin = 0;
-        EpiOps ops[2];
+        // operand loads run PD steps ahead of the step that uses them (ring of PD + 1 operand sets).  vmcnt retires in order and
+        // counts stores: the wait for step k's operands also waits for every store issued before their load, i.e. for the stores
+        // of step k - PD - 1 and older -- the depth is the slack the stores get to be acknowledged
+        constexpr int PD = P8_EPI_PD > 0 ? P8_EPI_PD : (EPI == P8_DGELU || EPI == P8_DGELU_Q) ? 3 : 2;
+        EpiOps ops[PD + 1];
         const bool with_ops = EK::loads && (EK::act2(ei) || EK::gate(ei) || EK::resid(ei) || EK::rowadd(ei));
+        int64_t m_ld = mrow0;                // row of the next operand load
+        auto load_next = [&](EpiOps& dst, bool first) {
+            if (first) {
+                const int64_t mc = m_ld < m_last ? m_ld : m_last;
+                smp = (unsigned)mc / rpb;
+                rin = (unsigned)mc % rpb;
+                epi_load8<EPI>(ei, (unsigned)mc, n_ld, smp, rin, dst);
+                return;
+            }
+            int64_t mn = m_ld + 8;
+            m_ld = mn;
+            if (mn <= m_last) {
+                rin += 8;
+                if (rin >= rpb) {
+                    if (rpb >= 8) { rin -= rpb; smp += 1; }
+                    else { smp += rin / rpb; rin %= rpb; }
+                }
+            } else {
+                mn = m_last;                 // beyond the edge: any valid row (its result is not stored)
+                smp = (unsigned)mn / rpb;
+                rin = (unsigned)mn % rpb;
+            }
+            epi_load8<EPI>(ei, (unsigned)mn, n_ld, smp, rin, dst);
+        };
         if (with_ops) {
-            const int64_t mc = mrow0 < m_last ? mrow0 : m_last;
-            smp = (unsigned)mc / rpb;
-            rin = (unsigned)mc % rpb;
-            epi_load8<EPI>(ei, (unsigned)mc, n_ld, smp, rin, ops[0]);
+#pragma unroll
+            for (int d = 0; d < PD; ++d) load_next(ops[d], d == 0);
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -710,21 +743,8 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
             for (int pass = 0; pass < 2; ++pass) {
                 const int k = 2 * i + pass;
                 const int64_t m = mrow0 + 8 * k;
-                if (with_ops && k + 1 < 16) {        // operands of the next step: in flight while this step computes and stores
-                    int64_t mn = m + 8;
-                    if (mn <= m_last) {
-                        rin += 8;
-                        if (rin >= rpb) {
-                            if (rpb >= 8) { rin -= rpb; smp += 1; }
-                            else { smp += rin / rpb; rin %= rpb; }
-                        }
-                    } else {
-                        mn = m_last;                 // beyond the edge: any valid row (its result is not stored)
-                        smp = (unsigned)mn / rpb;
-                        rin = (unsigned)mn % rpb;
-                    }
-                    epi_load8<EPI>(ei, (unsigned)mn, n_ld, smp, rin, ops[(k + 1) & 1]);
-                }
+                if (with_ops && k + PD < 16)         // operands of step k + PD: in flight while the steps before it compute and store
+                    load_next(ops[(k + PD) % (PD + 1)], false);
                 f32x4 v0, v1;
                 asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
                              : "=&v"(v0), "=&v"(v1)
@@ -740,7 +760,7 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
                     buf_store16(rs_c, ok ? bo + 16u : EPI_OOB, v1, false);
                 } else {
                     const int64_t mc = m <= m_last ? m : m_last;
-                    epi_apply8<EPI>(ei, rs_c, rs_aux, loc, (const float*)ei.C + mc * ei.ldc + n_ld, v0, v1, b0, b1, ops[k & 1], qmax);
+                    epi_apply8<EPI>(ei, rs_c, rs_aux, loc, (const float*)ei.C + mc * ei.ldc + n_ld, v0, v1, b0, b1, ops[k % (PD + 1)], qmax);
                     if (EK::may_colsum) {      // unconditional arithmetic (a run-time condition here makes the compiler keep
                                                // all 16 steps' values alive and sum them at the end: spills)
                         const f32x4 z = {0, 0, 0, 0};
