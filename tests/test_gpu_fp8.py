@@ -56,7 +56,7 @@ def test_quantize_bytes_and_transpose(dtype, R, C, fmt):
     assert torch.equal(f3.q.cpu(), (x3 * (torch.tensor(1.0) / s3)).to(E).view(torch.uint8))
 
 
-@pytest.mark.parametrize("R,C", [(520, 328), (576, 384)])        # generic kernel | the 64 x 128 tiled kernel of the training shapes
+@pytest.mark.parametrize("R,C", [(520, 328), (576, 384), (640, 384)])        # generic kernel | the 64 x 128 | the 128 x 128 tiled kernel (training shapes)
 @pytest.mark.parametrize("fmt", ["e4m3", "e5m2"])
 def test_quantize_delayed_scaling_state(fmt, R, C):
     """vaw_fp8_quantize_delayed + vaw_fp8_scale_update: bytes = cast(clamp(x / scale)) with the scale in the state, the state's

@@ -246,26 +246,18 @@ fp8_transpose_kernel(const unsigned char* __restrict__ q, int64_t ldq, unsigned 
     }
 }
 
-// The same for R % 128 == 0 and 16-byte aligned rows on both sides: 128 x 128-byte tiles, 16 bytes per lane in AND out.  The small
-// kernel above reads 8 and writes 4 bytes per lane in 64-byte runs and reaches 2.5 TB/s; the step runs 6 such transposes per
-// DiT block (149 launches, 4.6 ms of the DiT-XL/2 fp8 step).  Thread (cq = 4-column group, r16 = 16-row group) gathers the
-// 16 x 4 byte block rows r16 .. r16 + 15, columns 4 cq .. 4 cq + 3 from LDS (16 words), transposes it with v_perm_b32 (four 4 x 4
-// byte transposes) and stores four 16-byte row segments of the output.
-__global__ void __launch_bounds__(256)
-fp8_transpose128_kernel(const unsigned char* __restrict__ q, int64_t ldq, unsigned char* __restrict__ qt, int64_t ldt) {
-    __shared__ unsigned tile[128][33];                    // [source row][word column], +1 word of padding
-    const int64_t r0 = (int64_t)blockIdx.y * 128, c0 = (int64_t)blockIdx.x * 128;
-    {
-        const int ch = threadIdx.x & 7, rr = threadIdx.x >> 3;            // 16-byte chunk of the row, row within the pass
-#pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-            const int r = pass * 32 + rr;
-            const uint4 w = *reinterpret_cast<const uint4*>(q + (r0 + r) * ldq + c0 + 16 * ch);
-            tile[r][4 * ch] = w.x; tile[r][4 * ch + 1] = w.y; tile[r][4 * ch + 2] = w.z; tile[r][4 * ch + 3] = w.w;
-        }
-    }
-    __syncthreads();
-    const int cq = threadIdx.x & 31, r16 = (threadIdx.x >> 5) * 16;
+// The same for R % 128 == 0 and 16-byte aligned rows on both sides: 128 x 128-byte tiles, 16 bytes per lane in AND out, and the
+// output leaves as WHOLE 128-byte rows.  The 64 x 128 kernels above write 4 bytes per lane in 64-byte runs and reach 2.5 TB/s; a first
+// 128 x 128 version stored its transposed registers directly (16 bytes per lane, but 32-byte runs of 32 different rows per
+// wave-instruction: 29.5 us for the 37.7 MB tensors of DiT-XL/2, still 2.5 TB/s).  Now the transposed 16-byte pieces go back into
+// the LDS tile (XOR-swizzled chunks: conflict-free for the writes and the row reads) and eight lanes store one output row.
+//   tile in : [source row][33 words]            (+1 word of padding)
+//   tile out: [output row o][8 chunks of 16 B], chunk k (= source rows 16 k .. 16 k + 15) at position k ^ ((o >> 2) & 7)
+// Thread (cq = 4-column group, r16 = 16-row group) gathers the 16 x 4 byte block rows r16 .. r16 + 15, columns 4 cq .. 4 cq + 3
+// from LDS (16 words) and transposes it with v_perm_b32 (four 4 x 4 byte transposes).
+__device__ __forceinline__ void fp8_tile128_transpose_store(unsigned (*tile)[33], unsigned char* __restrict__ qt, int64_t ldt,
+                                                            int64_t r0, int64_t c0) {
+    const int cq = threadIdx.x & 31, k16 = threadIdx.x >> 5, r16 = k16 * 16;
     unsigned o[4][4];                                     // o[column j of the group][word = rows 4 i .. 4 i + 3]
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -277,9 +269,89 @@ fp8_transpose128_kernel(const unsigned char* __restrict__ q, int64_t ldq, unsign
         o[2][i] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x05040100);
         o[3][i] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x07060302);
     }
-    unsigned char* dst = qt + (c0 + 4 * cq) * ldt + r0 + r16;
+    __syncthreads();                                      // everybody has read the input tile: reuse its memory for the output
+    uint4* out = reinterpret_cast<uint4*>(&tile[0][0]);   // [128 rows][8 chunks]
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<uint4*>(dst + j * ldt) = uint4{o[j][0], o[j][1], o[j][2], o[j][3]};
+    for (int j = 0; j < 4; ++j) {
+        const int orow = 4 * cq + j;
+        out[orow * 8 + (k16 ^ (cq & 7))] = uint4{o[j][0], o[j][1], o[j][2], o[j][3]};
+    }
+    __syncthreads();
+    const int ch = threadIdx.x & 7, rr = threadIdx.x >> 3;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int orow = pass * 32 + rr;
+        *reinterpret_cast<uint4*>(qt + (c0 + orow) * ldt + r0 + 16 * ch) = out[orow * 8 + (ch ^ ((orow >> 2) & 7))];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+fp8_transpose128_kernel(const unsigned char* __restrict__ q, int64_t ldq, unsigned char* __restrict__ qt, int64_t ldt) {
+    __shared__ __attribute__((aligned(16))) unsigned tile[128][33];                    // [source row][word column], +1 word of padding
+    const int64_t r0 = (int64_t)blockIdx.y * 128, c0 = (int64_t)blockIdx.x * 128;
+    {
+        const int ch = threadIdx.x & 7, rr = threadIdx.x >> 3;            // 16-byte chunk of the row, row within the pass
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int r = pass * 32 + rr;
+            const uint4 w = *reinterpret_cast<const uint4*>(q + (r0 + r) * ldq + c0 + 16 * ch);
+            tile[r][4 * ch] = w.x; tile[r][4 * ch + 1] = w.y; tile[r][4 * ch + 2] = w.z; tile[r][4 * ch + 3] = w.w;
+        }
+    }
+    __syncthreads();
+    fp8_tile128_transpose_store(tile, qt, ldt, r0, c0);
+}
+
+// bf16 -> fp8 bytes q AND their transposed copy qt on the same 128 x 128 tile (R % 128 == 0, C % 128 == 0, 16-byte aligned rows):
+// 32 bytes in, 16 bytes of q out per lane and row piece; qt as in fp8_transpose128_kernel.  Same values as
+// fp8_quantize_bf16_tile_kernel (same scale, saturation, rounding and running-max update).
+template <bool E5M2>
+__global__ void __launch_bounds__(256)
+fp8_quantize_bf16_tile128_kernel(const bf16_t* __restrict__ x, int64_t ld, unsigned char* __restrict__ q, int64_t ldq,
+                                 unsigned char* __restrict__ qt, int64_t ldt, const float* __restrict__ scale, float* __restrict__ amax_acc) {
+    __shared__ __attribute__((aligned(16))) unsigned tile[128][33];
+    __shared__ float sh[4];
+    const float inv = 1.f / scale[0];
+    const float fmax_ = E5M2 ? 57344.f : 448.f;
+    const int64_t r0 = (int64_t)blockIdx.y * 128, c0 = (int64_t)blockIdx.x * 128;
+    const int ch = threadIdx.x & 7, rr = threadIdx.x >> 3;
+    float am = 0.f;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int r = pass * 32 + rr;
+        const bf16_t* src = x + (r0 + r) * ld + c0 + 16 * ch;
+        const bf16x8 h0 = *reinterpret_cast<const bf16x8*>(src), h1 = *reinterpret_cast<const bf16x8*>(src + 8);
+        unsigned w[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const bf16x8& h = g < 2 ? h0 : h1;
+            const int b = 4 * (g & 1);
+            f32x4 v = {(float)h[b], (float)h[b + 1], (float)h[b + 2], (float)h[b + 3]};
+            if (amax_acc) {
+                am = fmaxf(am, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+                v = v * inv;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) v[jj] = __builtin_amdgcn_fmed3f(v[jj], -fmax_, fmax_);
+            } else {
+                v = v * inv;
+            }
+            w[g] = fp8_pack4<E5M2>(v);
+            tile[r][4 * ch + g] = w[g];
+        }
+        *reinterpret_cast<uint4*>(q + (r0 + r) * ldq + c0 + 16 * ch) = uint4{w[0], w[1], w[2], w[3]};
+    }
+    if (amax_acc) {
+        am = wave_max(am);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = am;
+    }
+    __syncthreads();
+    if (amax_acc && threadIdx.x == 0) {
+        const float m = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+        unsigned* acc = reinterpret_cast<unsigned*>(amax_acc);
+        const unsigned mb = __float_as_uint(m);
+        if (m > 0.f && !(m != m) && mb > __hip_atomic_load(acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(acc, mb);
+    }
+    fp8_tile128_transpose_store(tile, qt, ldt, r0, c0);
 }
 
 extern "C" int vaw_fp8_transpose(const void* q, int64_t R, int64_t C, int64_t ldq, void* qt, int64_t ldt, vaw_stream stream) {
@@ -332,8 +404,11 @@ extern "C" int vaw_fp8_quantize(vaw_dtype src_dt, vaw_dtype dst_format, const vo
     if (tiled) {
         fp8_amax_partial_kernel<bf16_t><<<(int)nb, 256, 0, s>>>((const bf16_t*)src, R, C, ld, workspace);
         fp8_amax_final_kernel<<<1, 64, 0, s>>>(workspace, (int)nb, scale_out, fmt_max);
-        dim3 gt((unsigned)(C / 128), (unsigned)(R / 64));
-        if (e5) fp8_quantize_bf16_tile_kernel<true><<<gt, 256, 0, s>>>((const bf16_t*)src, ld, qp, ldq, qtp, ldt, scale_out, nullptr);
+        const bool t128 = R % 128 == 0 && ld % 8 == 0 && ldq % 16 == 0 && ldt % 16 == 0 && ((((uintptr_t)q) | ((uintptr_t)qt)) & 15) == 0;
+        dim3 gt((unsigned)(C / 128), (unsigned)(R / (t128 ? 128 : 64)));
+        if (t128 && e5) fp8_quantize_bf16_tile128_kernel<true><<<gt, 256, 0, s>>>((const bf16_t*)src, ld, qp, ldq, qtp, ldt, scale_out, nullptr);
+        else if (t128) fp8_quantize_bf16_tile128_kernel<false><<<gt, 256, 0, s>>>((const bf16_t*)src, ld, qp, ldq, qtp, ldt, scale_out, nullptr);
+        else if (e5) fp8_quantize_bf16_tile_kernel<true><<<gt, 256, 0, s>>>((const bf16_t*)src, ld, qp, ldq, qtp, ldt, scale_out, nullptr);
         else fp8_quantize_bf16_tile_kernel<false><<<gt, 256, 0, s>>>((const bf16_t*)src, ld, qp, ldq, qtp, ldt, scale_out, nullptr);
         VAW_CHECK_LAUNCH("fp8_quantize");
         return VAW_OK;
@@ -366,8 +441,11 @@ extern "C" int vaw_fp8_quantize_delayed(vaw_dtype src_dt, vaw_dtype dst_format, 
     const bool tiled = src_dt == VAW_BF16 && qt && R % 64 == 0 && C % 128 == 0 && ld % 8 == 0 && ldq % 8 == 0 &&
                        ((((uintptr_t)src) & 15) == 0) && ((((uintptr_t)q) & 7) == 0);
     if (tiled) {
-        dim3 gt((unsigned)(C / 128), (unsigned)(R / 64));
-        if (e5) fp8_quantize_bf16_tile_kernel<true><<<gt, 256, 0, s>>>((const bf16_t*)src, ld, qp, ldq, qtp, ldt, state, state + 1);
+        const bool t128 = R % 128 == 0 && ld % 8 == 0 && ldq % 16 == 0 && ldt % 16 == 0 && ((((uintptr_t)q) | ((uintptr_t)qt)) & 15) == 0;
+        dim3 gt((unsigned)(C / 128), (unsigned)(R / (t128 ? 128 : 64)));
+        if (t128 && e5) fp8_quantize_bf16_tile128_kernel<true><<<gt, 256, 0, s>>>((const bf16_t*)src, ld, qp, ldq, qtp, ldt, state, state + 1);
+        else if (t128) fp8_quantize_bf16_tile128_kernel<false><<<gt, 256, 0, s>>>((const bf16_t*)src, ld, qp, ldq, qtp, ldt, state, state + 1);
+        else if (e5) fp8_quantize_bf16_tile_kernel<true><<<gt, 256, 0, s>>>((const bf16_t*)src, ld, qp, ldq, qtp, ldt, state, state + 1);
         else fp8_quantize_bf16_tile_kernel<false><<<gt, 256, 0, s>>>((const bf16_t*)src, ld, qp, ldq, qtp, ldt, state, state + 1);
         VAW_CHECK_LAUNCH("fp8_quantize_delayed");
         return VAW_OK;
