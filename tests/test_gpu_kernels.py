@@ -3,6 +3,8 @@ statement of the same op, on seeded inputs.  Run on the MI355X box: pytest -m gp
 import math
 
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -551,8 +553,20 @@ def _attention_token_major(dtype, tol, B, H, T, hd):
     if took:
         assert torch.equal(dqkv2, dqkv)
         R = part.rows.value
-        assert R == (B if T == 64 else B * (T // 64) // (2 if (T % 128 == 0 and 64 < hd <= 96) else 1))
+        big = os.environ.get("VAW_ATTN_BWD_BIG") == "1" and T % 256 == 0 and T <= 1024 and 32 < hd <= 96     # attention_bwd_big.hip: one row per 256 tokens
+        assert R == (B if T == 64 else B * (T // 256) if big else B * (T // 64) // (2 if (T % 128 == 0 and 64 < hd <= 96) else 1))
         torch.testing.assert_close(part.buf[:R].sum(0).cpu().double(), dqkv.cpu().double().sum(0), rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("B,H,T,hd", [(1, 1, 256, 64), (2, 4, 256, 96), (1, 2, 1024, 64), (1, 16, 256, 72), (2, 2, 512, 40)])
+def test_attention_backward_big_owner_experiment(B, H, T, hd):
+    """VAW_ATTN_BWD_BIG=1: the 64-rows-per-wave backward pair (attention_bwd_big.hip; off by default) gives the same gradients and
+    column sums as the reference within the bf16 tolerance of the default kernels."""
+    os.environ["VAW_ATTN_BWD_BIG"] = "1"
+    try:
+        _attention_token_major(torch.bfloat16, dict(rtol=3e-2, atol=3e-2), B, H, T, hd)
+    finally:
+        del os.environ["VAW_ATTN_BWD_BIG"]
 
 
 _forced_rowwise = [False]

@@ -1,0 +1,418 @@
+// EXPERIMENT, off by default (VAW_ATTN_BWD_BIG=1): attention backward for sequences that are multiples of 256 tokens (DiT-B/2 and
+// DiT-XL/2: T = 256; the UNets' 16 x 16 and 32 x 32 attention levels: T = 256 / 1024), head dims 40 .. 96, with one wave per SIMD
+// and the WHOLE register file.  Correct (the attention tests run it), and measured at parity with the 16-row kernels, not ahead.
+//
+// The idea: in attn_bwd_dq_mfma / attn_bwd_dkv_mfma (attention_mfma.hip) a wave owns 16 (or 32) rows, so every 16 x 16 score tile
+// costs a full fragment read of the streamed operand from LDS.  Here a wave OWNS 64 rows: their S- and dP-operand fragments (K and
+// V rows for the key-owner kernel, Q and dO rows for the query-owner kernel) sit in registers for the whole kernel next to the
+// 64 x HD output accumulators, and the other side streams through LDS in slices of 32 rows that all four waves share -- one
+// fragment read feeds four MFMAs.  Per slice and wave (HD 96): 96 MFMAs for 24 KB of LDS reads (key owner), 72 for 18 KB (query owner).
+//
+//   MODE 0, key owner   (dK, dV):  S [q][key] = Q_s K_w^T and dP = dO_s V_w^T with the KEY on the lane; P and dS (accumulator
+//                                  tiles, two query tiles packed = one k-step of 32) are the B operands of
+//                                  dV^T[hd][key] += dO_s^T P  and  dK^T[hd][key] += Q_s^T dS  (contraction over the queries).
+//   MODE 1, query owner (dQ, delta): S^T[key][q] = K_s Q_w^T, dP^T = V_s dO_w^T with the QUERY on the lane; dS^T feeds
+//                                  dQ^T[hd][q] += K_s^T dS^T (contraction over the keys).  Also delta_i = rowsum(dO * O).
+// Seven products for the pair (the minimum is five with dS handed across LDS; that kernel would have to sum dQ across waves).
+// P = exp2(S c - lse log2 e), dS = P (dP - delta) with the scale applied once to the accumulated dK / dQ, bf16 operands, f32
+// accumulation, k-steps of 32 rows in ascending order.  Outputs leave through LDS as whole rows; their column sums (the qkv bias
+// gradient) are taken from the staged rows in a fixed order.
+//
+// What was measured (tools/attn_t.sh, DiT-XL/2's 2048 (sample, head) pairs; T = 256 and 1024 give time = rounds x (F + slices x S)):
+//   key owner  HD 96: 238.6 us at T = 256; S = 2.0 us per 32-row slice (96 MFMAs = 0.64 us of MFMA time), F = 14 us per workgroup
+//   query owner HD 96: 209.2 us;            S = 1.5 us, F = 14 us          -- the pair 448 us against 438 us for the 16-row kernels;
+//   HD 64: 165.1 + 147.6 us (S = 1.5 / 1.2 us, F = 8 / 12 us); T = 1024 (ADM_64's 32 x 32 level) 2.35 ms against 2.05 ms.
+// Why it does not win: a workgroup has the CU to itself (4 waves x 448 registers), so nothing covers (a) its fixed costs -- first
+// memory latency, accumulator set-up, two staged outputs, dispatch gap: 14 us of a 30 us workgroup at T = 256 -- and (b) the
+// serial phases inside a slice: MFMAs (1 536 cycles), ~350 VALU instructions of softmax recomputation and accumulator moves
+// (1 400), four LDS round trips.  PMC: MFMA pipe busy 19 % of the wave time, VALU 32 %, waiting 33 %.  The 16-row kernels pay twice
+// the LDS traffic per MFMA but run 2-3 workgroups per CU that cover each other.  What it would take: the slice loop as a hand-placed
+// software pipeline (softmax of slice n under the score products of slice n + 1) and a persistent workgroup that prefetches the next
+// pair's owner fragments under the current pair's output phase.
+//
+// Slices arrive by LDS-DMA into a ring of four buffers: three slices are in flight while one is computed (counted vmcnt waits, one raw
+// barrier per slice).
+// Reference: timm Attention's backward as autograd derives it (models/dit.py:126) / QKVAttention (models/unet.py:350-394).
+#include "attention_mfma.h"
+
+// ROWS x HD bf16 rows starting at g -> an LDS image with the layout of Img<HD> (all 4 waves cooperate, LDS-DMA)
+template <int HD, int ROWS>
+__device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ g, int64_t stride_t, char* img, int wid, int lane, int hd) {
+    constexpr int PCH = Img<HD>::PCH, TOTAL = ROWS * PCH, PIECES = (TOTAL + 63) / 64;
+#pragma unroll
+    for (int i = 0; i < (PIECES + 3) / 4; ++i) {
+        const int piece = wid + 4 * i;
+        if (PIECES % 4 != 0 && piece >= PIECES) break;          // uniform per wave
+        const int idx = piece * 64 + lane;
+        if (TOTAL % 64 == 0 || idx < TOTAL) {                   // (a last, partial piece: the other lanes write nothing)
+            const int row = idx / PCH;
+            const int chunk = (idx % PCH) ^ swz<HD>(row);
+            const bf16_t* src = chunk * 8 < hd ? g + (int64_t)row * stride_t + chunk * 8
+                                               : reinterpret_cast<const bf16_t*>(attn_zero_page);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(img + piece * 1024), 16, 0, 0);
+        }
+    }
+}
+
+// column sums of 256 staged rows (as stored: bf16) -> out_row[c], c < hd: four 64-row quarters, folded in ascending order
+template <int HD>
+__device__ __forceinline__ void cs_from_stage(const char* stage, int hd, float* red, float* out_row) {
+    for (int idx = threadIdx.x; idx < 4 * HD; idx += 256) {
+        const int qd = idx / HD, c = idx - qd * HD;
+        if (c >= hd) continue;
+        float sum = 0.f;
+#pragma unroll 8
+        for (int r = 64 * qd; r < 64 * qd + 64; ++r) sum += (float)*reinterpret_cast<const bf16_t*>(stage + out_off<HD>(r, c >> 3) + 2 * (c & 7));
+        red[qd * HD + c] = sum;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < hd; c += 256) out_row[c] = ((red[c] + red[HD + c]) + red[2 * HD + c]) + red[3 * HD + c];
+}
+
+// LDS reads of the main loop go through inline asm: the compiler orders every ordinary LDS access behind ALL pending LDS-DMA with
+// s_waitcnt vmcnt(0) (it cannot tell which image a read touches), which would wait for the slices just put in flight.  The asm reads
+// carry no such wait; LDS_WAIT() is ours, before the first consumer (cdna_hip_programming.md rule 18).
+__device__ __forceinline__ bf16x8 lds_rd128(unsigned addr) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ f32x4 lds_rd128f(unsigned addr) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ bf16x4 lds_rd64tr(unsigned addr) {
+    bf16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+#define LDS_WAIT()                                          \
+    do {                                                    \
+        __builtin_amdgcn_sched_barrier(0);                  \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
+        __builtin_amdgcn_sched_barrier(0);                  \
+    } while (0)
+// frag_rows / frag_cols_perm of attention_mfma.h on an image given by its LDS byte address
+template <int HD>
+__device__ __forceinline__ bf16x8 afrag_rows(unsigned img, int r0, int s, int lane) {
+    return lds_rd128(img + (unsigned)img_off<HD>(r0 + (lane & 15), 4 * s + (lane >> 4)));
+}
+template <int HD>
+__device__ __forceinline__ void afrag_cols_perm(unsigned img, int d0, int lane, bf16x4& lo, bf16x4& hi) {      // k = image rows 0 .. 31
+    const int li = lane & 15, q = li >> 2, p = li & 3, g = lane >> 4;
+    const int ch = (d0 >> 3) + (p >> 1);
+    const int r_lo = 4 * g + q, r_hi = r_lo + 16;
+    lo = lds_rd64tr(img + (unsigned)(img_off<HD>(r_lo, ch) + 8 * (p & 1)));
+    hi = lds_rd64tr(img + (unsigned)(img_off<HD>(r_hi, ch) + 8 * (p & 1)));
+}
+__device__ __forceinline__ bf16x8 cat44(bf16x4 lo, bf16x4 hi) {
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+// counted wait for this wave's LDS-DMA: at most n of its youngest vector-memory instructions still in flight (n wave-uniform)
+__device__ __forceinline__ void wait_vm(int n) {
+    if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (n >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int HD> struct BigLds {
+    static constexpr int SIMG = 32 * Img<HD>::PITCH;                       // one 32-row slice image
+    static constexpr int NB = 4;                                           // slice buffers: three slices in flight beside the one in use
+    static constexpr int RING = NB * 2 * SIMG;
+    static constexpr int STAGE = 256 * (HD == 96 ? 208 : 2 * HD);         // 256 output rows, over the ring once the loop is done
+    static constexpr int FRONT = RING > STAGE ? RING : STAGE;
+    static int bytes(int T) { return FRONT + 2 * T * 4 + 4 * HD * 4; }
+};
+
+template <int HD, int MODE>
+__global__ void __launch_bounds__(256)
+attn_bwd_big(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+             const bf16_t* __restrict__ o, const bf16_t* __restrict__ d_o, const float* __restrict__ lse, float* __restrict__ delta,
+             bf16_t* __restrict__ out0, bf16_t* __restrict__ out1, float* __restrict__ cs_part, int64_t cs_ld) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KS = HD / 32, DT = HD / 16, SIMG = BigLds<HD>::SIMG;
+    constexpr int NB = BigLds<HD>::NB, DEPTH = NB - 1;
+    char* slices = smem;                                               // [NB buffers][X slice | Y slice]
+    char* stage = smem;                                                // (the outputs are staged over the ring after the loop)
+    float* lse_s = reinterpret_cast<float*>(smem + BigLds<HD>::FRONT); // MODE 0: lse log2 e and delta of every query
+    float* del_s = lse_s + a.T;
+    float* red = del_s + a.T;
+    const int lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
+    const int64_t base = b * a.q_sb + h * a.q_sh, obase = b * a.o_sb + h * a.o_sh;
+    const int own0 = blockIdx.x * 256 + 64 * wid;                      // this wave's 64 owner rows (keys | queries)
+    const float c2 = a.scale * 1.4426950408889634f;
+    // streamed side: X_s feeds S, Y_s feeds dP
+    const bf16_t* xs = MODE == 0 ? q + base : k + base;
+    const bf16_t* ys = MODE == 0 ? d_o + obase : v + base;
+    const int64_t xs_st = a.q_st, ys_st = MODE == 0 ? a.o_st : a.q_st;
+    const int n_slices = a.T / 32;
+    // this wave's LDS-DMA instructions per slice (two images; piece p of an image belongs to wave p % 4)
+    constexpr int PIECES = (32 * Img<HD>::PCH + 63) / 64;
+    const int dma_per_slice = 2 * ((PIECES - wid + 3) / 4);
+    auto issue = [&](int sl) {
+        char* nx = slices + (sl % NB) * 2 * SIMG;
+        stage_rows<HD, 32>(xs + (int64_t)sl * 32 * xs_st, xs_st, nx, wid, lane, a.hd);
+        stage_rows<HD, 32>(ys + (int64_t)sl * 32 * ys_st, ys_st, nx + SIMG, wid, lane, a.hd);
+    };
+    // Everything the workgroup needs before its first MFMA is requested at once -- the first slices, the owner fragments, the row
+    // constants -- so that the workgroup (alone on its CU: nobody else covers its latencies) pays ONE memory latency, not three.
+    for (int sl = 0; sl < DEPTH && sl < n_slices; ++sl) issue(sl);
+    float lse_r[(MODE == 0) ? 4 : 1], del_r[(MODE == 0) ? 4 : 1];      // MODE 0: T <= 1024 row constants per thread, stored to LDS below
+    if (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = threadIdx.x + 256 * j;
+            lse_r[j] = i < a.T ? lse[(int64_t)bh * a.T + i] : 0.f;
+            del_r[j] = i < a.T ? delta[(int64_t)bh * a.T + i] : 0.f;
+        }
+    }
+    // owner side, straight from global memory into B-operand fragments: lane (li, g) holds channels 32 s + 8 g .. + 7 of row 16 t + li
+    bf16x8 xf[4][KS], yf[4][KS];
+    {
+        const bf16_t* xo = MODE == 0 ? k + base : q + base;
+        const bf16_t* yo = MODE == 0 ? v + base : d_o + obase;
+        const int64_t yo_st = MODE == 0 ? a.q_st : a.o_st;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int ch = 32 * s + 8 * g;
+                const int64_t row = own0 + 16 * t + li;
+                const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                xf[t][s] = ch < a.hd ? *reinterpret_cast<const bf16x8*>(xo + row * a.q_st + ch) : z;
+                yf[t][s] = ch < a.hd ? *reinterpret_cast<const bf16x8*>(yo + row * yo_st + ch) : z;
+            }
+    }
+    float lse_q[4] = {0, 0, 0, 0}, del_q[4] = {0, 0, 0, 0};           // MODE 1: of this lane's query in each of the 4 tiles
+    if (MODE == 1) {
+        // delta_i = sum_c dO[i][c] O[i][c]: dO is already here as yf (this lane: channels 32 s + 8 g .. + 7 of row 16 t + li)
+        bf16x8 of[4][KS];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int ch = 32 * s + 8 * g;
+                const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                of[t][s] = ch < a.hd ? *reinterpret_cast<const bf16x8*>(o + obase + (int64_t)(own0 + 16 * t + li) * a.o_st + ch) : z;
+            }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) lse_q[t] = lse[(int64_t)bh * a.T + own0 + 16 * t + li] * 1.4426950408889634f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float dl = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dl += (float)yf[t][s][j] * (float)of[t][s][j];
+            dl = group_sum(dl);
+            del_q[t] = dl;
+            if (g == 0) delta[(int64_t)bh * a.T + own0 + 16 * t + li] = dl;
+        }
+    } else {
+        // (ordinary LDS stores: the compiler puts them behind every pending LDS-DMA -- the slices requested above, which the loop needs anyway)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = threadIdx.x + 256 * j;
+            if (i < a.T) {
+                lse_s[i] = lse_r[j] * 1.4426950408889634f;
+                del_s[i] = del_r[j];
+            }
+        }
+    }
+    f32x4 acc0[4][DT], acc1[MODE == 0 ? 4 : 1][DT];                   // MODE 0: dK^T, dV^T per key tile; MODE 1: dQ^T per query tile
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            acc0[t][dt] = f32x4{0, 0, 0, 0};
+            if (MODE == 0) acc1[t][dt] = f32x4{0, 0, 0, 0};
+        }
+    const unsigned ring = (unsigned)(uintptr_t)(lds_ptr_t)slices;
+    const unsigned lse_a = (unsigned)(uintptr_t)(lds_ptr_t)lse_s, del_a = (unsigned)(uintptr_t)(lds_ptr_t)del_s;
+    if (MODE == 0) __syncthreads();                      // lse_s / del_s are complete
+    for (int sl = 0; sl < n_slices; ++sl) {
+        const unsigned ximg = ring + (unsigned)((sl % NB) * 2 * SIMG), yimg = ximg + SIMG;
+        {
+            const int last = sl + DEPTH - 1 < n_slices - 1 ? sl + DEPTH - 1 : n_slices - 1;      // youngest slice issued so far
+            wait_vm((last - sl) * dma_per_slice);        // this wave's pieces of slice sl have landed ...
+            __builtin_amdgcn_s_barrier();                // ... everybody's have; and everybody is done with slice sl - 1
+            if (sl + DEPTH < n_slices) issue(sl + DEPTH);                                       // into the buffer slice sl - 1 used
+        }
+        if (MODE == 0) {
+            bf16x8 xa[2][KS], ya[2][KS];
+            f32x4 L4[2], D4[2];
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    xa[it][s] = afrag_rows<HD>(ximg, 16 * it, s, lane);
+                    ya[it][s] = afrag_rows<HD>(yimg, 16 * it, s, lane);
+                }
+                const unsigned i0 = 4u * (unsigned)(32 * sl + 16 * it + 4 * g);
+                L4[it] = lds_rd128f(lse_a + i0);
+                D4[it] = lds_rd128f(del_a + i0);
+            }
+            LDS_WAIT();
+            // the first pair of transposed fragments flies under the S / dP products; every later pair under the products before it
+            bf16x4 yl[2][2], yh[2][2], xl[2][2], xh[2][2];           // [ping-pong][channel tile of the pair]
+            auto rd_pair = [&](int dh, int pp) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    afrag_cols_perm<HD>(yimg, 16 * (dh + u), lane, yl[pp][u], yh[pp][u]);
+                    afrag_cols_perm<HD>(ximg, 16 * (dh + u), lane, xl[pp][u], xh[pp][u]);
+                }
+            };
+            rd_pair(0, 0);
+            const f32x4 zero4 = {0, 0, 0, 0};
+            f32x4 p[2][4], ds[2][4];
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                f32x4 c[4], d[4];
+#pragma unroll
+                for (int s = 0; s < KS; ++s)
+#pragma unroll
+                    for (int jt = 0; jt < 4; ++jt) {
+                        c[jt] = MFMA(xa[it][s], xf[jt][s], s == 0 ? zero4 : c[jt]);          // S [query 4g + r][key li]
+                        d[jt] = MFMA(ya[it][s], yf[jt][s], s == 0 ? zero4 : d[jt]);          // dP
+                    }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int jt = 0; jt < 4; ++jt) {
+                        const float pr = __builtin_amdgcn_exp2f(c[jt][r] * c2 - L4[it][r]);
+                        p[it][jt][r] = pr;
+                        ds[it][jt][r] = pr * (d[jt][r] - D4[it][r]);      // (x scale: once, on the accumulated dK^T)
+                    }
+            }
+            bf16x8 pf[4], sf[4];
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) {
+                pf[jt] = pack_acc(p[0][jt], p[1][jt]);
+                sf[jt] = pack_acc(ds[0][jt], ds[1][jt]);
+            }
+#pragma unroll
+            for (int dh = 0; dh < DT; dh += 2) {             // transposed fragments two channel tiles at a time
+                const int pp = (dh >> 1) & 1;
+                LDS_WAIT();
+                if (dh + 2 < DT) rd_pair(dh + 2, pp ^ 1);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const bf16x8 yt = cat44(yl[pp][u], yh[pp][u]), xt = cat44(xl[pp][u], xh[pp][u]);
+#pragma unroll
+                    for (int jt = 0; jt < 4; ++jt) {
+                        acc1[jt][dh + u] = MFMA(yt, pf[jt], acc1[jt][dh + u]);    // dV^T [channel][key]
+                        acc0[jt][dh + u] = MFMA(xt, sf[jt], acc0[jt][dh + u]);    // dK^T / scale
+                    }
+                }
+            }
+        } else {
+            bf16x8 xa[2][KS], ya[2][KS];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    xa[kt][s] = afrag_rows<HD>(ximg, 16 * kt, s, lane);
+                    ya[kt][s] = afrag_rows<HD>(yimg, 16 * kt, s, lane);
+                }
+            LDS_WAIT();
+            bf16x4 xl[2][2], xh[2][2];
+            auto rd_pair = [&](int dh, int pp) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) afrag_cols_perm<HD>(ximg, 16 * (dh + u), lane, xl[pp][u], xh[pp][u]);
+            };
+            rd_pair(0, 0);
+            const f32x4 zero4 = {0, 0, 0, 0};
+            f32x4 ds[2][4];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                f32x4 c[4], d[4];
+#pragma unroll
+                for (int s = 0; s < KS; ++s)
+#pragma unroll
+                    for (int qt = 0; qt < 4; ++qt) {
+                        c[qt] = MFMA(xa[kt][s], xf[qt][s], s == 0 ? zero4 : c[qt]);          // S^T [key 4g + r][query li]
+                        d[qt] = MFMA(ya[kt][s], yf[qt][s], s == 0 ? zero4 : d[qt]);          // dP^T
+                    }
+#pragma unroll
+                for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        ds[kt][qt][r] = __builtin_amdgcn_exp2f(c[qt][r] * c2 - lse_q[qt]) * (d[qt][r] - del_q[qt]);      // (x scale: on dQ^T)
+            }
+            bf16x8 sf[4];
+#pragma unroll
+            for (int qt = 0; qt < 4; ++qt) sf[qt] = pack_acc(ds[0][qt], ds[1][qt]);
+#pragma unroll
+            for (int dh = 0; dh < DT; dh += 2) {
+                const int pp = (dh >> 1) & 1;
+                LDS_WAIT();
+                if (dh + 2 < DT) rd_pair(dh + 2, pp ^ 1);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const bf16x8 xt = cat44(xl[pp][u], xh[pp][u]);
+#pragma unroll
+                    for (int qt = 0; qt < 4; ++qt) acc0[qt][dh + u] = MFMA(xt, sf[qt], acc0[qt][dh + u]);    // dQ^T / scale
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // ---- outputs: 256 rows per workgroup through the staging tile, whole rows out, column sums from the staged values ----
+    const int64_t orow0 = (int64_t)blockIdx.x * 256;
+    float* cs_row = cs_part ? cs_part + ((int64_t)b * gridDim.x + blockIdx.x) * cs_ld : nullptr;
+    const int Hhd = a.H * a.hd;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) acc0[t][dt] *= a.scale;      // dS was accumulated without its scale factor
+#pragma unroll
+    for (int which = 0; which < (MODE == 0 ? 2 : 1); ++which) {
+        __syncthreads();                                 // (first pass: the last slice's reads; second: the flush before)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) out_stage16<HD, DT>(stage, 64 * wid + 16 * t, which == 0 ? acc0[t] : acc1[MODE == 0 ? t : 0], lane);
+        __syncthreads();
+        bf16_t* dst = (which == 0 ? out0 : out1) + base + orow0 * a.q_st;
+        out_flush<HD>(stage, 256, dst, a.q_st, a.hd);
+        if (cs_row) {
+            // packed qkv column order [3][H][hd]: dq = 0, dk = 1, dv = 2
+            const int col = (MODE == 1 ? 0 : 1 + which) * Hhd + h * a.hd;
+            cs_from_stage<HD>(stage, a.hd, red, cs_row + col);
+        }
+    }
+}
+
+static AttnMfmaArgs mk_args_big(const vaw_attn_desc* d) {
+    AttnMfmaArgs a{d->B, d->H, d->T, d->q_sb, d->q_sh, d->q_st, d->o_sb, d->o_sh, d->o_st, d->scale, d->hd};
+    return a;
+}
+
+// true when the shape is taken (both launches enqueued); cs_part / cs_rows_out as in vaw_attn_bwd_mfma
+bool vaw_attn_bwd_big(const vaw_attn_desc* d, const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                      const float* lse, float* delta, void* dq, void* dk, void* dv, hipStream_t s, float* cs_part, int64_t* cs_rows_out) {
+    // OFF by default: measured at parity with the 16-row kernels, not ahead (see the header).  VAW_ATTN_BWD_BIG=1 switches it on
+    // (read per call: tests toggle it).
+    const char* e = getenv("VAW_ATTN_BWD_BIG");
+    const int on = e ? atoi(e) : 0;
+    if (!on || d->T % 256 != 0 || d->T > 1024 || d->hd <= 32 || d->hd > 96) return false;
+    const AttnMfmaArgs a = mk_args_big(d);
+    const int64_t cs_ld = 3LL * d->H * d->hd;
+    dim3 grid(d->T / 256, d->B * d->H);
+#define BIG_GO(HDv)                                                                                                                  \
+    do {                                                                                                                             \
+        const int lds = BigLds<HDv>::bytes(d->T);                                                                                    \
+        (void)hipFuncSetAttribute((const void*)attn_bwd_big<HDv, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);               \
+        (void)hipFuncSetAttribute((const void*)attn_bwd_big<HDv, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);               \
+        attn_bwd_big<HDv, 1><<<grid, 256, lds, s>>>(a, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o,       \
+                                                    (const bf16_t*)d_o, lse, delta, (bf16_t*)dq, nullptr, cs_part, cs_ld);           \
+        attn_bwd_big<HDv, 0><<<grid, 256, lds, s>>>(a, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o,       \
+                                                    (const bf16_t*)d_o, lse, delta, (bf16_t*)dk, (bf16_t*)dv, cs_part, cs_ld);       \
+    } while (0)
+    if (d->hd <= 64) BIG_GO(64); else BIG_GO(96);
+#undef BIG_GO
+    if (cs_rows_out) *cs_rows_out = (int64_t)d->B * (d->T / 256);
+    return true;
+}
