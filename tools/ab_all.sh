@@ -1,0 +1,13 @@
+#!/bin/bash
+# The round's A/B table in ONE call (one box): round-2 tree (_base) against this tree, every workload, interleaved.
+ab() { echo "== $1"; bash tools/ab_bench.sh "$1" ${2:-2}; }
+ab "--steps 40 --warmup 8" 3
+ab "--batch 128 --steps 40 --warmup 8"
+ab "--batch 64 --steps 40 --warmup 8"
+ab "--batch 32 --steps 40 --warmup 8"
+ab "--workload dit_b2 --steps 10 --warmup 3"
+ab "--workload dit_xl2_fp8 --steps 5 --warmup 2"
+ab "--workload dit_xl2 --steps 5 --warmup 2"
+ab "--workload unet64 --steps 6 --warmup 2"
+ab "--workload adm64 --steps 3 --warmup 1"
+ab "--workload unet32 --steps 40 --warmup 8"
