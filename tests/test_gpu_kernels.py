@@ -553,16 +553,19 @@ def _attention_token_major(dtype, tol, B, H, T, hd):
     if took:
         assert torch.equal(dqkv2, dqkv)
         R = part.rows.value
-        big = os.environ.get("VAW_ATTN_BWD_BIG") == "1" and T % 256 == 0 and T <= 1024 and 32 < hd <= 96     # attention_bwd_big.hip: one row per 256 tokens
-        assert R == (B if T == 64 else B * (T // 256) if big else B * (T // 64) // (2 if (T % 128 == 0 and 64 < hd <= 96) else 1))
+        wgr = {"0": 0, "1": 256, "2": 128}[os.environ.get("VAW_ATTN_BWD_BIG", "2")]       # attention_bwd_big.hip: one row per workgroup of 256 / 128 owner rows
+        big = wgr and T % wgr == 0 and T <= 1024 and 32 < hd <= 96
+        assert R == (B if T == 64 else B * (T // wgr) if big else B * (T // 64) // (2 if (T % 128 == 0 and 64 < hd <= 96) else 1))
         torch.testing.assert_close(part.buf[:R].sum(0).cpu().double(), dqkv.cpu().double().sum(0), rtol=1e-5, atol=1e-3)
 
 
-@pytest.mark.parametrize("B,H,T,hd", [(1, 1, 256, 64), (2, 4, 256, 96), (1, 2, 1024, 64), (1, 16, 256, 72), (2, 2, 512, 40)])
-def test_attention_backward_big_owner_experiment(B, H, T, hd):
-    """VAW_ATTN_BWD_BIG=1: the 64-rows-per-wave backward pair (attention_bwd_big.hip; off by default) gives the same gradients and
-    column sums as the reference within the bf16 tolerance of the default kernels."""
-    os.environ["VAW_ATTN_BWD_BIG"] = "1"
+@pytest.mark.parametrize("variant", ["0", "1"])
+@pytest.mark.parametrize("B,H,T,hd", [(1, 1, 256, 64), (2, 4, 256, 96), (1, 2, 1024, 64), (1, 16, 256, 72), (2, 2, 512, 40), (3, 2, 128, 64)])
+def test_attention_backward_other_variants(B, H, T, hd, variant):
+    """VAW_ATTN_BWD_BIG=0 / 1: the 16-row backward kernels and the 64-rows-per-wave pair (the default for these shapes is the
+    32-rows-per-wave pair of attention_bwd_big.hip, which test_attention_token_major runs) give the same gradients and column sums
+    as the reference within the bf16 tolerance."""
+    os.environ["VAW_ATTN_BWD_BIG"] = variant
     try:
         _attention_token_major(torch.bfloat16, dict(rtol=3e-2, atol=3e-2), B, H, T, hd)
     finally:

@@ -1,37 +1,39 @@
-// EXPERIMENT, off by default (VAW_ATTN_BWD_BIG=1): attention backward for sequences that are multiples of 256 tokens (DiT-B/2 and
-// DiT-XL/2: T = 256; the UNets' 16 x 16 and 32 x 32 attention levels: T = 256 / 1024), head dims 40 .. 96, with one wave per SIMD
-// and the WHOLE register file.  Correct (the attention tests run it), and measured at parity with the 16-row kernels, not ahead.
+// Attention backward for sequences that are multiples of 128 tokens up to 1024 (DiT-B/2 and DiT-XL/2: T = 256; the UNets' 16 x 16
+// and 32 x 32 attention levels: T = 256 / 1024), head dims 40 .. 96: owner rows in registers, the other side streamed through a
+// deep LDS-DMA ring in 32-row slices.  The default backward for these shapes since round 3 (attn_bwd_dq_mfma / attn_bwd_dkv_mfma of
+// attention_mfma.hip keep the rest: T % 64, head dims up to 128).
 //
-// The idea: in attn_bwd_dq_mfma / attn_bwd_dkv_mfma (attention_mfma.hip) a wave owns 16 (or 32) rows, so every 16 x 16 score tile
-// costs a full fragment read of the streamed operand from LDS.  Here a wave OWNS 64 rows: their S- and dP-operand fragments (K and
-// V rows for the key-owner kernel, Q and dO rows for the query-owner kernel) sit in registers for the whole kernel next to the
-// 64 x HD output accumulators, and the other side streams through LDS in slices of 32 rows that all four waves share -- one
-// fragment read feeds four MFMAs.  Per slice and wave (HD 96): 96 MFMAs for 24 KB of LDS reads (key owner), 72 for 18 KB (query owner).
+// A wave OWNS 16 NT rows: their S- and dP-operand fragments (K and V rows for the key-owner kernel, Q and dO rows for the query-owner
+// kernel) come straight from global memory into registers and stay there for the whole kernel next to the 16 NT x HD output
+// accumulators; the other side streams through LDS in slices of 32 rows that all four waves share -- one fragment read feeds NT MFMAs.
 //
 //   MODE 0, key owner   (dK, dV):  S [q][key] = Q_s K_w^T and dP = dO_s V_w^T with the KEY on the lane; P and dS (accumulator
 //                                  tiles, two query tiles packed = one k-step of 32) are the B operands of
 //                                  dV^T[hd][key] += dO_s^T P  and  dK^T[hd][key] += Q_s^T dS  (contraction over the queries).
 //   MODE 1, query owner (dQ, delta): S^T[key][q] = K_s Q_w^T, dP^T = V_s dO_w^T with the QUERY on the lane; dS^T feeds
-//                                  dQ^T[hd][q] += K_s^T dS^T (contraction over the keys).  Also delta_i = rowsum(dO * O).
+//                                  dQ^T[hd][q] += K_s^T dS^T (contraction over the keys).  Also delta_i = rowsum(dO * O), from the
+//                                  owner's dO fragments.
 // Seven products for the pair (the minimum is five with dS handed across LDS; that kernel would have to sum dQ across waves).
 // P = exp2(S c - lse log2 e), dS = P (dP - delta) with the scale applied once to the accumulated dK / dQ, bf16 operands, f32
 // accumulation, k-steps of 32 rows in ascending order.  Outputs leave through LDS as whole rows; their column sums (the qkv bias
 // gradient) are taken from the staged rows in a fixed order.
 //
-// What was measured (tools/attn_t.sh, DiT-XL/2's 2048 (sample, head) pairs; T = 256 and 1024 give time = rounds x (F + slices x S)):
-//   key owner  HD 96: 238.6 us at T = 256; S = 2.0 us per 32-row slice (96 MFMAs = 0.64 us of MFMA time), F = 14 us per workgroup
-//   query owner HD 96: 209.2 us;            S = 1.5 us, F = 14 us          -- the pair 448 us against 438 us for the 16-row kernels;
-//   HD 64: 165.1 + 147.6 us (S = 1.5 / 1.2 us, F = 8 / 12 us); T = 1024 (ADM_64's 32 x 32 level) 2.35 ms against 2.05 ms.
-// Why it does not win: a workgroup has the CU to itself (4 waves x 448 registers), so nothing covers (a) its fixed costs -- first
-// memory latency, accumulator set-up, two staged outputs, dispatch gap: 14 us of a 30 us workgroup at T = 256 -- and (b) the
-// serial phases inside a slice: MFMAs (1 536 cycles), ~350 VALU instructions of softmax recomputation and accumulator moves
-// (1 400), four LDS round trips.  PMC: MFMA pipe busy 19 % of the wave time, VALU 32 %, waiting 33 %.  The 16-row kernels pay twice
-// the LDS traffic per MFMA but run 2-3 workgroups per CU that cover each other.  What it would take: the slice loop as a hand-placed
-// software pipeline (softmax of slice n under the score products of slice n + 1) and a persistent workgroup that prefetches the next
-// pair's owner fragments under the current pair's output phase.
-//
-// Slices arrive by LDS-DMA into a ring of four buffers: three slices are in flight while one is computed (counted vmcnt waits, one raw
-// barrier per slice).
+// What differs from the 16-row kernels, and what it is worth (tools/attn_bench.py, one box, interleaved; us per backward):
+//   * slices arrive by LDS-DMA into a ring of FOUR buffers: three slices in flight while one is computed, counted vmcnt waits, one
+//     raw barrier per slice (the 16-row kernels prefetch one 64-row block into registers and commit it after a barrier);
+//   * every LDS read of the loop is inline asm: the compiler orders an ordinary LDS access behind ALL pending LDS-DMA with
+//     s_waitcnt vmcnt(0), which would wait for the slices just put in flight; the transposed fragments of the next channel pair
+//     are read under the MFMAs of the current one;
+//   * everything a workgroup needs before its first MFMA -- first slices, owner fragments, row constants -- is requested at once.
+//   NT = 2 (32 owner rows per wave, <= 256 registers, two workgroups per CU; VAW_ATTN_BWD_BIG=2, the default):
+//       DiT-B/2 460 -> 375, DiT-XL/2 444 -> 405, ADM_64 32 x 32 2052 -> 1756, 16 x 16 270 -> 232, UNet_64 16 x 16 124 -> 108.
+//   NT = 4 (64 owner rows per wave, 450 registers, ONE workgroup per CU; VAW_ATTN_BWD_BIG=1): half the LDS reads per MFMA, and at
+//       PARITY with the 16-row kernels, not ahead (468 / 435 / 2057 / 321 / 106): with T = 256 and 1024 the kernel time fits
+//       rounds x (F + slices x S) with S = 2.0 us per slice (96 MFMAs = 0.64 us of MFMA time) and F = 14 us of fixed cost per
+//       workgroup (key owner, HD 96) -- a workgroup alone on its CU has nobody to cover its first memory latency, accumulator
+//       set-up, two staged outputs and dispatch gap, nor the serial MFMA / softmax / LDS phases inside a slice (PMC: MFMA pipe busy
+//       19 % of the wave time, VALU 32 %, waiting 33 %).  Two smaller workgroups cover each other; what the big one would need is
+//       the slice loop as a hand-placed software pipeline and a persistent workgroup that prefetches the next pair's owner fragments.
 // Reference: timm Attention's backward as autograd derives it (models/dit.py:126) / QKVAttention (models/unet.py:350-394).
 #include "attention_mfma.h"
 
@@ -54,15 +56,16 @@ __device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ g, int64_t
     }
 }
 
-// column sums of 256 staged rows (as stored: bf16) -> out_row[c], c < hd: four 64-row quarters, folded in ascending order
-template <int HD>
+// column sums of ROWS staged rows (as stored: bf16) -> out_row[c], c < hd: four quarters, folded in ascending order
+template <int HD, int ROWS>
 __device__ __forceinline__ void cs_from_stage(const char* stage, int hd, float* red, float* out_row) {
+    constexpr int QR = ROWS / 4;
     for (int idx = threadIdx.x; idx < 4 * HD; idx += 256) {
         const int qd = idx / HD, c = idx - qd * HD;
         if (c >= hd) continue;
         float sum = 0.f;
 #pragma unroll 8
-        for (int r = 64 * qd; r < 64 * qd + 64; ++r) sum += (float)*reinterpret_cast<const bf16_t*>(stage + out_off<HD>(r, c >> 3) + 2 * (c & 7));
+        for (int r = QR * qd; r < QR * qd + QR; ++r) sum += (float)*reinterpret_cast<const bf16_t*>(stage + out_off<HD>(r, c >> 3) + 2 * (c & 7));
         red[qd * HD + c] = sum;
     }
     __syncthreads();
@@ -117,33 +120,36 @@ __device__ __forceinline__ void wait_vm(int n) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int HD> struct BigLds {
+template <int HD, int NT> struct BigLds {
     static constexpr int SIMG = 32 * Img<HD>::PITCH;                       // one 32-row slice image
     static constexpr int NB = 4;                                           // slice buffers: three slices in flight beside the one in use
     static constexpr int RING = NB * 2 * SIMG;
-    static constexpr int STAGE = 256 * (HD == 96 ? 208 : 2 * HD);         // 256 output rows, over the ring once the loop is done
+    static constexpr int WGR = 64 * NT;                                    // owner rows per workgroup (4 waves x NT tiles of 16)
+    static constexpr int STAGE = WGR * (HD == 96 ? 208 : 2 * HD);         // the output rows, over the ring once the loop is done
     static constexpr int FRONT = RING > STAGE ? RING : STAGE;
     static int bytes(int T) { return FRONT + 2 * T * 4 + 4 * HD * 4; }
 };
 
-template <int HD, int MODE>
-__global__ void __launch_bounds__(256)
+// NT = 16-row owner tiles per wave: 4 -> 64 rows per wave, one workgroup per CU (the whole register file); 2 -> 32 rows per wave,
+// two workgroups per CU that cover each other's fixed costs and phases at twice the LDS reads per MFMA
+template <int HD, int MODE, int NT>
+__global__ void __launch_bounds__(256, NT == 2 ? 2 : 1)
 attn_bwd_big(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
              const bf16_t* __restrict__ o, const bf16_t* __restrict__ d_o, const float* __restrict__ lse, float* __restrict__ delta,
              bf16_t* __restrict__ out0, bf16_t* __restrict__ out1, float* __restrict__ cs_part, int64_t cs_ld) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int KS = HD / 32, DT = HD / 16, SIMG = BigLds<HD>::SIMG;
-    constexpr int NB = BigLds<HD>::NB, DEPTH = NB - 1;
+    constexpr int KS = HD / 32, DT = HD / 16, SIMG = BigLds<HD, NT>::SIMG, WGR = BigLds<HD, NT>::WGR;
+    constexpr int NB = BigLds<HD, NT>::NB, DEPTH = NB - 1;
     char* slices = smem;                                               // [NB buffers][X slice | Y slice]
     char* stage = smem;                                                // (the outputs are staged over the ring after the loop)
-    float* lse_s = reinterpret_cast<float*>(smem + BigLds<HD>::FRONT); // MODE 0: lse log2 e and delta of every query
+    float* lse_s = reinterpret_cast<float*>(smem + BigLds<HD, NT>::FRONT); // MODE 0: lse log2 e and delta of every query
     float* del_s = lse_s + a.T;
     float* red = del_s + a.T;
     const int lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
     const int64_t base = b * a.q_sb + h * a.q_sh, obase = b * a.o_sb + h * a.o_sh;
-    const int own0 = blockIdx.x * 256 + 64 * wid;                      // this wave's 64 owner rows (keys | queries)
+    const int own0 = blockIdx.x * WGR + 16 * NT * wid;                 // this wave's 16 NT owner rows (keys | queries)
     const float c2 = a.scale * 1.4426950408889634f;
     // streamed side: X_s feeds S, Y_s feeds dP
     const bf16_t* xs = MODE == 0 ? q + base : k + base;
@@ -171,13 +177,13 @@ attn_bwd_big(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __restr
         }
     }
     // owner side, straight from global memory into B-operand fragments: lane (li, g) holds channels 32 s + 8 g .. + 7 of row 16 t + li
-    bf16x8 xf[4][KS], yf[4][KS];
+    bf16x8 xf[NT][KS], yf[NT][KS];
     {
         const bf16_t* xo = MODE == 0 ? k + base : q + base;
         const bf16_t* yo = MODE == 0 ? v + base : d_o + obase;
         const int64_t yo_st = MODE == 0 ? a.q_st : a.o_st;
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const int ch = 32 * s + 8 * g;
@@ -187,12 +193,12 @@ attn_bwd_big(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __restr
                 yf[t][s] = ch < a.hd ? *reinterpret_cast<const bf16x8*>(yo + row * yo_st + ch) : z;
             }
     }
-    float lse_q[4] = {0, 0, 0, 0}, del_q[4] = {0, 0, 0, 0};           // MODE 1: of this lane's query in each of the 4 tiles
+    float lse_q[NT] = {}, del_q[NT] = {};           // MODE 1: of this lane's query in each of the 4 tiles
     if (MODE == 1) {
         // delta_i = sum_c dO[i][c] O[i][c]: dO is already here as yf (this lane: channels 32 s + 8 g .. + 7 of row 16 t + li)
-        bf16x8 of[4][KS];
+        bf16x8 of[NT][KS];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const int ch = 32 * s + 8 * g;
@@ -200,9 +206,9 @@ attn_bwd_big(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __restr
                 of[t][s] = ch < a.hd ? *reinterpret_cast<const bf16x8*>(o + obase + (int64_t)(own0 + 16 * t + li) * a.o_st + ch) : z;
             }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) lse_q[t] = lse[(int64_t)bh * a.T + own0 + 16 * t + li] * 1.4426950408889634f;
+        for (int t = 0; t < NT; ++t) lse_q[t] = lse[(int64_t)bh * a.T + own0 + 16 * t + li] * 1.4426950408889634f;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < NT; ++t) {
             float dl = 0.f;
 #pragma unroll
             for (int s = 0; s < KS; ++s)
@@ -223,9 +229,9 @@ attn_bwd_big(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __restr
             }
         }
     }
-    f32x4 acc0[4][DT], acc1[MODE == 0 ? 4 : 1][DT];                   // MODE 0: dK^T, dV^T per key tile; MODE 1: dQ^T per query tile
+    f32x4 acc0[NT][DT], acc1[MODE == 0 ? NT : 1][DT];                   // MODE 0: dK^T, dV^T per key tile; MODE 1: dQ^T per query tile
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             acc0[t][dt] = f32x4{0, 0, 0, 0};
@@ -268,29 +274,29 @@ attn_bwd_big(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __restr
             };
             rd_pair(0, 0);
             const f32x4 zero4 = {0, 0, 0, 0};
-            f32x4 p[2][4], ds[2][4];
+            f32x4 p[2][NT], ds[2][NT];
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
-                f32x4 c[4], d[4];
+                f32x4 c[NT], d[NT];
 #pragma unroll
                 for (int s = 0; s < KS; ++s)
 #pragma unroll
-                    for (int jt = 0; jt < 4; ++jt) {
+                    for (int jt = 0; jt < NT; ++jt) {
                         c[jt] = MFMA(xa[it][s], xf[jt][s], s == 0 ? zero4 : c[jt]);          // S [query 4g + r][key li]
                         d[jt] = MFMA(ya[it][s], yf[jt][s], s == 0 ? zero4 : d[jt]);          // dP
                     }
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int jt = 0; jt < 4; ++jt) {
+                    for (int jt = 0; jt < NT; ++jt) {
                         const float pr = __builtin_amdgcn_exp2f(c[jt][r] * c2 - L4[it][r]);
                         p[it][jt][r] = pr;
                         ds[it][jt][r] = pr * (d[jt][r] - D4[it][r]);      // (x scale: once, on the accumulated dK^T)
                     }
             }
-            bf16x8 pf[4], sf[4];
+            bf16x8 pf[NT], sf[NT];
 #pragma unroll
-            for (int jt = 0; jt < 4; ++jt) {
+            for (int jt = 0; jt < NT; ++jt) {
                 pf[jt] = pack_acc(p[0][jt], p[1][jt]);
                 sf[jt] = pack_acc(ds[0][jt], ds[1][jt]);
             }
@@ -303,7 +309,7 @@ attn_bwd_big(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __restr
                 for (int u = 0; u < 2; ++u) {
                     const bf16x8 yt = cat44(yl[pp][u], yh[pp][u]), xt = cat44(xl[pp][u], xh[pp][u]);
 #pragma unroll
-                    for (int jt = 0; jt < 4; ++jt) {
+                    for (int jt = 0; jt < NT; ++jt) {
                         acc1[jt][dh + u] = MFMA(yt, pf[jt], acc1[jt][dh + u]);    // dV^T [channel][key]
                         acc0[jt][dh + u] = MFMA(xt, sf[jt], acc0[jt][dh + u]);    // dK^T / scale
                     }
@@ -326,26 +332,26 @@ attn_bwd_big(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __restr
             };
             rd_pair(0, 0);
             const f32x4 zero4 = {0, 0, 0, 0};
-            f32x4 ds[2][4];
+            f32x4 ds[2][NT];
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
-                f32x4 c[4], d[4];
+                f32x4 c[NT], d[NT];
 #pragma unroll
                 for (int s = 0; s < KS; ++s)
 #pragma unroll
-                    for (int qt = 0; qt < 4; ++qt) {
+                    for (int qt = 0; qt < NT; ++qt) {
                         c[qt] = MFMA(xa[kt][s], xf[qt][s], s == 0 ? zero4 : c[qt]);          // S^T [key 4g + r][query li]
                         d[qt] = MFMA(ya[kt][s], yf[qt][s], s == 0 ? zero4 : d[qt]);          // dP^T
                     }
 #pragma unroll
-                for (int qt = 0; qt < 4; ++qt)
+                for (int qt = 0; qt < NT; ++qt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         ds[kt][qt][r] = __builtin_amdgcn_exp2f(c[qt][r] * c2 - lse_q[qt]) * (d[qt][r] - del_q[qt]);      // (x scale: on dQ^T)
             }
-            bf16x8 sf[4];
+            bf16x8 sf[NT];
 #pragma unroll
-            for (int qt = 0; qt < 4; ++qt) sf[qt] = pack_acc(ds[0][qt], ds[1][qt]);
+            for (int qt = 0; qt < NT; ++qt) sf[qt] = pack_acc(ds[0][qt], ds[1][qt]);
 #pragma unroll
             for (int dh = 0; dh < DT; dh += 2) {
                 const int pp = (dh >> 1) & 1;
@@ -355,32 +361,32 @@ attn_bwd_big(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __restr
                 for (int u = 0; u < 2; ++u) {
                     const bf16x8 xt = cat44(xl[pp][u], xh[pp][u]);
 #pragma unroll
-                    for (int qt = 0; qt < 4; ++qt) acc0[qt][dh + u] = MFMA(xt, sf[qt], acc0[qt][dh + u]);    // dQ^T / scale
+                    for (int qt = 0; qt < NT; ++qt) acc0[qt][dh + u] = MFMA(xt, sf[qt], acc0[qt][dh + u]);    // dQ^T / scale
                 }
             }
         }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     // ---- outputs: 256 rows per workgroup through the staging tile, whole rows out, column sums from the staged values ----
-    const int64_t orow0 = (int64_t)blockIdx.x * 256;
+    const int64_t orow0 = (int64_t)blockIdx.x * WGR;
     float* cs_row = cs_part ? cs_part + ((int64_t)b * gridDim.x + blockIdx.x) * cs_ld : nullptr;
     const int Hhd = a.H * a.hd;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) acc0[t][dt] *= a.scale;      // dS was accumulated without its scale factor
 #pragma unroll
     for (int which = 0; which < (MODE == 0 ? 2 : 1); ++which) {
         __syncthreads();                                 // (first pass: the last slice's reads; second: the flush before)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) out_stage16<HD, DT>(stage, 64 * wid + 16 * t, which == 0 ? acc0[t] : acc1[MODE == 0 ? t : 0], lane);
+        for (int t = 0; t < NT; ++t) out_stage16<HD, DT>(stage, 16 * NT * wid + 16 * t, which == 0 ? acc0[t] : acc1[MODE == 0 ? t : 0], lane);
         __syncthreads();
         bf16_t* dst = (which == 0 ? out0 : out1) + base + orow0 * a.q_st;
-        out_flush<HD>(stage, 256, dst, a.q_st, a.hd);
+        out_flush<HD>(stage, WGR, dst, a.q_st, a.hd);
         if (cs_row) {
             // packed qkv column order [3][H][hd]: dq = 0, dk = 1, dv = 2
             const int col = (MODE == 1 ? 0 : 1 + which) * Hhd + h * a.hd;
-            cs_from_stage<HD>(stage, a.hd, red, cs_row + col);
+            cs_from_stage<HD, WGR>(stage, a.hd, red, cs_row + col);
         }
     }
 }
@@ -391,28 +397,31 @@ static AttnMfmaArgs mk_args_big(const vaw_attn_desc* d) {
 }
 
 // true when the shape is taken (both launches enqueued); cs_part / cs_rows_out as in vaw_attn_bwd_mfma
+template <int HD, int NT>
+static void big_go(const AttnMfmaArgs& a, const vaw_attn_desc* d, const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                   const float* lse, float* delta, void* dq, void* dk, void* dv, hipStream_t s, float* cs_part, int64_t cs_ld) {
+    const int lds = BigLds<HD, NT>::bytes(d->T);
+    dim3 grid(d->T / BigLds<HD, NT>::WGR, d->B * d->H);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_big<HD, 1, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_big<HD, 0, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attn_bwd_big<HD, 1, NT><<<grid, 256, lds, s>>>(a, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)d_o,
+                                                   lse, delta, (bf16_t*)dq, nullptr, cs_part, cs_ld);
+    attn_bwd_big<HD, 0, NT><<<grid, 256, lds, s>>>(a, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)d_o,
+                                                   lse, delta, (bf16_t*)dk, (bf16_t*)dv, cs_part, cs_ld);
+}
+
 bool vaw_attn_bwd_big(const vaw_attn_desc* d, const void* q, const void* k, const void* v, const void* o, const void* d_o,
                       const float* lse, float* delta, void* dq, void* dk, void* dv, hipStream_t s, float* cs_part, int64_t* cs_rows_out) {
-    // OFF by default: measured at parity with the 16-row kernels, not ahead (see the header).  VAW_ATTN_BWD_BIG=1 switches it on
-    // (read per call: tests toggle it).
+    // VAW_ATTN_BWD_BIG: 2 (default) = 32 owner rows per wave, two workgroups per CU (T % 128 == 0); 1 = 64 owner rows per wave, one
+    // workgroup per CU (T % 256 == 0; the experiment of the header); 0 = the 16-row kernels of attention_mfma.hip.  Read per call.
     const char* e = getenv("VAW_ATTN_BWD_BIG");
-    const int on = e ? atoi(e) : 0;
-    if (!on || d->T % 256 != 0 || d->T > 1024 || d->hd <= 32 || d->hd > 96) return false;
+    const int on = e ? atoi(e) : 2;
+    const int wgr = on == 2 ? 128 : 256;
+    if ((on != 1 && on != 2) || d->T % wgr != 0 || d->T > 1024 || d->hd <= 32 || d->hd > 96) return false;
     const AttnMfmaArgs a = mk_args_big(d);
     const int64_t cs_ld = 3LL * d->H * d->hd;
-    dim3 grid(d->T / 256, d->B * d->H);
-#define BIG_GO(HDv)                                                                                                                  \
-    do {                                                                                                                             \
-        const int lds = BigLds<HDv>::bytes(d->T);                                                                                    \
-        (void)hipFuncSetAttribute((const void*)attn_bwd_big<HDv, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);               \
-        (void)hipFuncSetAttribute((const void*)attn_bwd_big<HDv, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);               \
-        attn_bwd_big<HDv, 1><<<grid, 256, lds, s>>>(a, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o,       \
-                                                    (const bf16_t*)d_o, lse, delta, (bf16_t*)dq, nullptr, cs_part, cs_ld);           \
-        attn_bwd_big<HDv, 0><<<grid, 256, lds, s>>>(a, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o,       \
-                                                    (const bf16_t*)d_o, lse, delta, (bf16_t*)dk, (bf16_t*)dv, cs_part, cs_ld);       \
-    } while (0)
-    if (d->hd <= 64) BIG_GO(64); else BIG_GO(96);
-#undef BIG_GO
-    if (cs_rows_out) *cs_rows_out = (int64_t)d->B * (d->T / 256);
+    if (d->hd <= 64) { if (on == 2) big_go<64, 2>(a, d, q, k, v, o, d_o, lse, delta, dq, dk, dv, s, cs_part, cs_ld); else big_go<64, 4>(a, d, q, k, v, o, d_o, lse, delta, dq, dk, dv, s, cs_part, cs_ld); }
+    else { if (on == 2) big_go<96, 2>(a, d, q, k, v, o, d_o, lse, delta, dq, dk, dv, s, cs_part, cs_ld); else big_go<96, 4>(a, d, q, k, v, o, d_o, lse, delta, dq, dk, dv, s, cs_part, cs_ld); }
+    if (cs_rows_out) *cs_rows_out = (int64_t)d->B * (d->T / wgr);
     return true;
 }
