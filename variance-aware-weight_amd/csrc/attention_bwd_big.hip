@@ -34,6 +34,11 @@
 //       set-up, two staged outputs and dispatch gap, nor the serial MFMA / softmax / LDS phases inside a slice (PMC: MFMA pipe busy
 //       19 % of the wave time, VALU 32 %, waiting 33 %).  Two smaller workgroups cover each other; what the big one would need is
 //       the slice loop as a hand-placed software pipeline and a persistent workgroup that prefetches the next pair's owner fragments.
+// Where the default form's time goes (tools/attn_abl.sh: measurement builds -DBIG_ABL=n, results wrong, timing only; DiT-XL/2, DiT-B/2,
+// ADM_64 32 x 32; base 400 / 350 / 1718 us): no slice barrier -1.5 %; no exp -1..-5 %; no LDS waits -1..-4 %; no barrier and no DMA wait
+// -9 / -3 / -3 %; NO MFMAs at all -22 / -16 / -37 %; no slice DMA in the loop -23 / -6 / -12 %.  No single term dominates: the loop is
+// ~335 vector instructions per slice and wave for 48 MFMAs (95 of them integer address arithmetic), and the fixed costs per workgroup
+// weigh as much as the loop at T = 256.
 // Reference: timm Attention's backward as autograd derives it (models/dit.py:126) / QKVAttention (models/unet.py:350-394).
 #include "attention_mfma.h"
 
@@ -90,12 +95,32 @@ __device__ __forceinline__ bf16x4 lds_rd64tr(unsigned addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
     return v;
 }
+#ifndef BIG_ABL
+#define BIG_ABL 0
+#endif
+#if BIG_ABL == 3
+#define LDS_WAIT() __builtin_amdgcn_sched_barrier(0)
+#else
 #define LDS_WAIT()                                          \
     do {                                                    \
         __builtin_amdgcn_sched_barrier(0);                  \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
         __builtin_amdgcn_sched_barrier(0);                  \
     } while (0)
+#endif
+#if BIG_ABL == 5
+#undef MFMA
+#define MFMA(a, b, c) big_fake_mfma(a, b, c)
+__device__ __forceinline__ f32x4 big_fake_mfma(bf16x8 a, bf16x8 b, f32x4 c) {      // keeps the operands alive, one VALU op
+    c[0] += (float)a[0] * (float)b[0];
+    return c;
+}
+#endif
+#if BIG_ABL == 2
+#define BIG_EXP2(x) (x)
+#else
+#define BIG_EXP2(x) __builtin_amdgcn_exp2f(x)
+#endif
 // frag_rows / frag_cols_perm of attention_mfma.h on an image given by its LDS byte address
 template <int HD>
 __device__ __forceinline__ bf16x8 afrag_rows(unsigned img, int r0, int s, int lane) {
@@ -244,9 +269,16 @@ attn_bwd_big(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __restr
         const unsigned ximg = ring + (unsigned)((sl % NB) * 2 * SIMG), yimg = ximg + SIMG;
         {
             const int last = sl + DEPTH - 1 < n_slices - 1 ? sl + DEPTH - 1 : n_slices - 1;      // youngest slice issued so far
+#if BIG_ABL != 4
             wait_vm((last - sl) * dma_per_slice);        // this wave's pieces of slice sl have landed ...
+#endif
+#if BIG_ABL != 1 && BIG_ABL != 4                         // (measurement builds, -DBIG_ABL=n: 1 no barrier, 2 no exp, 3 no LDS waits, 4 no
+                                                         //  barrier and no DMA wait, 5 no MFMAs, 6 no slice DMA in the loop: wrong results)
             __builtin_amdgcn_s_barrier();                // ... everybody's have; and everybody is done with slice sl - 1
+#endif
+#if BIG_ABL != 6
             if (sl + DEPTH < n_slices) issue(sl + DEPTH);                                       // into the buffer slice sl - 1 used
+#endif
         }
         if (MODE == 0) {
             bf16x8 xa[2][KS], ya[2][KS];
@@ -289,7 +321,7 @@ attn_bwd_big(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __restr
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int jt = 0; jt < NT; ++jt) {
-                        const float pr = __builtin_amdgcn_exp2f(c[jt][r] * c2 - L4[it][r]);
+                        const float pr = BIG_EXP2(c[jt][r] * c2 - L4[it][r]);
                         p[it][jt][r] = pr;
                         ds[it][jt][r] = pr * (d[jt][r] - D4[it][r]);      // (x scale: once, on the accumulated dK^T)
                     }
@@ -347,7 +379,7 @@ attn_bwd_big(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __restr
                 for (int qt = 0; qt < NT; ++qt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        ds[kt][qt][r] = __builtin_amdgcn_exp2f(c[qt][r] * c2 - lse_q[qt]) * (d[qt][r] - del_q[qt]);      // (x scale: on dQ^T)
+                        ds[kt][qt][r] = BIG_EXP2(c[qt][r] * c2 - lse_q[qt]) * (d[qt][r] - del_q[qt]);      // (x scale: on dQ^T)
             }
             bf16x8 sf[NT];
 #pragma unroll
