@@ -152,6 +152,55 @@ def test_trainer_trajectory_kl_objective_vs_oracle_trainer(loss):
     np.testing.assert_allclose(got, want, rtol=1e-4)
 
 
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("mode", ["bf16", "fp8"])
+def test_ema_model_forward_follows_training(mode, fused):
+    """The EMA copy is rewritten through raw pointers (fused AdamW+EMA kernel / ops.ema_update), which moves no parameter version:
+    its bf16 shadow and fp8 weight copies must be dropped explicitly (FlatModule.mark_weights_changed), or an EMA model that was
+    forwarded once keeps answering with the weights of that first forward (periodic sampling / evaluation during training, as the
+    reference main loop does).  EMA forward, two training steps with a fast-moving average, EMA forward again: the second answer must
+    match an f32 model carrying the current average within the mode's tolerance, and must differ from the first."""
+    random.seed(1); np.random.seed(1); torch.manual_seed(1)
+    kw = dict(image_size=8, patch_size=2, in_channels=4, hidden_size=128, depth=2, num_heads=2, class_dropout_prob=0.0, num_classes=10,
+              learn_sigma=False)
+    model = vaw_amd.DiT(**kw, compute_dtype=mode).to(DEV)
+    with torch.no_grad():                                     # adaLN-Zero would make every output 0: move off the init
+        for p_ in model.parameters():
+            if p_.requires_grad:
+                p_.add_(torch.randn_like(p_) * 0.05)
+    ema_model = copy.deepcopy(model)
+    opt = vaw_amd.FusedAdamW(model, lr=5e-2, betas=(0.9, 0.95), weight_decay=0.0, eps=1e-8)
+    decay = 0.5
+    if fused:
+        opt.attach_ema(ema_model, decay)
+    B = 32
+    x = torch.randn(B, 4, 8, 8, device=DEV)
+    t = torch.rand(B, device=DEV) * 999.0
+    y = torch.randint(0, 10, (B,), device=DEV)
+    ema_model.eval()
+    with torch.no_grad():
+        out0 = ema_model(x, t, y)[0].clone()
+    for _ in range(2):
+        out, _ = model(x, t, y)
+        (out.float() ** 2).mean().backward()
+        opt.step()
+        opt.zero_grad()
+        if not fused:
+            vaw_amd.ema(model, ema_model, decay)
+    with torch.no_grad():
+        out1 = ema_model(x, t, y)[0].clone()
+    ref = vaw_amd.DiT(**kw, compute_dtype="fp32").to(DEV)
+    ref.load_state_dict(ema_model.state_dict())
+    ref.eval()
+    with torch.no_grad():
+        want = ref(x, t, y)[0]
+    # rms error relative to the rms of the answer; a stale copy is off by the whole weight movement
+    rms = lambda v: float(v.float().pow(2).mean().sqrt())
+    e1, e0 = rms(out1 - want) / rms(want), rms(out0 - want) / rms(want)
+    assert e1 < (0.03 if mode == "bf16" else 0.20), (e1, e0)      # (e4m3 on this tiny random model: 0.13; the stale copy: 0.91)
+    assert e0 > 3 * e1, ("the average did not move enough for this test to mean anything", e1, e0)
+
+
 def test_trainer_trajectory_dit_b4_fp32_vs_reference():
     """BASELINE config 4 (DiT-B/4 on 4x32x32 latents, 130 M parameters) at batch 8: 3 reference steps."""
     exp = load_json("trainer.json")["dit_b4_b8"]
