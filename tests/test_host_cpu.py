@@ -328,6 +328,38 @@ def test_sharded_sampler_equals_torch_distributed_sampler(n, world, shuffle, dro
             assert set(seen) == set(data)
 
 
+def test_sharded_sampler_in_a_loader_the_way_trainer_drives_it():
+    """The loader contract of Trainer (tools/trainer.py:38,52,70-71): re-iterable, `.sampler.set_epoch(step)` called every step when
+    args.parallel.  A minimal batch loader over ShardedSampler, wrapped in DevicePrefetcher (which forwards `.sampler`): the ranks'
+    batches of one epoch tile the dataset, and set_epoch through the wrapper reshuffles them."""
+    n, world, bs = 40, 2, 5
+    data, labels = torch.arange(n).float().view(n, 1), torch.arange(n) % 10
+
+    class Loader:
+        def __init__(self, rank):
+            self.sampler = vaw_amd.ShardedSampler(n, world, rank, shuffle=True, seed=3)
+
+        def __len__(self):
+            return len(self.sampler) // bs
+
+        def __iter__(self):
+            idx = list(self.sampler)
+            for i in range(0, len(idx) - bs + 1, bs):
+                j = torch.tensor(idx[i:i + bs])
+                yield data[j], labels[j]
+
+    loaders = [vaw_amd.DevicePrefetcher(Loader(r), "cpu", depth=2) for r in range(world)]
+    seen = {}
+    for step in (0, 1):
+        for ld in loaders:
+            ld.sampler.set_epoch(step)            # what Trainer.train_step does first (trainer.py:70-71)
+        got = [torch.cat([x.view(-1) for x, _ in ld]).long().tolist() for ld in loaders]
+        assert sorted(got[0] + got[1]) == list(range(n)), "the two ranks must tile the epoch"
+        seen[step] = got
+    assert seen[0] != seen[1], "set_epoch through the prefetcher must reshuffle"
+    assert len(loaders[0]) == n // world // bs
+
+
 @pytest.mark.parametrize("name", ["UNet-32", "ADM-32", "UNet-64", "LDM"])
 def test_unet_factories_have_the_reference_structure(name):
     """Every UNet factory of models/unet.py:921-1032 builds (no GPU needed to construct) with the state_dict keys, shapes and
