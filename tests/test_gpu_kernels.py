@@ -566,10 +566,12 @@ def test_attention_backward_other_variants(B, H, T, hd, variant):
     32-rows-per-wave pair of attention_bwd_big.hip, which test_attention_token_major runs) give the same gradients and column sums
     as the reference within the bf16 tolerance."""
     os.environ["VAW_ATTN_BWD_BIG"] = variant
+    os.environ["VAW_ATTN_FWD_BIG"] = "1" if variant == "0" else "0"      # (and the forward's two forms, crossed with the backward's)
     try:
         _attention_token_major(torch.bfloat16, dict(rtol=3e-2, atol=3e-2), B, H, T, hd)
     finally:
         del os.environ["VAW_ATTN_BWD_BIG"]
+        del os.environ["VAW_ATTN_FWD_BIG"]
 
 
 _forced_rowwise = [False]

@@ -1,4 +1,4 @@
-// Attention backward for sequences that are multiples of 128 tokens up to 1024 (DiT-B/2 and DiT-XL/2: T = 256; the UNets' 16 x 16
+// Attention backward (and, for the 96-wide head images, forward: attn_fwd_big below) for sequences that are multiples of 128 tokens up to 1024 (DiT-B/2 and DiT-XL/2: T = 256; the UNets' 16 x 16
 // and 32 x 32 attention levels: T = 256 / 1024), head dims 40 .. 96: owner rows in registers, the other side streamed through a
 // deep LDS-DMA ring in 32-row slices.  The default backward for these shapes since round 3 (attn_bwd_dq_mfma / attn_bwd_dkv_mfma of
 // attention_mfma.hip keep the rest: T % 64, head dims up to 128).
@@ -423,6 +423,144 @@ attn_bwd_big(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// forward in the same form: a wave owns 16 NT queries (Q fragments in registers, O^T accumulators), K and V stream through the ring
+// in 32-key slices; online softmax per query with the running maximum on the lane (base-2 domain, deferred rescale as in
+// attn_fwd_mfma: the maximum only moves when a slice exceeds it by more than 2^6).  S^T[key][q] = K_s Q_w^T, O^T[hd][q] += V_s^T P^T.
+// ------------------------------------------------------------------------------------------------
+template <int HD, int NT>
+__global__ void __launch_bounds__(256, NT == 2 ? 2 : 1)
+attn_fwd_big(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+             bf16_t* __restrict__ o, float* __restrict__ lse) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KS = HD / 32, DT = HD / 16, SIMG = BigLds<HD, NT>::SIMG, WGR = BigLds<HD, NT>::WGR;
+    constexpr int NB = BigLds<HD, NT>::NB, DEPTH = NB - 1;
+    char* slices = smem;
+    char* stage = smem;
+    const int lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
+    const int64_t base = b * a.q_sb + h * a.q_sh, obase = b * a.o_sb + h * a.o_sh;
+    const int own0 = blockIdx.x * WGR + 16 * NT * wid;
+    const float c2 = a.scale * 1.4426950408889634f;
+    const bf16_t* xs = k + base;
+    const bf16_t* ys = v + base;
+    const int n_slices = a.T / 32;
+    constexpr int PIECES = (32 * Img<HD>::PCH + 63) / 64;
+    const int dma_per_slice = 2 * ((PIECES - wid + 3) / 4);
+    auto issue = [&](int sl) {
+        char* nx = slices + (sl % NB) * 2 * SIMG;
+        stage_rows<HD, 32>(xs + (int64_t)sl * 32 * a.q_st, a.q_st, nx, wid, lane, a.hd);
+        stage_rows<HD, 32>(ys + (int64_t)sl * 32 * a.q_st, a.q_st, nx + SIMG, wid, lane, a.hd);
+    };
+    for (int sl = 0; sl < DEPTH && sl < n_slices; ++sl) issue(sl);
+    bf16x8 qf[NT][KS];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int ch = 32 * s + 8 * g;
+            const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            qf[t][s] = ch < a.hd ? *reinterpret_cast<const bf16x8*>(q + base + (int64_t)(own0 + 16 * t + li) * a.q_st + ch) : z;
+        }
+    f32x4 ot[NT][DT];
+    float m[NT], l[NT];                  // running maximum (whole query: equal on its 4 lanes), this LANE's share of the running sum
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        m[t] = -INFINITY;
+        l[t] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) ot[t][dt] = f32x4{0, 0, 0, 0};
+    }
+    const unsigned ring = (unsigned)(uintptr_t)(lds_ptr_t)slices;
+    for (int sl = 0; sl < n_slices; ++sl) {
+        const unsigned ximg = ring + (unsigned)((sl % NB) * 2 * SIMG), yimg = ximg + SIMG;
+        {
+            const int last = sl + DEPTH - 1 < n_slices - 1 ? sl + DEPTH - 1 : n_slices - 1;
+            wait_vm((last - sl) * dma_per_slice);
+            __builtin_amdgcn_s_barrier();
+            if (sl + DEPTH < n_slices) issue(sl + DEPTH);
+        }
+        bf16x8 xa[2][KS];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) xa[kt][s] = afrag_rows<HD>(ximg, 16 * kt, s, lane);
+        LDS_WAIT();
+        bf16x4 yl[2][2], yh[2][2];
+        auto rd_pair = [&](int dh, int pp) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) afrag_cols_perm<HD>(yimg, 16 * (dh + u), lane, yl[pp][u], yh[pp][u]);
+        };
+        rd_pair(0, 0);
+        const f32x4 zero4 = {0, 0, 0, 0};
+        f32x4 c[2][NT];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int qt = 0; qt < NT; ++qt) c[kt][qt] = MFMA(xa[kt][s], qf[qt][s], s == 0 ? zero4 : c[kt][qt]);      // S^T [key 4g + r][query li]
+        bf16x8 pf[NT];
+        bool any_rescale = false;
+        float alpha[NT];
+#pragma unroll
+        for (int qt = 0; qt < NT; ++qt) {
+            float bm = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bm = fmaxf(bm, c[kt][qt][r]);
+            float m_new = fmaxf(m[qt], group_max(bm) * c2);
+            if (m_new - m[qt] <= 6.f) m_new = m[qt];            // (first slice: m = -inf -> always taken over)
+            alpha[qt] = __builtin_amdgcn_exp2f(m[qt] - m_new);   // exp2(-inf) = 0 on l = 0, ot = 0; 1 when the maximum stayed
+            float ps = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    c[kt][qt][r] = __builtin_amdgcn_exp2f(c[kt][qt][r] * c2 - m_new);
+                    ps += c[kt][qt][r];
+                }
+            l[qt] = l[qt] * alpha[qt] + ps;
+            m[qt] = m_new;
+            pf[qt] = pack_acc(c[0][qt], c[1][qt]);
+            any_rescale = any_rescale || alpha[qt] != 1.f;
+        }
+        if (!__all(!any_rescale)) {
+#pragma unroll
+            for (int qt = 0; qt < NT; ++qt)
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) ot[qt][dt] *= alpha[qt];
+        }
+#pragma unroll
+        for (int dh = 0; dh < DT; dh += 2) {
+            const int pp = (dh >> 1) & 1;
+            LDS_WAIT();
+            if (dh + 2 < DT) rd_pair(dh + 2, pp ^ 1);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const bf16x8 yt = cat44(yl[pp][u], yh[pp][u]);
+#pragma unroll
+                for (int qt = 0; qt < NT; ++qt) ot[qt][dh + u] = MFMA(yt, pf[qt], ot[qt][dh + u]);    // O^T [channel][query]
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();                                     // the last slice's reads: O is staged over the ring
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float lt = group_sum(l[t]);
+        const float inv = 1.f / lt;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) ot[t][dt] *= inv;
+        out_stage16<HD, DT>(stage, 16 * NT * wid + 16 * t, ot[t], lane);
+        if (g == 0) lse[(int64_t)bh * a.T + own0 + 16 * t + li] = m[t] * 0.6931471805599453f + __logf(lt);   // back to the natural log
+    }
+    __syncthreads();
+    out_flush<HD>(stage, WGR, o + obase + (int64_t)blockIdx.x * WGR * a.o_st, a.o_st, a.hd);
+}
+
 static AttnMfmaArgs mk_args_big(const vaw_attn_desc* d) {
     AttnMfmaArgs a{d->B, d->H, d->T, d->q_sb, d->q_sh, d->q_st, d->o_sb, d->o_sh, d->o_st, d->scale, d->hd};
     return a;
@@ -455,5 +593,27 @@ bool vaw_attn_bwd_big(const vaw_attn_desc* d, const void* q, const void* k, cons
     if (d->hd <= 64) { if (on == 2) big_go<64, 2>(a, d, q, k, v, o, d_o, lse, delta, dq, dk, dv, s, cs_part, cs_ld); else big_go<64, 4>(a, d, q, k, v, o, d_o, lse, delta, dq, dk, dv, s, cs_part, cs_ld); }
     else { if (on == 2) big_go<96, 2>(a, d, q, k, v, o, d_o, lse, delta, dq, dk, dv, s, cs_part, cs_ld); else big_go<96, 4>(a, d, q, k, v, o, d_o, lse, delta, dq, dk, dv, s, cs_part, cs_ld); }
     if (cs_rows_out) *cs_rows_out = (int64_t)d->B * (d->T / wgr);
+    return true;
+}
+
+template <int HD, int NT>
+static void big_fwd_go(const AttnMfmaArgs& a, const vaw_attn_desc* d, const void* q, const void* k, const void* v, void* o, float* lse, hipStream_t s) {
+    const int lds = BigLds<HD, NT>::FRONT;
+    dim3 grid(d->T / BigLds<HD, NT>::WGR, d->B * d->H);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_big<HD, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attn_fwd_big<HD, NT><<<grid, 256, lds, s>>>(a, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse);
+}
+
+// The owner-rows forward (T % 128 == 0).  Measured against attn_fwd_mfma (tools/attn_bench.py, interleaved): the 96-wide images win
+// (DiT-XL/2 138.7 -> 120.8 us, UNet_64 16 x 16 39.2 -> 36.6), the 64-wide ones -- where attn_fwd_mfma double-buffers K / V by LDS-DMA and
+// keeps three workgroups per CU -- lose 2-4 % (DiT-B/2 103.0 -> 105.5, ADM_64 32 x 32 641 -> 668).  So: head dims 72 .. 96 by default;
+// VAW_ATTN_FWD_BIG=1 all of 40 .. 96, =0 none.  Read per call.
+bool vaw_attn_fwd_big(const vaw_attn_desc* d, const void* q, const void* k, const void* v, void* o, float* lse, hipStream_t s) {
+    const char* e = getenv("VAW_ATTN_FWD_BIG");
+    const int on = e ? atoi(e) : 2;
+    const int hd_lo = on == 1 ? 32 : 64;
+    if (on == 0 || d->T % 128 != 0 || d->hd <= hd_lo || d->hd > 96) return false;
+    const AttnMfmaArgs a = mk_args_big(d);
+    if (d->hd <= 64) big_fwd_go<64, 2>(a, d, q, k, v, o, lse, s); else big_fwd_go<96, 2>(a, d, q, k, v, o, lse, s);
     return true;
 }

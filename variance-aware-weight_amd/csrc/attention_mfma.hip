@@ -622,8 +622,14 @@ static bool attn_qg2() {
         default: { constexpr int HD = 128; __VA_ARGS__ } break;  \
     }
 
+bool vaw_attn_fwd_big(const vaw_attn_desc* d, const void* q, const void* k, const void* v, void* o, float* lse, hipStream_t s);
+
 int vaw_attn_fwd_mfma(const vaw_attn_desc* d, const void* q, const void* k, const void* v, void* o, float* lse,
                       hipStream_t s) {
+    if (vaw_attn_fwd_big(d, q, k, v, o, lse, s)) {        // attention_bwd_big.hip
+        VAW_CHECK_LAUNCH("attn_fwd_big");
+        return VAW_OK;
+    }
     AttnMfmaArgs a = mk_args(d);
     // two 16-query groups per wave: +10..17 % for head dims <= 64 (tools/attn_bench.py), +30 % for the padded 96-wide images
     // (DiT-XL's 72, UNet_64's 96) now that their rows are conflict-free; 128-wide images keep one group (accumulators)
