@@ -572,8 +572,12 @@ static void big_go(const AttnMfmaArgs& a, const vaw_attn_desc* d, const void* q,
                    const float* lse, float* delta, void* dq, void* dk, void* dv, hipStream_t s, float* cs_part, int64_t cs_ld) {
     const int lds = BigLds<HD, NT>::bytes(d->T);
     dim3 grid(d->T / BigLds<HD, NT>::WGR, d->B * d->H);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_big<HD, 1, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_big<HD, 0, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    static bool attr_done = false;                       // (once per instantiation: the limit for the longest sequence taken, T = 1024)
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)attn_bwd_big<HD, 1, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, BigLds<HD, NT>::bytes(1024));
+        (void)hipFuncSetAttribute((const void*)attn_bwd_big<HD, 0, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, BigLds<HD, NT>::bytes(1024));
+        attr_done = true;
+    }
     attn_bwd_big<HD, 1, NT><<<grid, 256, lds, s>>>(a, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)d_o,
                                                    lse, delta, (bf16_t*)dq, nullptr, cs_part, cs_ld);
     attn_bwd_big<HD, 0, NT><<<grid, 256, lds, s>>>(a, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)d_o,
@@ -600,7 +604,11 @@ template <int HD, int NT>
 static void big_fwd_go(const AttnMfmaArgs& a, const vaw_attn_desc* d, const void* q, const void* k, const void* v, void* o, float* lse, hipStream_t s) {
     const int lds = BigLds<HD, NT>::FRONT;
     dim3 grid(d->T / BigLds<HD, NT>::WGR, d->B * d->H);
-    (void)hipFuncSetAttribute((const void*)attn_fwd_big<HD, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)attn_fwd_big<HD, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_done = true;
+    }
     attn_fwd_big<HD, NT><<<grid, 256, lds, s>>>(a, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse);
 }
 
