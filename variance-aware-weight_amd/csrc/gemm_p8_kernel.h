@@ -71,6 +71,12 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 #ifndef P8_GATE_R4
 #define P8_GATE_R4 1
 #endif
+// 1: the same 4-column lanes for the raw f32 slabs of K-split launches (conv weight gradients, half-empty input gradients).  Measured
+// on the UNet_64 conv weight gradients (tools/conv_bench.py, interleaved): +-1 %, i.e. nothing -- the slabs are re-read at once and
+// live in L2 / MALL; off.
+#ifndef P8_SLAB_R4
+#define P8_SLAB_R4 0
+#endif
 #define P8_BM 256
 #define P8_PART 8192
 #define P8_EPI_BYTES 32768
@@ -702,6 +708,32 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
                     : epi_rsrc(EK::out_q ? (const void*)((const unsigned char*)ei.C + tile_off)
                                          : c_f32 ? (const void*)((const float*)ei.C + tile_off) : (const void*)((const bf16_t*)ei.C + tile_off));
         const __amdgpu_buffer_rsrc_t rs_aux = epi_rsrc(EK::aux_out(ei) ? (const void*)((const bf16_t*)ei.aux_out + tile_off) : (const void*)ei.C);
+        if constexpr (EPI == P8_SLAB && P8_SLAB_R4 != 0 && !GRP) {
+            // ---- raw f32 partial sums of a K split, FOUR columns per lane: one 16-byte store per lane and row, 16 lanes = one
+            // 256-byte row piece of the slab (the 8-column layout writes every other 16 bytes of a row per instruction)
+            const int r4 = lane_e >> 4, c4 = lane_e & 15;
+            const int64_t n4 = n0 + wn0 + 4 * c4;
+            const bool col_ok4 = 4 * c4 < Cfg::WN && n4 < ei.N;
+            const int loc_col4 = wn0 + 4 * c4;
+            const int64_t mrow4 = m0 + wr * 128 + r4, m_last4 = ei.M - 1;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                for (int u = 0; u < NTW; ++u)
+                    asm volatile("ds_write_b128 %0, %1" ::"v"(ep_w + (unsigned)(((4 * u) ^ (wr_row & 12)) << 4)), "v"(acc[i][u]) : "memory");
+#pragma unroll
+                for (int pass = 0; pass < 4; ++pass) {
+                    const int64_t m = mrow4 + 4 * (4 * i + pass);
+                    const int rr = 4 * pass + r4;
+                    f32x4 v;
+                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(ep_base + (unsigned)(rr * 256 + ((c4 ^ rr) << 4))) : "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    const bool ok = col_ok4 && m <= m_last4;
+                    buf_store16(rs_c, ok ? 4u * (unsigned)((m - m0) * slab_ld + loc_col4) : EPI_OOB, v, false);
+                }
+            }
+            continue;
+        }
         if constexpr (EPI == P8_GATE && P8_GATE_R4 != 0) {
             // ---- gated-residual epilogue, FOUR columns per lane: the f32 output (and the f32 residual it reads) then moves as
             // whole 256-byte row pieces per 16 lanes -- one 16-byte access per lane and row -- where the 8-column layout below
