@@ -313,6 +313,85 @@ def _gemm_epilogues(dtype):
                                **(tol if dtype == torch.float32 else dict(rtol=2e-2, atol=5e-2)))
 
 
+@pytest.mark.parametrize("tile", [10, 11])
+@pytest.mark.parametrize("layout", ["fwd", "dgrad"])
+def test_gemm_parked_drain_exact_integers(layout, tile):
+    """gemm_pd_kernel (128-row tiles, the finished tile parked in registers and drained under the next tile's K loop): small
+    integers are exact, so every element of every tile must match; shapes cover edge tiles in M and N, the shortest K it
+    takes (4 K tiles: the drain does not fit under the next K loop and is flushed), an odd K tile count, one item per
+    workgroup (everything drains in the open) and 3-4 items per workgroup (steady state), with fused column sums."""
+    b_k = layout == "fwd"
+    lib().vaw_debug_gemm_tile(tile)     # 10 / 11: the parked-drain kernel with 256 / 192 columns wherever it applies
+    try:
+        for (M, N, K) in [(256, 512, 256), (200, 72, 320), (1160, 776, 832), (16384, 768, 768), (40008, 520, 768), (4096, 3072, 448)]:
+            A, B = _mk(M, N, K, True, b_k, torch.bfloat16, seed=M + N + K, ints=True)
+            Ad, Bd = A.to(DEV), B.to(DEV)
+            ref = _gemm_ref(A, B, True, b_k).float().bfloat16()
+            cs = torch.zeros(N, device=DEV)
+            got = ops.gemm_t(Ad, Bd, a_kmajor=True, b_kmajor=b_k, colsum_out=cs)
+            assert torch.equal(got.cpu(), ref), (layout, tile, M, N, K, (got.cpu().double() - ref.double()).abs().max())
+            torch.testing.assert_close(cs.cpu().double(), ref.double().sum(0), rtol=1e-6, atol=1e-2)
+            got2 = ops.gemm_t(Ad, Bd, a_kmajor=True, b_kmajor=b_k)
+            assert torch.equal(got2, got)
+    finally:
+        lib().vaw_debug_gemm_tile(-1)
+
+
+@pytest.mark.parametrize("tile", [10, 11])
+def test_gemm_parked_drain_epilogues_vs_persistent_kernel(tile):
+    """The four epilogue kinds of the Linear launches on gemm_pd_kernel against gemm_p8_kernel on the same operands: bias + store,
+    GELU with the saved pre-activation and the gated residual must be BITWISE equal (both round acc + bias to bf16 first);
+    GELU' rounds the input gradient to bf16 before the multiply (the reference's autocast order), so it is held to one bf16 ulp
+    of the persistent kernel and to the f64 reference within bf16 tolerance.  Edge rows, several items per workgroup."""
+    Bt, T, D, H = 130, 64, 768, 3072
+    M = Bt * T - 24                           # a ragged last row tile
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(M, D, generator=g).bfloat16().to(DEV)
+    w1 = (torch.randn(H, D, generator=g) * 0.05).bfloat16().to(DEV)
+    w2 = (torch.randn(D, H, generator=g) * 0.05).bfloat16().to(DEV)
+    b1, b2 = torch.randn(H, generator=g).to(DEV), torch.randn(D, generator=g).to(DEV)
+    gate = torch.randn(Bt, D, generator=g).to(DEV)
+    resid = torch.randn(M, D, generator=g).to(DEV)
+    dy = torch.randn(M, D, generator=g).bfloat16().to(DEV)
+
+    def run(t):
+        lib().vaw_debug_gemm_tile(t)
+        out = {}
+        out["qkv"] = ops.gemm_t(x, w1[:2304].contiguous(), bias=b1[:2304].contiguous())
+        a, hpre = ops.gemm_t(x, w1, bias=b1, act=1, want_aux=True)
+        out["a"], out["hpre"] = a, hpre
+        res = torch.empty(M, D, device=DEV)
+        aux = torch.empty(M, D, device=DEV, dtype=torch.bfloat16)
+        ops.gemm(BF16, 1, 1, M, D, H, ptr(a), H, ptr(w2), H, ptr(res), D, bias=ptr(b2), aux_out=ptr(aux), gate=ptr(gate), gate_ld=D,
+                 resid=ptr(resid), rows_per_batch=T, out_f32=True)
+        out["res"], out["y"] = res, aux
+        cs = torch.zeros(H, device=DEV)
+        out["dh"] = ops.gemm_t(dy, w2, b_kmajor=False, act=2, aux_in=hpre, colsum_out=cs)       # dy [M, D] . W2 [D, H] (as stored)
+        out["dh_cs"] = cs
+        cs2 = torch.zeros(D, device=DEV)
+        out["dx"] = ops.gemm_t(out["dh"], w1, b_kmajor=False, colsum_out=cs2)
+        out["dx_cs"] = cs2
+        torch.cuda.synchronize()
+        return out
+
+    try:
+        ref, got = run(3 if tile == 11 else 2), run(tile)
+    finally:
+        lib().vaw_debug_gemm_tile(-1)
+    for k in ("qkv", "a", "hpre", "res", "y"):
+        assert torch.equal(ref[k], got[k]), (k, (ref[k].double() - got[k].double()).abs().max())
+    # GELU': within one bf16 ulp of the single-rounding kernel, everywhere
+    d = (ref["dh"].double() - got["dh"].double()).abs()
+    assert bool((d <= ref["dh"].double().abs() * 2.0 ** -7 + 1e-30).all()), d.max()
+    hh = got["hpre"].double().cpu().requires_grad_(True)
+    torch.nn.functional.gelu(hh, approximate="tanh").sum().backward()
+    exact = (dy.double().cpu() @ w2.double().cpu()) * hh.grad
+    torch.testing.assert_close(got["dh"].double().cpu(), exact, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(got["dh_cs"].double().cpu(), got["dh"].double().sum(0).cpu(), rtol=1e-5, atol=1e-2)
+    torch.testing.assert_close(got["dx_cs"].double().cpu(), got["dx"].double().sum(0).cpu(), rtol=1e-5, atol=1e-2)
+    torch.testing.assert_close(got["dx"].double().cpu(), got["dh"].double().cpu() @ w1.double().cpu(), rtol=2e-2, atol=5e-2)
+
+
 @pytest.mark.parametrize("case", ["few_tiles_split", "full_rounds_plus_split", "n192", "edges_accumulate"])
 def test_wgrad_grouped_exact_integers(case):
     """vaw_wgrad_grouped: many dW_p (+)= dy_p^T x_p in one launch; whole tiles + K-split tiles of the last round + fixup.

@@ -74,7 +74,7 @@ if __name__ == "__main__":
     ap.add_argument("--shapes", default="dit_b4")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default=None, help="substring of the shape name")
-    ap.add_argument("--tile", default="auto", help="auto | 128 | 256 | both | p8 | cmp (128 vs persistent) | sm (dispatcher without the "
+    ap.add_argument("--tile", default="auto", help="auto | 128 | 256 | both | p8 | pd (auto vs parked-drain) | pdcmp | cmp (128 vs persistent) | sm (dispatcher without the "
                                                    "small-M kernel vs gemm_sm with 64- and 128-column tiles): bf16 MFMA kernel")
     ap.add_argument("--m", type=int, default=None, help="token rows instead of 16384 (dit_b4 forward / input-gradient shapes)")
     a = ap.parse_args()
@@ -83,11 +83,11 @@ if __name__ == "__main__":
     if a.m:
         DIT_B4[:] = [(n, l, a.m, N, K, e) for (n, l, _, N, K, e) in DIT_B4 if l != "wgrad"]
     from vaw_amd._lib import lib
-    tiles = {"auto": [-1], "128": [0], "256": [1], "both": [0, 1], "p8": [4], "cmp": [0, 2, 3], "p8_256": [2], "p8_192": [3], "sm": [-1, 6, 7, 8]}[a.tile]
+    tiles = {"auto": [-1], "128": [0], "256": [1], "both": [0, 1], "p8": [4], "cmp": [0, 2, 3], "p8_256": [2], "p8_192": [3], "sm": [-1, 6, 7, 8], "pd": [-1, 9], "pdcmp": [2, 3, 10, 11]}[a.tile]
     for row in {"dit_b4": DIT_B4, "square": SQUARE, "unet64": UNET64, "all": DIT_B4 + SQUARE, "rounds": ROUNDS}[a.shapes]:
         if a.only is None or a.only in row[0]:
             for t in tiles:
                 lib().vaw_debug_gemm_tile(t)
                 if len(tiles) > 1:
-                    print(f"[tile {('128', '256', 'p8/256', 'p8/192', 'p8', 'sm', 'sm/64', 'sm/128', 'sm/128x128', 'auto')[t]}] ", end="")
+                    print(f"[tile {('128', '256', 'p8/256', 'p8/192', 'p8', 'sm', 'sm/64', 'sm/128', 'sm/128x128', 'pd', 'pd/256', 'pd/192', 'auto')[t]}] ", end="")
                 run(*row, a.iters)

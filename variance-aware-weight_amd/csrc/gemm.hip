@@ -734,10 +734,18 @@ bool vaw_p8_conv(int mode, const bf16_t* act, const bf16_t* act2, const bf16_t* 
 void vaw_p8_launch(const P8Plan& pl, int a_kmajor, int b_kmajor, int64_t M, int64_t N, int64_t K, const bf16_t* a, int64_t lda,
                    const bf16_t* b, int64_t ldb, const EpiDev& e, hipStream_t s);
 
+// the parked-drain kernel (gemm_pd.hip)
+int vaw_pd_epi_kind(const EpiDev& e, bool a_kmajor, bool b_kmajor, int64_t M, int64_t N, int64_t K);
+int vaw_pd_pick_ntw(int64_t M, int64_t N, int cus_avail);
+void vaw_pd_launch(int ntw, int epi, int b_kmajor, int64_t M, int64_t N, int64_t K, const bf16_t* a, int64_t lda, const bf16_t* b,
+                   int64_t ldb, const EpiDev& e, int cus_avail, hipStream_t s);
+int vaw_p8_cus_available();
+
 static int g_force_generic = 0;
 extern "C" void vaw_debug_force_generic_gemm(int on) { g_force_generic = on; }
 // bf16 MFMA tile choice: -1 = by shape (default), 0 = always 128 x 128, 1 = always the 256 x 256 ring kernel,
-// 2 / 3 = always the persistent kernel with 256 / 192 columns, 4 = always the persistent kernel (width by shape).
+// 2 / 3 = always the persistent kernel with 256 / 192 columns, 4 = always the persistent kernel (width by shape),
+// 5-8 = the small-M ring kernel, 9 / 10 / 11 = the parked-drain kernel wherever it applies (width by shape / 256 / 192 columns).
 // Env VAW_GEMM_BIG seeds it.
 static int g_gemm_tile = -2;
 extern "C" void vaw_debug_gemm_tile(int mode) { g_gemm_tile = mode; }
@@ -939,6 +947,38 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
         else LAUNCH_FAST(false, false, BKTv);                        \
     } while (0)
         if (g_gemm_tile == -2) { const char* v = getenv("VAW_GEMM_BIG"); g_gemm_tile = v ? atoi(v) : -1; }
+        {
+            // parked-drain kernel (gemm_pd_kernel.h): the un-split forward / input-gradient launches of the Linear layers whose
+            // epilogue it can hide under the next tile's K loop.  VAW_GEMM_PD=0 switches the automatic choice off.
+            static int pd_auto = -1;
+            if (pd_auto < 0) { const char* v = getenv("VAW_GEMM_PD"); pd_auto = v ? atoi(v) : 1; }
+            const bool pd_forced = g_gemm_tile >= 9 && g_gemm_tile <= 11;
+            const int64_t rows64 = (M + 63) / 64;
+            EpiDev epd = e;          // (e.colpart is set above when this launch carries column sums)
+            const int pd_kind = (pd_forced || (pd_auto && g_gemm_tile == -1)) && bk_env == 0 && !rowsum_out &&
+                                        (!colsum_out || colsum_part || workspace_floats >= rows64 * N)
+                                    ? vaw_pd_epi_kind(epd, a_kmajor != 0, b_kmajor != 0, M, N, K) : -1;
+            if (pd_kind >= 0) {
+                const int cus = vaw_p8_cus_available();
+                const int ntw = g_gemm_tile == 10 ? 4 : g_gemm_tile == 11 ? 3 : vaw_pd_pick_ntw(M, N, cus);
+                const int64_t items = ((M + 127) / 128) * ((N + 64 * ntw - 1) / (64 * ntw));
+                // by shape: at least two rounds of workgroups (the first tile of a workgroup has nothing to hide its epilogue
+                // under... the last one's leaves in the open), K of the blocks' Linear layers
+                const bool pd_shape = items >= 2 * cus && K >= 768 && K <= 4096;
+                if (pd_forced || pd_shape) {
+                    CS_CAP_CHECK(rows64);
+                    static int nt_aux = -1;
+                    if (nt_aux < 0) { const char* v = getenv("VAW_P8_NT_AUX"); nt_aux = (v && atoi(v) == 0) ? 0 : 1; }
+                    epd.nt_off = 1;
+                    epd.nt_aux = nt_aux;
+                    epd.colpart = colsum_out ? colsum_dst : nullptr;
+                    vaw_pd_launch(ntw, pd_kind, b_kmajor, M, N, K, a, lda, b, ldb, epd, cus, s);
+                    VAW_CHECK_LAUNCH("gemm_pd");
+                    if (colsum_out) return fold_colsum(rows64);
+                    return VAW_OK;
+                }
+            }
+        }
         {
             const int force = g_gemm_tile == -1 ? -1 : g_gemm_tile == 4 ? 1 : (g_gemm_tile == 2 || g_gemm_tile == 3) ? g_gemm_tile : 0;
             const bool p8_epi_ok = !(e.act == 2 && e.gate) && !(e.resid && e.rowadd);     // gemm_epi.h: EpiOps has two slots

@@ -35,6 +35,8 @@ static int p8_num_cus() {
     return (r > 0 && r < n - 8) ? n - r : n;
 }
 
+int vaw_p8_cus_available() { return p8_num_cus(); }
+
 // Measured on MI355X (tools/gemm_bench.py --tile cmp, DiT-B/4 shapes, one process): per item the 192-column tile costs
 // ~0.85x the 256-column one in multi-round launches (12 instead of 16 MFMAs per phase over the same barriers; 96-byte bf16
 // row segments in its epilogue) and is no faster when every workgroup has one item only (N = 768: 192 vs 256 items), so
