@@ -318,12 +318,12 @@ def _gemm_epilogues(dtype):
 def test_gemm_parked_drain_exact_integers(layout, tile):
     """gemm_pd_kernel (128-row tiles, the finished tile parked in registers and drained under the next tile's K loop): small
     integers are exact, so every element of every tile must match; shapes cover edge tiles in M and N, the shortest K it
-    takes (4 K tiles: the drain does not fit under the next K loop and is flushed), an odd K tile count, one item per
-    workgroup (everything drains in the open) and 3-4 items per workgroup (steady state), with fused column sums."""
+    takes (12 K tiles: the unrolled drain K tiles and nothing else), an odd K tile count, one item per workgroup (everything
+    drains in the open) and 3-4 items per workgroup (steady state), with fused column sums."""
     b_k = layout == "fwd"
     lib().vaw_debug_gemm_tile(tile)     # 10 / 11: the parked-drain kernel with 256 / 192 columns wherever it applies
     try:
-        for (M, N, K) in [(256, 512, 256), (200, 72, 320), (1160, 776, 832), (16384, 768, 768), (40008, 520, 768), (4096, 3072, 448)]:
+        for (M, N, K) in [(256, 512, 768), (200, 72, 832), (1160, 776, 832), (16384, 768, 768), (40008, 520, 768), (20000, 3072, 960)]:
             A, B = _mk(M, N, K, True, b_k, torch.bfloat16, seed=M + N + K, ints=True)
             Ad, Bd = A.to(DEV), B.to(DEV)
             ref = _gemm_ref(A, B, True, b_k).float().bfloat16()

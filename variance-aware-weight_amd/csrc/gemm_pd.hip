@@ -19,7 +19,8 @@ static int pd_num_cus() {
 // Epilogue kind this kernel offers for the launch, or -1.  (Same classification as vaw_p8_launch; K-split launches, f32 plain
 // outputs, fused row sums and the UNet's residual kinds stay with gemm_p8_kernel.)
 int vaw_pd_epi_kind(const EpiDev& e, bool a_kmajor, bool b_kmajor, int64_t M, int64_t N, int64_t K) {
-    if (!a_kmajor || K % 64 != 0 || K / 64 < 4 || N % 8 != 0 || M < PD_BM) return -1;
+    // (K >= 12 K tiles: the longest drain -- 8 steps + 2 slots of operand lead -- and the two K tiles behind it are unrolled in front of the K loop)
+    if (!a_kmajor || K % 64 != 0 || K / 64 < 12 || N % 8 != 0 || M < PD_BM) return -1;
     const bool bf16_out = !e.out_f32;
     if (e.act == 1 && e.aux_out && !e.gate && !e.resid && !e.rowadd && bf16_out && !e.colpart && b_kmajor) return P8_GELU;
     if (e.act == 2 && !e.bias && !e.aux_out && !e.gate && !e.resid && !e.rowadd && bf16_out && e.alpha == 1.f && !b_kmajor) return P8_DGELU;
