@@ -949,9 +949,11 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
         if (g_gemm_tile == -2) { const char* v = getenv("VAW_GEMM_BIG"); g_gemm_tile = v ? atoi(v) : -1; }
         {
             // parked-drain kernel (gemm_pd_kernel.h): the un-split forward / input-gradient launches of the Linear layers whose
-            // epilogue it can hide under the next tile's K loop.  VAW_GEMM_PD=0 switches the automatic choice off.
+            // epilogue it can hide under the next tile's K loop.  Measured level with or behind the 256-row
+            // kernel on every DiT-B/4 shape, so the automatic choice is OFF: VAW_GEMM_PD=1 switches it on by shape,
+            // vaw_debug_gemm_tile(9 / 10 / 11) forces it (tests, A/B runs).
             static int pd_auto = -1;
-            if (pd_auto < 0) { const char* v = getenv("VAW_GEMM_PD"); pd_auto = v ? atoi(v) : 1; }
+            if (pd_auto < 0) { const char* v = getenv("VAW_GEMM_PD"); pd_auto = v ? atoi(v) : 0; }
             const bool pd_forced = g_gemm_tile >= 9 && g_gemm_tile <= 11;
             const int64_t rows64 = (M + 63) / 64;
             EpiDev epd = e;          // (e.colpart is set above when this launch carries column sums)

@@ -77,6 +77,12 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 #ifndef P8_SLAB_R4
 #define P8_SLAB_R4 0
 #endif
+// 1: the DMA stream never "ends": past its last item it keeps issuing pieces at out-of-range offsets (zeros into a stage nobody
+// reads), so the K loop needs neither the per-piece `if (iss_done)` nor the two forms of every counted wait -- 12 scalar branches
+// per K tile gone (lesson of gemm_pd_kernel.h, where such branches cost 25 %)
+#ifndef P8_NOBR
+#define P8_NOBR 1
+#endif
 #define P8_BM 256
 #define P8_PART 8192
 #define P8_EPI_BYTES 32768
@@ -214,6 +220,7 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
     static_assert(CONV == 0 || (CONV == 1 && AK && BKM) || (CONV == 2 && AK && !BKM) || (CONV == 3 && !AK && !BKM), "conv layouts");
     using Cfg = P8Cfg<NTW>;
     constexpr int LS = 4 + NTW;                                  // DMA pieces per wave and K tile
+    constexpr bool NOBR = P8_NOBR != 0 && CONV != 3;             // (the transposed conv weight gradient spills 24 bytes with it)
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A parts 0-3 | B parts] | 8 x 4 KiB epilogue images
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -356,10 +363,25 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
         for (int p = 0; p < NTW; ++p) off_b[p] = p8_src_off<BKM, ES, F8 != 0>(false, p, wid, lane, t.ldb, nvalid);
     };
     if (!iss_done) iss_open();
+    auto iss_close = [&]() {                      // P8_NOBR: every later piece reads out of range
+#pragma unroll
+        for (int p = 0; p < 4; ++p) off_a[p] = EPI_OOB;
+#pragma unroll
+        for (int p = 0; p < NTW; ++p) off_b[p] = EPI_OOB;
+        if (CONV == 1 || CONV == 2) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) vm_a[p] = 0u;
+        }
+        if (CONV == 3) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) ga_dh[p] = 1 << 20;
+        }
+    };
+    if (NOBR && iss_done) iss_close();
     // piece c of the stream order [B parts 0..NTW-1, A parts 0..3]
     auto iss_piece = [&](auto cc) {
         constexpr int c = decltype(cc)::value;
-        if (iss_done) return;
+        if (!NOBR && iss_done) return;
         char* dst = smem + iss_stage * Cfg::stage_bytes + wid * 1024;
         if (c < NTW) {
             p8_dma16(rs_b, dst + Cfg::a_bytes + c * P8_PART, off_b[c < NTW ? c : 0], so_b);
@@ -385,7 +407,8 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
         }
     };
     auto iss_advance = [&]() {                    // after the last piece of a K tile
-        if (iss_done) return;
+        if (!NOBR && iss_done) return;
+        if (NOBR && iss_done) { iss_stage ^= 1; return; }
         iss_stage ^= 1;
         if (CONV == 1 || CONV == 2) {
             if (++iss_tw == 3) { iss_tw = 0; if (++iss_th == 3) { iss_th = 0; iss_c0 += 64; } }
@@ -395,7 +418,7 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
         }
         if (++iss_kt == iss_nk) {
             iss_item += G;
-            if (iss_item >= n_items) iss_done = true;
+            if (iss_item >= n_items) { iss_done = true; if (NOBR) iss_close(); }
             else iss_open();
         } else if (CONV == 1 || CONV == 2) {
             conv_point();
@@ -415,7 +438,7 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
     constexpr bool LATE = CONV != 0 || !AK;
 #define P8_WAIT(n_full)                                                                     \
     do {                                                                                    \
-        if (iss_done) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      \
+        if (!NOBR && iss_done) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              \
         else asm volatile("s_waitcnt vmcnt(" #n_full ")" ::: "memory");                     \
     } while (0)
 
@@ -909,6 +932,7 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
             }
         }
     }
+    if (NOBR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the stream's trailing out-of-range pieces still target this workgroup's LDS
 #ifdef P8_TIMING
     if (blockIdx.x == 0 && lane == 0 && (wid == 0 || wid == 4)) {
         __builtin_amdgcn_s_waitcnt(0);

@@ -494,6 +494,7 @@ gemm_pd_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
     }
     // the last tile of this workgroup: nothing left to hide it under
     if (parked) pd_unroll([&](auto dd) __attribute__((always_inline)) { run_slot(dd, std::true_type{}); }, std::make_integer_sequence<int, DMAX>{});
+    pd_vmwait<0>();        // the stream's trailing out-of-range pieces still target this workgroup's LDS
 }
 
 template <bool BKM, int NTW, int EPI>
