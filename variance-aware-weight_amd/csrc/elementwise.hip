@@ -524,9 +524,17 @@ __device__ __forceinline__ void adam_one(float& p, float& g, float& m, float& v,
     if (has_ema) e = e * a.ema_decay + p * (1.f - a.ema_decay);
 }
 
-__global__ void adamw_ema_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
-                                 float* __restrict__ v, float* __restrict__ ema, bf16_t* __restrict__ shadow, int64_t n,
-                                 const float* __restrict__ sumsq, AdamArgs a, const float* __restrict__ hyper) {
+// Each workgroup walks contiguous tiles of ADAM_U x 256 float4 per stream (16 KiB of p, g, m, v and ema each): every lane has
+// ADAM_U independent 16-byte loads of all five streams in flight before the first use (20 loads per lane instead of 5), a stream's
+// accesses stay inside one DRAM page run per tile instead of hopping 8 MiB between iterations, and every byte is touched once per
+// step (38 B per parameter, 5 GB for DiT-B: nothing of it is in a cache when the next step comes round) -> non-temporal loads and
+// stores.  Round 3's one-float4-per-iteration grid-stride loop ran at 5.0 TB/s of these bytes.
+#define ADAM_U 4
+__device__ __forceinline__ f32x4 nt_load4(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); }
+__global__ void __launch_bounds__(256)
+adamw_ema_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                 float* __restrict__ ema, bf16_t* __restrict__ shadow, int64_t n, const float* __restrict__ sumsq, AdamArgs a,
+                 const float* __restrict__ hyper) {
     if (hyper) {          // step-dependent scalars from device memory: the launch can then sit in a replayed hipGraph
         a.lr = hyper[0];
         a.bc1 = hyper[1];
@@ -539,7 +547,36 @@ __global__ void adamw_ema_kernel(float* __restrict__ p, float* __restrict__ g, f
     }
     const int64_t n4 = n / 4;
     const bool has_ema = ema != nullptr;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    constexpr int64_t TILE = (int64_t)ADAM_U * 256;                  // float4 per tile
+    const int64_t n_tiles = n4 / TILE;
+    for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const int64_t i0 = t * TILE + threadIdx.x;
+        f32x4 pv[ADAM_U], gv[ADAM_U], mv[ADAM_U], vv[ADAM_U], ev[ADAM_U];
+#pragma unroll
+        for (int u = 0; u < ADAM_U; ++u) {
+            const int64_t i = 4 * (i0 + 256 * u);
+            pv[u] = nt_load4(p + i); gv[u] = nt_load4(g + i); mv[u] = nt_load4(m + i); vv[u] = nt_load4(v + i);
+            ev[u] = has_ema ? nt_load4(ema + i) : f32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int u = 0; u < ADAM_U; ++u) {
+            const int64_t i = 4 * (i0 + 256 * u);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float pj = pv[u][j], gj = gv[u][j], mj = mv[u][j], vj = vv[u][j], ej = ev[u][j];
+                adam_one(pj, gj, mj, vj, ej, has_ema, gs, a);
+                pv[u][j] = pj; mv[u][j] = mj; vv[u][j] = vj; ev[u][j] = ej;
+            }
+            __builtin_nontemporal_store(pv[u], reinterpret_cast<f32x4*>(p + i));
+            __builtin_nontemporal_store(mv[u], reinterpret_cast<f32x4*>(m + i));
+            __builtin_nontemporal_store(vv[u], reinterpret_cast<f32x4*>(v + i));
+            if (has_ema) __builtin_nontemporal_store(ev[u], reinterpret_cast<f32x4*>(ema + i));
+            if (shadow) store4(shadow + i, pv[u]);          // default policy: the next forward reads the shadow weights first
+            if (a.zero_grad) store4(g + i, f32x4{0, 0, 0, 0});
+        }
+    }
+    // the last, partial tile (and n % 4 elements), one element group per thread
+    for (int64_t i = n_tiles * TILE + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         f32x4 pv = load4(p + 4 * i), gv = load4(g + 4 * i), mv = load4(m + 4 * i), vv = load4(v + 4 * i);
         f32x4 ev = has_ema ? load4(ema + 4 * i) : f32x4{0, 0, 0, 0};
 #pragma unroll
@@ -564,6 +601,11 @@ __global__ void adamw_ema_kernel(float* __restrict__ p, float* __restrict__ g, f
         if (a.zero_grad) g[i] = 0.f;
     }
 }
+static inline int adam_grid(int64_t n) {
+    const int64_t tiles = n / 4 / (ADAM_U * 256);
+    const int64_t cap = 256 * 8;
+    return (int)(tiles < 1 ? 1 : (tiles > cap ? cap : tiles));
+}
 
 extern "C" int vaw_adamw_ema_step(float* p, float* g, float* m, float* v, float* ema, void* shadow_bf16, int64_t n,
                                   float lr, float beta1, float beta2, float eps, float weight_decay, float bc1,
@@ -574,7 +616,7 @@ extern "C" int vaw_adamw_ema_step(float* p, float* g, float* m, float* v, float*
                       ((uintptr_t)shadow_bf16 & 7) == 0, "adamw: buffers must be 16-byte aligned");
     VAW_CHECK_ARG(clip_max_norm <= 0.f || sumsq != nullptr, "adamw: clip needs sumsq");
     AdamArgs a{lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), ema_decay, clip_max_norm, zero_grad};
-    adamw_ema_kernel<<<stream_grid(n / 4 + 1, 256), 256, 0, (hipStream_t)stream>>>(p, g, m, v, ema, (bf16_t*)shadow_bf16, n, sumsq, a, nullptr);
+    adamw_ema_kernel<<<adam_grid(n), 256, 0, (hipStream_t)stream>>>(p, g, m, v, ema, (bf16_t*)shadow_bf16, n, sumsq, a, nullptr);
     VAW_CHECK_LAUNCH("adamw_ema");
     return VAW_OK;
 }
@@ -588,7 +630,7 @@ extern "C" int vaw_adamw_ema_step_dev(float* p, float* g, float* m, float* v, fl
                       ((uintptr_t)shadow_bf16 & 7) == 0, "adamw_dev: buffers must be 16-byte aligned");
     VAW_CHECK_ARG(clip_max_norm <= 0.f || sumsq != nullptr, "adamw_dev: clip needs sumsq");
     AdamArgs a{0.f, beta1, beta2, eps, weight_decay, 1.f, 1.f, ema_decay, clip_max_norm, zero_grad};
-    adamw_ema_kernel<<<stream_grid(n / 4 + 1, 256), 256, 0, (hipStream_t)stream>>>(p, g, m, v, ema, (bf16_t*)shadow_bf16, n, sumsq, a, hyper);
+    adamw_ema_kernel<<<adam_grid(n), 256, 0, (hipStream_t)stream>>>(p, g, m, v, ema, (bf16_t*)shadow_bf16, n, sumsq, a, hyper);
     VAW_CHECK_LAUNCH("adamw_ema_dev");
     return VAW_OK;
 }
