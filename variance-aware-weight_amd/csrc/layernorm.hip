@@ -3,6 +3,9 @@
 // in registers between the statistics passes (one read of x, one write of the output), reductions are
 // wavefront shuffles, and per-sample sums over tokens are combined through LDS in a fixed wave order
 // (bitwise reproducible; no float atomics).
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "common.h"
 
 // NV = number of 256-column slabs a lane walks (D <= 256*NV), D % 4 == 0.
@@ -226,6 +229,154 @@ row_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ x, const fl
     }
 }
 
+// ---- the fused LayerNorm-backward + gate-backward pass for bf16 rows up to 768 wide (DiT-S / DiT-B), rebuilt around memory-level
+// parallelism (round 4).  row_bwd_kernel<FUSE> above keeps four accumulator sets in registers: at 1024 threads that leaves a wave
+// no room to have more than one slab of one row in flight, and the compiler ends every `if (c < D)` block that holds loads with a
+// wait for them -- 3.8-4.2 TB/s of its 18 B per element, 89 % of the wave time parked on memory (PMC, round 3).  Here:
+//   * 8 waves per workgroup and up to 256 registers each; the four per-sample column sums live in a per-wave LDS slab [4][D]
+//     (same additions in the same order as the register version, folded over the waves in wave order at the end);
+//   * all four operand rows of a token row (144 bytes per lane) are requested at once, non-temporally, with wave-uniform row
+//     bases and one unsigned per-lane column offset (lanes beyond D re-read column 0 and are masked out: no branch around a load);
+//   * the NEXT row of the wave is requested before the current one is worked on (two register sets, loop unrolled by two), so a
+//     wave always has 144-288 bytes per lane in flight and the two reductions of a row no longer expose a memory latency.
+// Arithmetic and its order are those of vaw_ln_modulate_bwd followed by vaw_gate_bwd at 8 waves per workgroup (bitwise: tests).
+template <int NV, bool QOUT>
+__global__ void __launch_bounds__(512)
+row_bwd_fuse8_kernel(const bf16_t* __restrict__ dout, const float* __restrict__ x, const float* __restrict__ mean,
+                     const float* __restrict__ rstd, const float* __restrict__ scale, int64_t mod_ld,
+                     const float* __restrict__ dres_in, float* __restrict__ dx, float* __restrict__ dshift,
+                     float* __restrict__ dscale, int64_t dmod_ld, int Tt, int D, const bf16_t* __restrict__ y,
+                     const float* __restrict__ gate, bf16_t* __restrict__ dy, float* __restrict__ dgate, float* __restrict__ dy_colpart,
+                     int rows_per_chunk, float* __restrict__ part, unsigned char* __restrict__ q_out, float* __restrict__ q_state,
+                     int q_e5m2) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // (1 + scale) row | gate row | [waves][4][D] sums
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+    const int b = blockIdx.x;
+    const int t_begin = blockIdx.y * rows_per_chunk;
+    const int t_end = t_begin + rows_per_chunk < Tt ? t_begin + rows_per_chunk : Tt;
+    float* const sc_lds = lds;
+    float* const gsc_lds = lds + D;
+    float* const slab = lds + 2 * D + wid * 4 * D;
+    const float q_inv = QOUT ? 1.f / q_state[0] : 1.f;
+    float q_am = 0.f;
+    bool act[NV];
+    unsigned col[NV], colc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        col[i] = (unsigned)(i * 64 + lane) * 4u;
+        act[i] = col[i] < (unsigned)D;
+        colc[i] = act[i] ? col[i] : 0u;
+        if (act[i]) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) store4(slab + q * D + col[i], f32x4{0, 0, 0, 0});
+            if (wid == 0) {
+                store4(sc_lds + col[i], 1.f + load4(scale + (int64_t)b * mod_ld + col[i]));
+                store4(gsc_lds + col[i], load4(gate + (int64_t)b * mod_ld + col[i]));
+            }
+        }
+    }
+    __syncthreads();
+    struct RowRegs {
+        bf16x4 dq[NV], yq[NV];
+        f32x4 xv[NV], rv[NV];
+        float mu, rs;
+    };
+    auto issue = [&](RowRegs& R, int t) __attribute__((always_inline)) {
+        const int64_t row = (int64_t)b * Tt + t;
+        const bf16_t* const dout_r = dout + row * D;
+        const float* const x_r = x + row * D;
+        const float* const res_r = dres_in ? dres_in + row * D : x_r;
+        const bf16_t* const y_r = y + row * D;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            R.dq[i] = __builtin_nontemporal_load(reinterpret_cast<const bf16x4*>(dout_r + colc[i]));
+            R.xv[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x_r + colc[i]));
+            R.rv[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(res_r + colc[i]));
+            R.yq[i] = __builtin_nontemporal_load(reinterpret_cast<const bf16x4*>(y_r + colc[i]));
+        }
+        R.mu = mean[row];
+        R.rs = rstd[row];
+    };
+    auto process = [&](RowRegs& R, int t) __attribute__((always_inline)) {
+        const int64_t row = (int64_t)b * Tt + t;
+        const float mu = R.mu, rs = R.rs;
+        const f32x4 z = {0, 0, 0, 0};
+        f32x4 xh[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const f32x4 d = act[i] ? f32x4{(float)R.dq[i][0], (float)R.dq[i][1], (float)R.dq[i][2], (float)R.dq[i][3]} : z;
+            xh[i] = act[i] ? (R.xv[i] - mu) * rs : z;
+            const f32x4 g = d * load4(sc_lds + colc[i]);
+            s1 += g[0] + g[1] + g[2] + g[3];
+            const f32x4 gx = g * xh[i];
+            s2 += gx[0] + gx[1] + gx[2] + gx[3];
+            if (act[i]) {
+                float* p0 = slab + col[i];
+                store4(p0, load4(p0) + d);                    // dshift
+                store4(p0 + D, load4(p0 + D) + d * xh[i]);    // dscale
+            }
+        }
+        const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if (!act[i]) continue;
+            const f32x4 d0 = {(float)R.dq[i][0], (float)R.dq[i][1], (float)R.dq[i][2], (float)R.dq[i][3]};
+            const f32x4 g = d0 * load4(sc_lds + col[i]);
+            f32x4 r = (g - c1 - xh[i] * c2) * rs;
+            if (dres_in) r += R.rv[i];
+            __builtin_nontemporal_store(r, reinterpret_cast<f32x4*>(dx + row * D + col[i]));
+            const f32x4 yv = {(float)R.yq[i][0], (float)R.yq[i][1], (float)R.yq[i][2], (float)R.yq[i][3]};
+            const f32x4 d = r * load4(gsc_lds + col[i]);
+            if (QOUT) *reinterpret_cast<unsigned*>(q_out + row * D + col[i]) = fp8_word_of_bf16(d, q_inv, q_e5m2, q_am);
+            else store4(dy + row * D + col[i], d);
+            const f32x4 dr = {(float)(bf16_t)d[0], (float)(bf16_t)d[1], (float)(bf16_t)d[2], (float)(bf16_t)d[3]};
+            float* p2 = slab + 2 * D + col[i];
+            store4(p2, load4(p2) + r * yv);                   // dgate
+            store4(p2 + D, load4(p2 + D) + dr);               // column sums of dy as stored
+        }
+    };
+    {
+        RowRegs A, Bq;
+        int t = t_begin + wid;
+        if (t < t_end) issue(A, t);
+        while (t < t_end) {
+            const int t1 = t + nw;
+            if (t1 < t_end) issue(Bq, t1);
+            process(A, t);
+            if (t1 >= t_end) break;
+            const int t2 = t1 + nw;
+            if (t2 < t_end) issue(A, t2);
+            process(Bq, t1);
+            t = t2;
+        }
+    }
+    if (QOUT) fp8_amax_commit(q_am, q_state + 1, lane);
+    __syncthreads();
+    // fold the waves' slabs in wave order (the order of row_bwd_kernel's turn-taking combine)
+    for (int idx = threadIdx.x; idx < 4 * D; idx += blockDim.x) {
+        const int q = idx / D, c = idx - q * D;
+        float s = 0.f;
+        for (int w = 0; w < nw; ++w) s += lds[2 * D + (w * 4 + q) * D + c];
+        if (part) part[((int64_t)blockIdx.y * gridDim.x + b) * 4 * D + idx] = s;
+        else if (q == 0) dshift[(int64_t)b * dmod_ld + c] = s;
+        else if (q == 1) dscale[(int64_t)b * dmod_ld + c] = s;
+        else if (q == 2) dgate[(int64_t)b * dmod_ld + c] = s;
+        else if (dy_colpart) dy_colpart[(int64_t)b * D + c] = s;
+    }
+}
+template <int NV, bool QOUT>
+static size_t row_fuse8_lds(int D, int block) {
+    const size_t lds = (2 + 4 * (size_t)(block / 64)) * (size_t)D * sizeof(float);
+    static bool done = false;
+    if (!done && lds > 64 * 1024) {
+        const hipError_t rc = hipFuncSetAttribute((const void*)row_bwd_fuse8_kernel<NV, QOUT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (rc != hipSuccess) fprintf(stderr, "row_fuse8_lds: hipFuncSetAttribute -> %s\n", hipGetErrorString(rc));
+        done = true;
+    }
+    return lds;
+}
+
 // out0[b][c] (row stride ld0) = sum_chunk part[chunk][b][0][c], out1 likewise from [1] (row stride ld1; may be NULL); the fused
 // kernel's part rows carry four quantities: out2 / out3 from [2] / [3]
 __global__ void row_bwd_finish_kernel(const float* __restrict__ part, int NC, int B, int D, float* __restrict__ out0, int64_t ld0,
@@ -262,6 +413,9 @@ static int pick_chunks(int B, int Tt, bool have_ws, int target_wgs = 256) {
 }
 extern "C" int64_t vaw_row_bwd_workspace_floats(int B, int T, int D) { return (int64_t)pick_chunks(B, T, true, 512) * B * 4 * D; }
 
+// (rows up to 768 wide: 8 waves everywhere, so that the fused pass -- row_bwd_fuse8_kernel -- and the pair of kernels it replaces cut a
+// sample's rows into the same per-wave partial sums and stay bitwise equal)
+static int row_waves(int nv, int wide_default) { return nv <= 3 ? 8 : wide_default; }
 static int pick_block(int Tt, int max_waves = 16) {
     int nw = Tt < max_waves ? Tt : max_waves;
     if (nw < 1) nw = 1;
@@ -324,7 +478,7 @@ extern "C" int vaw_ln_modulate_bwd(vaw_dtype dt, const void* dout, const float* 
     if (nc > 1 && workspace_floats < (int64_t)nc * B * 2 * D) nc = 1;
     const int rpc = (T + nc - 1) / nc;
     float* part = nc > 1 ? workspace : nullptr;
-    const int block = pick_block(rpc);
+    const int block = pick_block(rpc, row_waves(pick_nv(D), 16));
     const size_t lds = 2 * (size_t)D * sizeof(float);
     dim3 grid(B, nc);
     if (dt == VAW_F32) {
@@ -356,11 +510,17 @@ extern "C" int vaw_ln_modulate_bwd_gate(vaw_dtype dt, const void* dout, const fl
     if (nc > 1 && workspace_floats < (int64_t)nc * B * 4 * D) nc = 1;
     const int rpc = (T + nc - 1) / nc;
     float* part = nc > 1 ? workspace : nullptr;
-    const int block = pick_block(rpc, nv > 3 ? 8 : 16);
+    const int block = pick_block(rpc, 8);
     const size_t lds = 6 * (size_t)D * sizeof(float);
     dim3 grid(B, nc);
     if (dt == VAW_F32) {
         DISPATCH_NV(nv, (row_bwd_kernel<float, NV, false, false, true><<<grid, block, lds, s>>>((const float*)dout, x, mean, rstd, scale, mod_ld, dres_in, dx, dshift, dscale, dmod_ld, T, D, nullptr, (const float*)y_next, gate_next, (float*)dy_next, dgate_next, dy_colsum_partial, rpc, part)));
+    } else if (nv <= 3) {
+#define LAUNCH_FUSE8(NVv)                                                                                                              \
+    row_bwd_fuse8_kernel<NVv, false><<<grid, block, row_fuse8_lds<NVv, false>(D, block), s>>>(                                          \
+        (const bf16_t*)dout, x, mean, rstd, scale, mod_ld, dres_in, dx, dshift, dscale, dmod_ld, T, D, (const bf16_t*)y_next, gate_next, \
+        (bf16_t*)dy_next, dgate_next, dy_colsum_partial, rpc, part, nullptr, nullptr, 0)
+        if (nv == 1) LAUNCH_FUSE8(1); else if (nv == 2) LAUNCH_FUSE8(2); else LAUNCH_FUSE8(3);
     } else {
         DISPATCH_NV(nv, (row_bwd_kernel<bf16_t, NV, false, false, true><<<grid, block, lds, s>>>((const bf16_t*)dout, x, mean, rstd, scale, mod_ld, dres_in, dx, dshift, dscale, dmod_ld, T, D, nullptr, (const bf16_t*)y_next, gate_next, (bf16_t*)dy_next, dgate_next, dy_colsum_partial, rpc, part)));
     }
@@ -389,10 +549,18 @@ extern "C" int vaw_ln_modulate_bwd_gate_fp8(const void* dout, const float* x, co
     if (nc > 1 && workspace_floats < (int64_t)nc * B * 4 * D) nc = 1;
     const int rpc = (T + nc - 1) / nc;
     float* part = nc > 1 ? workspace : nullptr;
-    const int block = pick_block(rpc, nv > 3 ? 8 : 16);
+    const int block = pick_block(rpc, 8);
     const size_t lds = 6 * (size_t)D * sizeof(float);
     dim3 grid(B, nc);
-    DISPATCH_NV(nv, (row_bwd_kernel<bf16_t, NV, false, true, true><<<grid, block, lds, s>>>((const bf16_t*)dout, x, mean, rstd, scale, mod_ld, dres_in, dx, dshift, dscale, dmod_ld, T, D, nullptr, (const bf16_t*)y_next, gate_next, nullptr, dgate_next, dy_colsum_partial, rpc, part, (unsigned char*)dy_q, q_state, q_format == VAW_BF8)));
+    if (nv <= 3) {
+#define LAUNCH_FUSE8Q(NVv)                                                                                                             \
+    row_bwd_fuse8_kernel<NVv, true><<<grid, block, row_fuse8_lds<NVv, true>(D, block), s>>>(                                            \
+        (const bf16_t*)dout, x, mean, rstd, scale, mod_ld, dres_in, dx, dshift, dscale, dmod_ld, T, D, (const bf16_t*)y_next, gate_next, \
+        nullptr, dgate_next, dy_colsum_partial, rpc, part, (unsigned char*)dy_q, q_state, q_format == VAW_BF8)
+        if (nv == 1) LAUNCH_FUSE8Q(1); else if (nv == 2) LAUNCH_FUSE8Q(2); else LAUNCH_FUSE8Q(3);
+    } else {
+        DISPATCH_NV(nv, (row_bwd_kernel<bf16_t, NV, false, true, true><<<grid, block, lds, s>>>((const bf16_t*)dout, x, mean, rstd, scale, mod_ld, dres_in, dx, dshift, dscale, dmod_ld, T, D, nullptr, (const bf16_t*)y_next, gate_next, nullptr, dgate_next, dy_colsum_partial, rpc, part, (unsigned char*)dy_q, q_state, q_format == VAW_BF8)));
+    }
     if (nc > 1)
         row_bwd_finish_kernel<<<ceil_div((int64_t)B * D, 256), 256, 0, s>>>(part, nc, B, D, dshift, dmod_ld, dscale, dmod_ld, 4, dgate_next, dmod_ld,
                                                                              dy_colsum_partial, D);
@@ -410,7 +578,7 @@ extern "C" int vaw_gate_bwd(vaw_dtype dt, const float* dres, const void* y, cons
     if (nc > 1 && workspace_floats < (int64_t)nc * B * 2 * D) nc = 1;
     const int rpc = (T + nc - 1) / nc;
     float* part = nc > 1 ? workspace : nullptr;
-    const int block = pick_block(rpc);
+    const int block = pick_block(rpc, row_waves(pick_nv(D), 16));
     const size_t lds = 2 * (size_t)D * sizeof(float);
     dim3 grid(B, nc);
     if (dt == VAW_F32) {
@@ -435,7 +603,7 @@ extern "C" int vaw_gate_bwd_fp8(const float* dres, const void* y, const float* g
     if (nc > 1 && workspace_floats < (int64_t)nc * B * 2 * D) nc = 1;
     const int rpc = (T + nc - 1) / nc;
     float* part = nc > 1 ? workspace : nullptr;
-    const int block = pick_block(rpc);
+    const int block = pick_block(rpc, row_waves(pick_nv(D), 16));
     const size_t lds = 2 * (size_t)D * sizeof(float);
     dim3 grid(B, nc);
     DISPATCH_NV(pick_nv(D), (row_bwd_kernel<bf16_t, NV, true, true><<<grid, block, lds, s>>>(nullptr, nullptr, nullptr, nullptr, nullptr, mod_ld, nullptr, nullptr, nullptr, nullptr, dmod_ld, T, D, dres, (const bf16_t*)y, gate, nullptr, dgate, dy_colsum_partial, rpc, part, (unsigned char*)dy_q, q_state, q_format == VAW_BF8)));
