@@ -21,16 +21,36 @@ ln_modulate_fwd_kernel(const float* __restrict__ x, const float* __restrict__ sh
     // with one atomic at its end: 32768 waves polling one address cost more than the whole pass -- 104 vs 46 us on DiT-XL/2)
     const float q_inv = q_out ? 1.f / q_state[0] : 1.f;
     float am = 0.f;
-    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += (int64_t)gridDim.x * 4) {
+    // every launch caps its grid (8 workgroups per CU): a wave walks several rows and requests the NEXT row before it works on the
+    // current one -- a row is one 16-byte load per lane and slab, then two wave reductions: with one row per wave (round 3) the
+    // only thing in flight during the reductions was other waves' rows, and 4096 three-microsecond workgroups queued behind the
+    // dispatcher (3.9-4.2 TB/s of the 6 B/elem).  Row bases are wave-uniform, lanes beyond D re-read column 0 (masked below).
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t row0 = (int64_t)blockIdx.x * 4 + wave, rstep = (int64_t)gridDim.x * 4;
+    unsigned colc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const unsigned c = (unsigned)(i * 64 + lane) * 4u;
+        colc[i] = c < (unsigned)D ? c : 0u;
+    }
+    f32x4 nx[NV];
+    if (row0 < M) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) nx[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x + row0 * D + colc[i]));
+    }
+    for (int64_t row = row0; row < M; row += rstep) {
         const int b = (int)(row / Tt);
-        const float* xr = x + row * D;
         f32x4 v[NV];
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = (i * 64 + lane) * 4;
-            v[i] = c < D ? load4(xr + c) : f32x4{0, 0, 0, 0};
+            v[i] = c < D ? nx[i] : f32x4{0, 0, 0, 0};
             s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        }
+        if (row + rstep < M) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) nx[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x + (row + rstep) * D + colc[i]));
         }
         const float mean = wave_sum(s) / (float)D;
         float q = 0.f;
@@ -439,7 +459,7 @@ extern "C" int vaw_ln_modulate_fwd(vaw_dtype dt, const float* x, const float* sh
     VAW_CHECK_ARG(B > 0 && T > 0 && D > 0 && D % 4 == 0 && D <= 2048 && mod_ld % 4 == 0,
                   "ln_modulate_fwd: need D%%4==0, D<=2048, mod_ld%%4==0 (D=%d)", D);
     const int64_t M = (int64_t)B * T;
-    const int grid = ceil_div(M, 4);
+    const int grid = ceil_div(M, 4) < 2048 ? ceil_div(M, 4) : 2048;       // 8 workgroups per CU, every wave several rows: see the kernel
     hipStream_t s = (hipStream_t)stream;
     if (dt == VAW_F32) {
         DISPATCH_NV(pick_nv(D), (ln_modulate_fwd_kernel<float, NV><<<grid, 256, 0, s>>>(x, shift, scale, mod_ld, (float*)out, mean, rstd, M, T, D, eps)));
