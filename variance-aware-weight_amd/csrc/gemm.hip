@@ -618,7 +618,18 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int S, int6
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t m = (4 * i) / N, n = (4 * i) % N;
         f32x4 acc = {0, 0, 0, 0};
-        for (int sidx = 0; sidx < S; ++sidx) acc += load4(slab + (int64_t)sidx * M * N + 4 * i);
+        // eight slabs requested at once, added in slab order (the sum is the sequential one; only the loads overlap: the small
+        // outputs of the long-K launches -- adaLN input gradient, patch-embed / final-layer weight gradients -- give this kernel a
+        // few hundred threads each walking 64 slabs, 38 us per call in round 3 with one load in flight)
+        int sidx = 0;
+        for (; sidx + 8 <= S; sidx += 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = load4(slab + (int64_t)(sidx + u) * M * N + 4 * i);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; sidx < S; ++sidx) acc += load4(slab + (int64_t)sidx * M * N + 4 * i);
         acc *= alpha;
         const int64_t off = m * ldc + n;
         if (out_f32) {

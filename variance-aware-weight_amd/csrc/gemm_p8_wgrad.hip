@@ -4,6 +4,7 @@
 void p8_launch_wgrad(const P8Launch& L, const EpiDev& e, hipStream_t s) {
     switch (L.epi) {
         P8_CASE(false, false, P8_SLAB);
+        P8_CASE(false, false, P8_STORE);      // un-split plain results: the packed adaLN weight gradient (K = batch; round 3 ran it on P8_ANY: 116 us)
         default:
             if (L.ntw == 4) p8_launch_one<false, false, 4, P8_ANY>(L.a, L.lda, L.b, L.ldb, L.nk, L.tiles_m, L.tiles_n, L.split, L.grid, e, s, L.team_delay);
             else p8_launch_one<false, false, 3, P8_ANY>(L.a, L.lda, L.b, L.ldb, L.nk, L.tiles_m, L.tiles_n, L.split, L.grid, e, s, L.team_delay);
