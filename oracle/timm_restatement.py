@@ -11,8 +11,12 @@ dropout, norm_layer=None):
               -> softmax(q*hd^-0.5 @ k^T) @ v -> [B,N,D] -> Linear(D,D)
   Mlp       : fc1 -> act -> fc2
   PatchEmbed: Conv2d(C,D,k=p,s=p,bias) -> flatten(2).transpose(1,2)
-It is cross-checked against the in-tree statements of the same math in
-/root/reference/models/uvit.py:55-93 (tests/test_oracle_goldens.py).
+Attention and Mlp are pinned against the reference's OWN statements of the same
+math -- models/uvit.py:55-93 ('math' and 'flash' modes) and tools/timm.py:96-112,
+run unmodified by tests/golden/make_goldens.py::gen_uvit_anchor -- in
+tests/test_oracle_goldens.py::test_timm_restatement_vs_reference_uvit_attention_and_mlp
+(outputs and input gradients, same state_dict keys).  What stays unpinned is
+only "timm 0.9.2 == the reference's uvit statement" (and PatchEmbed's Conv2d).
 Parameter names (`qkv`, `proj`, `fc1`, `fc2`, `proj`) follow timm so reference
 checkpoints keep their state_dict keys.
 """

@@ -596,13 +596,45 @@ def gen_misc():
     json.dump(rec, open(os.path.join(HERE, "misc.json"), "w"))
 
 
+def gen_uvit_anchor():
+    """The reference's OWN statement of ViT attention and MLP (models/uvit.py:55-93 `Attention` in its 'math' and 'flash' modes,
+    tools/timm.py:96-112 `Mlp`): seeded weights, input, output and input gradient.  tests/test_oracle_goldens.py loads the same
+    weights into oracle/timm_restatement.{Attention, Mlp} -- the stand-in for the absent timm==0.9.2 classes of models/dit.py:17 --
+    and must reproduce these numbers: a reference-held pin of the (K H D) qkv packing and the hd^-1/2 scale."""
+    import models.uvit as uvit
+    from tools.timm import Mlp as RefMlp
+    out = {}
+    for heads, dim, L, B in ((4, 64, 16, 2), (6, 96, 9, 3)):
+        torch.manual_seed(100 + heads)
+        att = uvit.Attention(dim, num_heads=heads, qkv_bias=True)
+        perturb_(att, 7 + heads)
+        mlp = RefMlp(dim, 4 * dim, act_layer=lambda: torch.nn.GELU(approximate="tanh"))
+        perturb_(mlp, 17 + heads)
+        x = torch.randn(B, L, dim, generator=torch.Generator().manual_seed(3 + heads))
+        gy = torch.randn(B, L, dim, generator=torch.Generator().manual_seed(5 + heads))
+        rec = {"x": x, "gy": gy, "attn_state": {k: v.clone() for k, v in att.state_dict().items()},
+               "mlp_state": {k: v.clone() for k, v in mlp.state_dict().items()}}
+        for mode in ("math", "flash"):
+            uvit.ATTENTION_MODE = mode
+            xi = x.clone().requires_grad_(True)
+            y = att(xi)
+            (gx,) = torch.autograd.grad(y, xi, gy)
+            rec[f"attn_{mode}_y"], rec[f"attn_{mode}_gx"] = y.detach(), gx
+        xi = x.clone().requires_grad_(True)
+        y = mlp(xi)
+        (gx,) = torch.autograd.grad(y, xi, gy)
+        rec["mlp_y"], rec["mlp_gx"] = y.detach(), gx
+        out[f"h{heads}_d{dim}"] = rec
+    torch.save(out, os.path.join(HERE, "uvit_anchor.pt"))
+
+
 def main():
     install_stubs()
     torch.set_num_threads(8)
     from tools import gaussian_diffusion as gd
     jobs = {"tables": lambda: gen_tables(gd), "weights": lambda: gen_loss_weights(gd),
             "objective": lambda: gen_objective(gd), "dit": gen_dit_tiny, "unet": gen_unet_tiny, "unet_dropout": gen_unet_dropout, "misc": gen_misc,
-            "trainer": gen_trainer, "bigcfg": gen_bigcfg, "vb": lambda: gen_vb(gd), "trainer_vb": gen_trainer_vb, "sampling": lambda: gen_sampling(gd), "samplers": lambda: gen_samplers(gd)}
+            "trainer": gen_trainer, "bigcfg": gen_bigcfg, "vb": lambda: gen_vb(gd), "trainer_vb": gen_trainer_vb, "sampling": lambda: gen_sampling(gd), "samplers": lambda: gen_samplers(gd), "uvit_anchor": gen_uvit_anchor}
     for name in (sys.argv[1:] or list(jobs)):
         jobs[name]()
         print("wrote", name)

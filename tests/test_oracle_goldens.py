@@ -345,3 +345,26 @@ def test_misc_lr_resampler_latent():
     lat = torch.tensor(rec["sfl_in"], dtype=torch.float32)
     torch.manual_seed(1)
     assert otr.sample_from_latent(lat, 0.18215).double().tolist() == rec["sfl_out"]
+
+
+@pytest.mark.parametrize("key", ["h4_d64", "h6_d96"])
+def test_timm_restatement_vs_reference_uvit_attention_and_mlp(key):
+    """The stand-in for timm==0.9.2's Attention / Mlp (oracle/timm_restatement.py; timm is not importable here) against the
+    reference's OWN statements of the same arithmetic: models/uvit.py:55-93 `Attention` ('math' and 'flash' modes) and
+    tools/timm.py:96-112 `Mlp`, run unmodified by tests/golden/make_goldens.py::gen_uvit_anchor.  Same state_dict keys, same
+    weights -> same output and input gradient: a reference-held pin of the (K H D) qkv packing, the hd^-1/2 scale and the
+    head merge.  What stays unpinned is only "timm 0.9.2 == the reference's uvit statement"."""
+    from oracle import timm_restatement as tr
+    g = load_pt("uvit_anchor.pt")[key]
+    heads, dim = int(key[1]), int(key.split("_d")[1])
+    att = tr.Attention(dim, num_heads=heads, qkv_bias=True)
+    att.load_state_dict(g["attn_state"], strict=True)
+    mlp = tr.Mlp(dim, 4 * dim, act_layer=lambda: torch.nn.GELU(approximate="tanh"))
+    mlp.load_state_dict(g["mlp_state"], strict=True)
+    for mod, names in ((att, ("attn_math", "attn_flash")), (mlp, ("mlp",))):
+        x = g["x"].clone().requires_grad_(True)
+        y = mod(x)
+        (gx,) = torch.autograd.grad(y, x, g["gy"])
+        for n in names:
+            torch.testing.assert_close(y.detach(), g[n + "_y"], rtol=2e-6, atol=2e-6)
+            torch.testing.assert_close(gx, g[n + "_gx"], rtol=2e-6, atol=2e-6)
