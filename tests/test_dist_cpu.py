@@ -226,6 +226,37 @@ def _zero_worker(rank, world, port, q):
         opt = vaw_amd.FusedAdamW(m, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.01)
         opt.load_state_dict(ref_sd)
         assert opt.step_count == 3 and opt.exp_avg.numel() * world == m._flat_n_train
+        # misuse guards: an optimizer built BEFORE the wrap (zero captured as None) must not run its full update on the
+        # reduce-scattered gradients, and a Trainer must not accept a non-sharded optimizer on such a model
+        m = build()
+        early = vaw_amd.FusedAdamW(m, lr=1e-2)
+        ddp = vaw_amd.DistributedDataParallel(m, shard_optimizer=True)
+        fake_backward(m, 0)
+        try:
+            early.step()
+            raise AssertionError("FusedAdamW built before the shard_optimizer wrap stepped")
+        except RuntimeError as e:
+            assert "BEFORE" in str(e), str(e)
+        from conftest import base_args
+        diff = vaw_amd.GaussianDiffusion(args=base_args(), betas=vaw_amd.get_named_beta_schedule("cosine", 1000),
+                                         model_mean_type=vaw_amd.ModelMeanType.EPSILON, model_var_type=vaw_amd.ModelVarType.FIXED_LARGE,
+                                         loss_type=vaw_amd.LossType.MSE, rescale_timesteps=True)
+        for bad in (early, torch.optim.AdamW(m.parameters(), lr=1e-2)):
+            try:
+                vaw_amd.Trainer(base_args(parallel=True, amp=False), torch.device("cpu"), ddp, None, bad, None, diff, [(torch.zeros(1), torch.zeros(1))])
+                raise AssertionError("Trainer accepted a non-sharded optimizer on a shard_optimizer model")
+            except ValueError as e:
+                assert "shard_optimizer" in str(e), str(e)
+        # the stale-master flag lives on the module: state_dict() refuses until the collective consolidate() has run
+        late = vaw_amd.FusedAdamW(m, lr=1e-2)
+        late.master_stale = m._master_stale = True
+        try:
+            m.state_dict()
+            raise AssertionError("state_dict() on stale masters did not raise")
+        except RuntimeError as e:
+            assert "consolidate" in str(e)
+        late.consolidate()
+        assert not m._master_stale and m.state_dict()
         vaw_amd.dist_util.dist_barrier()
         vaw_amd.dist_util.cleanup_dist()
         q.put((rank, "ok"))

@@ -178,7 +178,16 @@ def _zero_bf16_worker(rank, world, port, q, shard):
             opt.zero_grad()
             mses.append(terms["mse"].detach().cpu().numpy())
         if shard:
+            # the f32 masters of the other rank's chunks are stale now: everything that reads or re-derives from them refuses
+            # (a silent stale mix was the alternative) until the collective consolidate() has run on every rank
+            for what, fn in (("state_dict", lambda: model.state_dict()), ("set_compute_dtype", lambda: model.set_compute_dtype("fp32"))):
+                try:
+                    fn()
+                    raise AssertionError(f"{what} on stale masters did not raise")
+                except RuntimeError as e:
+                    assert "consolidate" in str(e), (what, str(e))
             opt.consolidate()
+            model.state_dict()
         torch.cuda.synchronize()
         q.put((rank, mses, model._flat.detach().cpu().numpy(), None))
         vaw_amd.dist_util.cleanup_dist()

@@ -510,3 +510,47 @@ def test_edm_heun_sampling_hip_dit_vs_oracle_dit():
         rl = lambda t: torch.randn(t.shape, dtype=t.dtype).to(t.device)          # CPU stream for both
         outs.append(vaw_amd.edm_sample(net, lat.to(dev), class_labels=y.to(dev), num_steps=7, solver="heun", S_churn=2.0, randn_like=rl).cpu())
     torch.testing.assert_close(outs[1], outs[0], rtol=1e-4, atol=1e-4)
+
+
+def test_bias_gradient_fold_follows_the_producers_row_counts():
+    """The bias gradients of the blocks are folded from partial column sums whose ROW COUNT depends on the kernel each producer
+    ran on (one row per 64 / 128 / 256 rows of C for the GEMMs, per 64 / 128 / 256 query rows for the attention backward), and
+    that choice can change between two backwards of ONE workspace (CUs reserved for a collective, vaw_debug_gemm_tile,
+    VAW_ATTN_BWD_BIG).  The device table of the batched fold bakes the counts in: it has to be rebuilt when they move.  Two
+    backwards of one model under two settings must each give the bias gradients of a fresh model run under that setting."""
+    import os
+    from vaw_amd._lib import lib
+
+    def make():
+        torch.manual_seed(5)
+        m = vaw_amd.DiT(image_size=32, patch_size=2, in_channels=4, hidden_size=256, depth=2, num_heads=4, num_classes=10,
+                        class_dropout_prob=0.0, learn_sigma=False, compute_dtype="bf16").to(DEV).train()
+        perturb_(m, 3, 0.05)
+        return m
+
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(16, 4, 32, 32, generator=g).to(DEV)           # 16 x 256 tokens = 4096 rows
+    t = (torch.rand(16, generator=g) * 999).to(DEV)
+    y = torch.randint(0, 10, (16,), generator=g).to(DEV)
+    gout = torch.randn(16, 4, 32, 32, generator=g).to(DEV)
+
+    def backward(m, tile, attn):
+        lib().vaw_debug_gemm_tile(tile)
+        os.environ["VAW_ATTN_BWD_BIG"] = attn
+        try:
+            m.zero_grad_flat()
+            out, _ = m(x, t, y)
+            (out * gout).sum().backward()
+            torch.cuda.synchronize()
+            return {k: p.grad.clone() for k, p in m.named_parameters() if k.endswith("bias") and p.grad is not None}
+        finally:
+            lib().vaw_debug_gemm_tile(-1)
+            os.environ.pop("VAW_ATTN_BWD_BIG", None)
+
+    settings = [(0, "0"), (6, "2"), (2, "1"), (0, "0")]            # 128-row tiles / 64-row ring / 256-row persistent; three attention families
+    shared = make()
+    for tile, attn in settings:
+        got = backward(shared, tile, attn)
+        ref = backward(make(), tile, attn)
+        for k in ref:
+            assert torch.equal(got[k], ref[k]), (tile, attn, k, float((got[k] - ref[k]).abs().max()))

@@ -392,6 +392,89 @@ def test_gemm_parked_drain_epilogues_vs_persistent_kernel(tile):
     torch.testing.assert_close(got["dx"].double().cpu(), got["dh"].double().cpu() @ w1.double().cpu(), rtol=2e-2, atol=5e-2)
 
 
+CANARY = 12345.5
+
+
+def _colsum_partial_with_guard(rows, N):
+    """A ColsumPartial whose buffer is the first `rows` rows of a larger tensor filled with a canary: writes past the capacity
+    the caller stated land in the guard rows and are seen."""
+    big = torch.full((rows + 64, N), CANARY, device=DEV)
+    part = ops.ColsumPartial(1, N, torch.device(DEV))
+    part.buf = big[:rows]
+    return part, big
+
+
+@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3, 5, 6, 7, 8, 10, 11])
+@pytest.mark.parametrize("M", [2048, 4096, 16384])
+def test_gemm_colsum_partial_each_path(tile, M):
+    """vaw_gemm with colsum_partial_out on every dispatch target (vaw_debug_gemm_tile: 128 x 128, the 256 x 256 ring, the persistent
+    kernel with 256 / 192 columns, the small-M ring kernels, the parked-drain kernel; -1 = by shape): the number of partial rows
+    differs per kernel (one per 64, 128 or 256 rows of C), so each path must (a) report the rows it wrote, (b) write nothing beyond
+    them -- guard rows behind the buffer keep their canary --, (c) fold to the column sums of C as stored, and (d) refuse, before
+    anything is launched, a buffer one row too small (VAW_ERR_INVALID; C untouched).  Pins the round-3 fault: a 64-row kernel
+    writing ceil(M/64) rows into a buffer sized for ceil(M/128)."""
+    N, K = 768, 768
+    A, B = _mk(M, N, K, True, False, torch.bfloat16, seed=M + 7)
+    Ad, Bd = A.to(DEV), B.to(DEV)
+    lib().vaw_debug_gemm_tile(tile)
+    try:
+        cap = (M + 63) // 64
+        part, big = _colsum_partial_with_guard(cap, N)
+        out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        ops.gemm(BF16, 1, 0, M, N, K, ptr(Ad), K, ptr(Bd), N, ptr(out), N, colsum_partial=part)
+        torch.cuda.synchronize()
+        R = part.rows.value
+        assert 1 <= R <= cap, (tile, M, R)
+        assert bool((big[R:] == CANARY).all()), (tile, M, R, "rows beyond the reported count were written")
+        assert not bool((big[:R] == CANARY).any())
+        torch.testing.assert_close(big[:R].double().sum(0).cpu(), out.double().sum(0).cpu(), rtol=1e-5, atol=2e-2)
+        ref = (A.double() @ B.double()).float().bfloat16()
+        torch.testing.assert_close(out.cpu().double(), ref.double(), rtol=2e-2, atol=2e-1)
+        # one row short: an error, nothing launched
+        part2, big2 = _colsum_partial_with_guard(R - 1, N) if R > 1 else (None, None)
+        if part2 is not None:
+            out2 = torch.full((M, N), 3.0, device=DEV, dtype=torch.bfloat16)
+            with pytest.raises(vaw_amd.VawError, match="colsum_partial_out holds"):
+                ops.gemm(BF16, 1, 0, M, N, K, ptr(Ad), K, ptr(Bd), N, ptr(out2), N, colsum_partial=part2)
+            torch.cuda.synchronize()
+            assert bool((big2 == CANARY).all()) and bool((out2 == 3.0).all())
+    finally:
+        lib().vaw_debug_gemm_tile(-1)
+
+
+@pytest.mark.parametrize("B,H,T,hd", [(4, 12, 64, 64), (2, 4, 256, 64), (2, 4, 256, 96)])
+@pytest.mark.parametrize("variant", ["0", "1", "2"])
+def test_attn_bwd_colsum_capacity(B, H, T, hd, variant):
+    """vaw_attn_bwd_colsum: rows written == *rows_out, guard rows untouched, and a buffer one row short is refused before the
+    launch (every backward family: VAW_ATTN_BWD_BIG = 0 / 1 / 2 write B*T/64, B*T/256 or B*T/128 rows; T = 64: one per sample)."""
+    os.environ["VAW_ATTN_BWD_BIG"] = variant
+    try:
+        D = H * hd
+        qkv = (_rand(B * T, 3 * D, seed=T) * 0.7).bfloat16().to(DEV)
+        do = _rand(B * T, D, seed=T + 1).bfloat16().to(DEV)
+        o = torch.empty(B * T, D, device=DEV, dtype=torch.bfloat16)
+        lse, delta = torch.empty(B * H * T, device=DEV), torch.empty(B * H * T, device=DEV)
+        desc = ops.attn_desc_token_major(B, H, T, hd)
+        ops.attn_fwd(BF16, desc, ptr(qkv), ptr(qkv) + 2 * D, ptr(qkv) + 4 * D, ptr(o), ptr(lse))
+        args = (BF16, desc, ptr(qkv), ptr(qkv) + 2 * D, ptr(qkv) + 4 * D, ptr(o), ptr(do), ptr(lse), ptr(delta))
+        dqkv = torch.zeros_like(qkv)
+        part, big = _colsum_partial_with_guard(max(B, B * T // 64), 3 * D)
+        assert ops.attn_bwd_colsum(*args, ptr(dqkv), ptr(dqkv) + 2 * D, ptr(dqkv) + 4 * D, part)
+        torch.cuda.synchronize()
+        R = part.rows.value
+        assert bool((big[R:] == CANARY).all()) and not bool((big[:R] == CANARY).any())
+        torch.testing.assert_close(big[:R].double().sum(0).cpu(), dqkv.double().sum(0).cpu(), rtol=1e-5, atol=2e-2)
+        if R > 1:
+            part2, big2 = _colsum_partial_with_guard(R - 1, 3 * D)
+            dq2 = torch.full_like(qkv, 3.0)
+            with pytest.raises(vaw_amd.VawError):
+                ops.attn_bwd_colsum(*args, ptr(dq2), ptr(dq2) + 2 * D, ptr(dq2) + 4 * D, part2)
+            torch.cuda.synchronize()
+            assert bool((big2 == CANARY).all()) and bool((dq2 == 3.0).all())
+    finally:
+        os.environ.pop("VAW_ATTN_BWD_BIG", None)
+
+
 @pytest.mark.parametrize("case", ["few_tiles_split", "full_rounds_plus_split", "n192", "edges_accumulate"])
 def test_wgrad_grouped_exact_integers(case):
     """vaw_wgrad_grouped: many dW_p (+)= dy_p^T x_p in one launch; whole tiles + K-split tiles of the last round + fixup.

@@ -32,3 +32,25 @@ extern "C" int vaw_debug_cu_hog(int n_wgs, int microseconds, vaw_stream stream) 
     VAW_CHECK_LAUNCH("cu_hog");
     return VAW_OK;
 }
+
+// One-time uploads of descriptor tables (vaw_wgrad_grouped, vaw_reduce_rows_batched, vaw_fp8_quantize_delayed_batched): the callers
+// build the table in a reused pageable array, and an asynchronous copy from pageable memory is only guaranteed to have been STAGED
+// when the call returns for small sizes -- a later call that rewrites the array could corrupt a table that is uploaded exactly once.
+// The table is therefore copied into a pinned buffer of its own that is never reused (a few KiB per group, groups are built once per
+// workspace) and the asynchronous copy reads from there: no host synchronisation, legal inside a stream capture.
+#include <mutex>
+#include <string.h>
+#include <vector>
+hipError_t vaw_upload_table(void* dev, const void* host, size_t bytes, hipStream_t s) {
+    static std::mutex mu;
+    static std::vector<void*> keep;
+    void* pinned = nullptr;
+    hipError_t rc = hipHostMalloc(&pinned, bytes, hipHostMallocDefault);
+    if (rc != hipSuccess) return rc;
+    memcpy(pinned, host, bytes);
+    {
+        std::lock_guard<std::mutex> g(mu);
+        keep.push_back(pinned);
+    }
+    return hipMemcpyAsync(dev, pinned, bytes, hipMemcpyHostToDevice, s);
+}

@@ -31,6 +31,9 @@ void vaw_set_error(const char* fmt, ...);
         }                                                                            \
     } while (0)
 
+// one-time upload of a descriptor table from a pinned copy that stays alive (capi.hip)
+hipError_t vaw_upload_table(void* dev, const void* host, size_t bytes, hipStream_t s);
+
 // ---- element access by activation dtype ------------------------------------
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }

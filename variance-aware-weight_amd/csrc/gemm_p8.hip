@@ -169,7 +169,7 @@ extern "C" int vaw_wgrad_grouped(vaw_dtype dt, int n_problems, const vaw_wgrad_p
     }
     hipStream_t s = (hipStream_t)stream;
     if (upload) {
-        const hipError_t rc = hipMemcpyAsync(desc_dev, host.data(), sizeof(P8Prob) * n_problems, hipMemcpyHostToDevice, s);
+        const hipError_t rc = vaw_upload_table(desc_dev, host.data(), sizeof(P8Prob) * n_problems, s);
         VAW_CHECK_ARG(rc == hipSuccess, "wgrad_grouped: descriptor upload failed: %s", hipGetErrorString(rc));
     }
     const int cus = p8_num_cus(), nk = (int)(K / kt);

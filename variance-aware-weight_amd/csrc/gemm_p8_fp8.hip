@@ -475,7 +475,7 @@ extern "C" int vaw_fp8_quantize_delayed_batched(int n_jobs, const vaw_fp8_quant_
     }
     hipStream_t s = (hipStream_t)stream;
     if (upload) {
-        const hipError_t rc = hipMemcpyAsync(desc_dev, host, sizeof(QuantJobDev) * n_jobs, hipMemcpyHostToDevice, s);
+        const hipError_t rc = vaw_upload_table(desc_dev, host, sizeof(QuantJobDev) * n_jobs, s);
         VAW_CHECK_ARG(rc == hipSuccess, "fp8_quantize_delayed_batched: descriptor upload failed: %s", hipGetErrorString(rc));
     }
     fp8_quantize_batched_kernel<<<(unsigned)blocks, 256, 0, s>>>((const QuantJobDev*)desc_dev, n_jobs);

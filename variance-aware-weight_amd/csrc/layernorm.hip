@@ -774,7 +774,7 @@ extern "C" int vaw_reduce_rows_batched(int n_jobs, const vaw_reduce_job* jobs, f
     }
     hipStream_t s = (hipStream_t)stream;
     if (upload) {
-        const hipError_t rc = hipMemcpyAsync(desc_dev, host, sizeof(ReduceJobDev) * n_jobs, hipMemcpyHostToDevice, s);
+        const hipError_t rc = vaw_upload_table(desc_dev, host, sizeof(ReduceJobDev) * n_jobs, s);
         VAW_CHECK_ARG(rc == hipSuccess, "reduce_rows_batched: descriptor upload failed: %s", hipGetErrorString(rc));
     }
     colsum_final_batched_kernel<<<(unsigned)blocks, 1024, 0, s>>>((const ReduceJobDev*)desc_dev, n_jobs, beta);

@@ -263,6 +263,8 @@ class DiT(FlatModule):
             raise ValueError(f"compute_dtype must be 'bf16', 'fp32' or 'fp8', got {name}")
         if name == "fp8" and (self.D % 128 or self.Dm % 128):
             raise ValueError("compute_dtype='fp8' needs hidden and MLP widths that are multiples of 128 (one fp8 MFMA K tile)")
+        if name != getattr(self, "compute_dtype", name):
+            self.require_fresh_masters("set_compute_dtype()")      # (every other mode derives its weights from the f32 masters)
         self.compute_dtype = name
         self._dt = F32 if name == "fp32" else BF16
         self._fp8 = name == "fp8"
@@ -378,6 +380,7 @@ class DiT(FlatModule):
         epoch = (self._weights_epoch, self._flat.data_ptr())
         if self._fp8_epoch == epoch:
             return
+        self.require_fresh_masters("re-quantising the fp8 weights")
         dev = self._flat.device
         if self._fp8_wstates is None or self._fp8_wstates.device != dev:
             self._fp8_wstates, self._fp8_w, self._fp8_wgroup = ops.fp8_states([L.FP8] * (4 * self.depth), dev, self.fp8_margin), {}, None
@@ -575,16 +578,22 @@ class DiT(FlatModule):
         def fold_bias(blocks, qkv_too):
             """The bias gradients of `blocks` from the partial column sums their backward left behind: one launch."""
             key = (blocks[0], blocks[-1], self._gbase, qkv_too)
-            grp = ws.bias_groups.get(key)
-            if grp is None:
-                jobs = []
-                for l in blocks:
-                    b, pre = ws.blk[l], f"blocks.{l}."
-                    names = [("cp_fc2", "mlp.fc2."), ("cp_fc1", "mlp.fc1."), ("cp_proj", "attn.proj.")] + ([("cp_qkv", "attn.qkv.")] if qkv_too else [])
-                    for key_cp, nm in names:
-                        cp = b[key_cp]
-                        jobs.append((cp.buf.data_ptr(), self._g(pre + nm + "bias"), cp.rows.value, cp.N))
-                grp = ws.bias_groups[key] = ops.ReduceGroup(jobs, dout.device)
+            cps = []
+            for l in blocks:
+                b, pre = ws.blk[l], f"blocks.{l}."
+                names = [("cp_fc2", "mlp.fc2."), ("cp_fc1", "mlp.fc1."), ("cp_proj", "attn.proj.")] + ([("cp_qkv", "attn.qkv.")] if qkv_too else [])
+                cps += [(b[key_cp], pre + nm) for key_cp, nm in names]
+            # the number of partial rows a producer leaves is NOT a function of the shape alone: vaw_gemm writes one row per 64, 128
+            # or 256 rows of C depending on the kernel it picks (which moves with the CUs reserved for a collective, with
+            # vaw_debug_gemm_tile, ...), the attention backward one per 64 / 128 / 256 query rows by VAW_ATTN_BWD_BIG.  The device
+            # table bakes the counts in, so it is rebuilt whenever this backward's counts differ from the ones it was built with
+            # (a host-side integer compare per job; folding stale counts would drop or double-count rows silently).
+            rows = tuple(int(cp.rows.value) for cp, _ in cps)
+            ent = ws.bias_groups.get(key)
+            if ent is None or ent[1] != rows:
+                jobs = [(cp.buf.data_ptr(), self._g(nm + "bias"), r, cp.N) for (cp, nm), r in zip(cps, rows)]
+                ent = ws.bias_groups[key] = (ops.ReduceGroup(jobs, dout.device), rows)
+            grp = ent[0]
             grp.launch(beta)
 
         def flush():

@@ -155,6 +155,21 @@ class FlatModule(nn.Module):
         for p in self._flat_params:
             p.grad = None
 
+    # ---- sharded optimizer (ZeRO-1, bf16 mode): after a step only the bf16 shadow is gathered -- the f32 masters of OTHER ranks'
+    # chunks are stale until optimizer.consolidate() / trainer.consolidate() (a collective: every rank calls it).  The flag lives
+    # here, on the module, so that everything that would read or re-derive from the masters can refuse instead of silently
+    # using the stale mix: state_dict(), a re-cast of the shadow, fp8 re-quantisation, set_compute_dtype.
+    _master_stale = False
+
+    def require_fresh_masters(self, what):
+        if self._master_stale:
+            raise RuntimeError(f"{what}: the f32 master parameters of other ranks' chunks are stale (sharded optimizer, bf16 mode) -- "
+                               "call trainer.consolidate() / optimizer.consolidate() on EVERY rank first (it is a collective)")
+
+    def state_dict(self, *args, **kwargs):
+        self.require_fresh_masters("state_dict()")
+        return super().state_dict(*args, **kwargs)
+
     def shadow_bf16(self):
         """bf16 copy of the flat parameters, refreshed when any parameter was modified through torch."""
         self.ensure_flat()
@@ -163,6 +178,7 @@ class FlatModule(nn.Module):
             self._flat_shadow = torch.empty(self._flat.numel(), device=self._flat.device, dtype=torch.bfloat16)
             self._shadow_version = None
         if ver != self._shadow_version:
+            self.require_fresh_masters("re-casting the bf16 shadow weights (a parameter was modified through torch)")
             ops.cast_bf16(self._flat, self._flat_shadow)
             self._shadow_version = ver
             self._weights_epoch += 1

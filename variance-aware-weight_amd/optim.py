@@ -94,6 +94,9 @@ class FusedAdamW(torch.optim.Optimizer):
     def _step_sharded(self):
         """reduce-scattered gradients -> AdamW (+EMA) on this rank's chunks only -> all-gather of the updated weights."""
         m, z, grp = self.model, self.zero, self.param_groups[0]
+        m.ensure_flat()
+        if m._flat.data_ptr() != self._flat_ptr:
+            raise RuntimeError("the model's flat buffer was rebuilt (moved device / deep-copied) after the optimizer was created")
         g = m.flat_grads()
         z.wait_gathers()
         if self.device_hyper is None:
@@ -121,7 +124,7 @@ class FusedAdamW(torch.optim.Optimizer):
             # for this one at once but for the gathered buckets only as it reaches them)
             self._sync_f32_read_params()
             z.all_gather_chunks(shadow)
-            self.master_stale = True
+            self.master_stale = m._master_stale = True
         else:
             # f32 parity mode, and fp8 mode (whose e4m3 weight copies are quantised from the f32 masters)
             z.all_gather_chunks(m._flat)
@@ -166,7 +169,7 @@ class FusedAdamW(torch.optim.Optimizer):
         if self.zero is not None and getattr(self, "master_stale", False):
             self.zero.wait_gathers()
             self.zero.all_gather_chunks(self.model._flat, async_stream=False)
-            self.master_stale = False
+            self.master_stale = self.model._master_stale = False
 
     def consolidate_ema(self, ema_model):
         """ZeRO-1: gather the sharded average into `ema_model`'s trainable parameters (every rank that passes a model gets it)."""
@@ -204,6 +207,12 @@ class FusedAdamW(torch.optim.Optimizer):
         if self.zero is not None:
             return self._step_sharded()
         m = self.model
+        if getattr(m, "_zero", None) is not None:
+            # the model reduce-SCATTERS its gradients (DistributedDataParallel(..., shard_optimizer=True)): only this rank's chunk of
+            # every bucket is averaged.  An optimizer built before the wrap captured zero = None and would update every parameter
+            # from mostly un-reduced local gradients, never gather, and let the ranks drift apart silently
+            raise RuntimeError("this FusedAdamW was built BEFORE the model was wrapped with shard_optimizer=True: build the optimizer "
+                               "after vaw_amd.DistributedDataParallel(model, shard_optimizer=True)")
         m.ensure_flat()
         if m._flat.data_ptr() != self._flat_ptr:
             raise RuntimeError("the model's flat buffer was rebuilt (moved device / deep-copied) after the optimizer was created")

@@ -71,6 +71,11 @@ class Trainer:
             inner.host_dropout_rng = bool(getattr(args, "cpu_rng", False))      # dropout masks from the CPU stream in parity runs
         self._fused = isinstance(optimizer, FusedAdamW)
         self._zero = self._fused and getattr(optimizer, "zero", None) is not None
+        if getattr(inner, "_zero", None) is not None and not self._zero:
+            # gradients are reduce-scattered (shard_optimizer=True): only a FusedAdamW built AFTER the wrap updates its own chunks
+            # and gathers the weights; any other optimizer would step on mostly un-reduced gradients and the ranks would diverge
+            raise ValueError("the model was wrapped with shard_optimizer=True: it needs a vaw_amd.FusedAdamW built after the wrap "
+                             f"(got {type(optimizer).__name__}{' built before the wrap' if self._fused else ''})")
         if self._zero:
             # sharded optimizer: every rank averages its own chunks; rank 0's ema_model receives them on consolidate()
             if getattr(args, "ema_decay", None) is not None:

@@ -229,6 +229,8 @@ class UNetModel(FlatModule):
         name = {"float32": "fp32", "f32": "fp32", "bfloat16": "bf16"}.get(name, name)
         if name not in ("bf16", "fp32"):
             raise ValueError(f"compute_dtype must be 'bf16' or 'fp32', got {name}")
+        if name != getattr(self, "compute_dtype", name):
+            self.require_fresh_masters("set_compute_dtype()")
         self.compute_dtype = name
         self._dt = BF16 if name == "bf16" else F32
 
