@@ -378,3 +378,66 @@ def test_unet_factories_have_the_reference_structure(name):
     assert sum(p.numel() for p in ref.parameters()) == sum(p.numel() for p in got.parameters())
     for k in list(sd_r)[:8] + list(sd_r)[-8:]:       # same seed, same construction order => same initial weights
         torch.testing.assert_close(sd_g[k], sd_r[k], rtol=0, atol=0)
+
+
+class _StrictH5Array:
+    """Stand-in for an h5py dataset: integer, slice or STRICTLY INCREASING index-array reads only (h5py's fancy-index rule)."""
+
+    def __init__(self, a):
+        self.a, self.reads = a, 0
+
+    def __len__(self):
+        return len(self.a)
+
+    def __getitem__(self, i):
+        self.reads += 1
+        if isinstance(i, np.ndarray):
+            assert i.ndim == 1 and (np.diff(i) > 0).all(), "h5py wants increasing indices without repeats"
+        return self.a[i]
+
+
+def test_latent_h5_dataset_contract_and_loader():
+    """vaw_amd.LatentH5Dataset mirrors the reference's `Latent` dataset (datasets/data_loader.py:62-81; layout written by
+    preprocessing/encode_latent.py:95-126: '<split>_latents' f32 [N, 8, 32, 32] = cat[mean, std], '<split>_labels' uint16) on a
+    duck-typed handle (h5py is not in this image: real-file parity is unpinned, the contract is what is tested): item dtypes and
+    values, one sorted read per array and batch with the rows back in request order (repeats included), the sharded sampler +
+    batch loader + prefetcher chain the Trainer consumes, and sample_from_latent on what comes out."""
+    import vaw_amd
+    rng = np.random.default_rng(0)
+    N = 37
+    lat = rng.standard_normal((N, 8, 4, 4)).astype(np.float32)
+    lab = rng.integers(0, 1000, N).astype(np.uint16)
+    h = {"train_latents": _StrictH5Array(lat), "train_labels": _StrictH5Array(lab),
+         "val_latents": _StrictH5Array(lat[:5]), "val_labels": _StrictH5Array(lab[:5])}
+    ds = vaw_amd.LatentH5Dataset(h, "train")
+    assert len(ds) == N and len(vaw_amd.LatentH5Dataset(h, "val")) == 5
+    x, y = ds[7]
+    assert x.dtype == torch.float32 and y.dtype == torch.long and x.shape == (8, 4, 4)
+    assert torch.equal(x, torch.from_numpy(lat[7])) and int(y) == int(lab[7])
+    idx = [30, 2, 2, 19, 0, 36, 19]
+    r0 = h["train_latents"].reads
+    xb, yb = ds.batch(idx)
+    assert h["train_latents"].reads == r0 + 1                                  # one read for the whole batch
+    assert torch.equal(xb, torch.from_numpy(lat[idx])) and torch.equal(yb, torch.from_numpy(lab[idx].astype(np.int64)))
+    # data-parallel input side: rank r of 2 sees its half of every epoch's permutation, batches of 4, last partial batch dropped
+    seen = []
+    for rank in range(2):
+        smp = vaw_amd.ShardedSampler(len(ds), 2, rank, shuffle=True, seed=3)
+        loader = vaw_amd.DevicePrefetcher(vaw_amd.LatentBatchLoader(ds, 4, smp), "cpu")
+        loader.sampler.set_epoch(5)
+        batches = list(loader)
+        assert len(batches) == len(loader) == len(smp) // 4
+        order = list(smp)
+        for k, (xb, yb) in enumerate(batches):
+            want = order[4 * k:4 * k + 4]
+            assert torch.equal(xb, torch.from_numpy(lat[want])) and torch.equal(yb, torch.from_numpy(lab[want].astype(np.int64)))
+            seen += want
+    assert len(set(seen)) >= N - 5                                              # the two ranks cover the set (minus the dropped tail)
+    z = vaw_amd.sample_from_latent(batches[0][0], 0.18215, cpu_rng=True)
+    assert z.shape == (4, 4, 4, 4)
+    # the object travels to DataLoader workers before any file is open
+    import pickle
+    ds2 = pickle.loads(pickle.dumps(vaw_amd.LatentH5Dataset({"train_latents": lat, "train_labels": lab})))
+    assert torch.equal(ds2[3][0], torch.from_numpy(lat[3]))
+    with pytest.raises(ValueError):
+        vaw_amd.LatentH5Dataset({"train_latents": lat, "train_labels": lab[:-1]})

@@ -9,7 +9,7 @@ from .gaussian_diffusion import (FlowMatching, GaussianDiffusion, LossType, Mode
                                  compute_mse_loss_weight, get_named_beta_schedule, mean_flat)
 from .optim import FusedAdamW  # noqa: F401
 from .parallel import DistributedDataParallel  # noqa: F401
-from .data import DevicePrefetcher, ShardedSampler  # noqa: F401
+from .data import DevicePrefetcher, LatentBatchLoader, LatentH5Dataset, ShardedSampler  # noqa: F401
 from .samplers import EDMDenoiser, edm_sample, flow_ode_sample, flow_sde_sample  # noqa: F401
 from .respace import SpacedDiffusion, space_timesteps  # noqa: F401
 from .sampler import IntervalCFG  # noqa: F401

@@ -101,3 +101,101 @@ class DevicePrefetcher:
                     if torch.is_tensor(t):
                         t.record_stream(torch.cuda.current_stream(self.device))
             yield batch
+
+
+class LatentH5Dataset:
+    """The latent dataset of the reference's ImageNet-256 runs: datasets/data_loader.py:62-81 (`Latent`), written by
+    preprocessing/encode_latent.py:95-126 --
+
+        '<split>_latents'  float32 [N, 2 C, H, W]   cat[posterior mean, posterior std] of the SD-VAE (8 x 32 x 32 for 256-px images)
+        '<split>_labels'   uint16  [N]
+
+    `__getitem__(i)` -> (latent f32 tensor, label int64 tensor), exactly what `Latent.__getitem__` hands the DataLoader (the mean/std
+    pair is sampled and scaled later, by `sample_from_latent` in `Trainer.train_step`).  `source` is a path (opened with h5py, which
+    is imported only then -- it is not part of this image) or ANY mapping-like handle with those two keys whose values support
+    `len()` and integer / slice / sorted-index-array `__getitem__` (an open `h5py.File`, a dict of numpy arrays, a zarr group ...).
+    Unlike the reference, which re-opens the file for every sample, the handle is opened once per process (lazily, so the object
+    can be pickled into DataLoader workers before any file is open) and `batch(indices)` reads a whole batch with ONE sorted
+    fancy-index read per array (h5py needs increasing indices; the rows are put back in request order).
+    Real-file parity is unpinned here (no h5py, no file): the tests pin the contract above on an in-memory stand-in."""
+
+    def __init__(self, source, dataset_type="train"):
+        self.source, self.dataset_type = source, dataset_type
+        self._h = None
+        self._lat_key, self._lab_key = f"{dataset_type}_latents", f"{dataset_type}_labels"
+        self.num_samples = len(self._handle()[self._lat_key])
+        if len(self._handle()[self._lab_key]) != self.num_samples:
+            raise ValueError(f"{self._lat_key} and {self._lab_key} differ in length")
+        if isinstance(source, (str, bytes)) or hasattr(source, "__fspath__"):
+            self._close()                      # re-opened lazily in whichever process reads (DataLoader workers)
+
+    def _handle(self):
+        if self._h is None:
+            src = self.source
+            if isinstance(src, (str, bytes)) or hasattr(src, "__fspath__"):
+                try:
+                    import h5py
+                except ImportError as e:       # pragma: no cover - h5py is absent from the build image
+                    raise ImportError("LatentH5Dataset(path) needs h5py; pass an open mapping-like handle instead") from e
+                src = h5py.File(src, "r")
+            self._h = src
+        return self._h
+
+    def _close(self):
+        h, self._h = self._h, None
+        if h is not None and h is not self.source and hasattr(h, "close"):
+            h.close()
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        if d["_h"] is not d["source"]:
+            d["_h"] = None                     # an open file does not travel; the worker opens its own
+        return d
+
+    def __len__(self):
+        return self.num_samples
+
+    def __getitem__(self, idx):
+        import numpy as np
+        h = self._handle()
+        latent = np.asarray(h[self._lat_key][idx], dtype=np.float32)
+        label = np.asarray(h[self._lab_key][idx])
+        return torch.tensor(latent.copy(), dtype=torch.float32), torch.tensor(label.astype(np.int64), dtype=torch.long)
+
+    def batch(self, indices):
+        """(latents [B, 2C, H, W] f32, labels [B] int64) for `indices` in the order given: one read per array."""
+        import numpy as np
+        idx = np.asarray(list(indices), dtype=np.int64)
+        order = np.argsort(idx, kind="stable")
+        uniq, inverse = np.unique(idx[order], return_inverse=True)      # h5py: strictly increasing, no repeats
+        h = self._handle()
+        lat = np.asarray(h[self._lat_key][uniq], dtype=np.float32)[inverse]
+        lab = np.asarray(h[self._lab_key][uniq])[inverse]
+        back = np.empty_like(order)
+        back[order] = np.arange(len(order))
+        return torch.from_numpy(np.ascontiguousarray(lat[back])), torch.from_numpy(lab[back].astype(np.int64))
+
+
+class LatentBatchLoader:
+    """Re-iterable loader of (latents, labels) batches over a LatentH5Dataset, driven by a sampler's index stream (a
+    `ShardedSampler` in data-parallel runs: main.py:173-180's DistributedSampler + DataLoader(batch_size // world_size,
+    drop_last=True)).  One `dataset.batch()` read per step; wrap it in `DevicePrefetcher` to overlap read and copy with the step.
+    Keeps the surface `Trainer` uses: `.sampler.set_epoch`, `__iter__`, `__len__`."""
+
+    def __init__(self, dataset, batch_size, sampler=None, drop_last=True):
+        self.dataset, self.batch_size, self.drop_last = dataset, int(batch_size), drop_last
+        self.sampler = sampler if sampler is not None else ShardedSampler(len(dataset), 1, 0, shuffle=False)
+
+    def __len__(self):
+        n = len(self.sampler)
+        return n // self.batch_size if self.drop_last else math.ceil(n / self.batch_size)
+
+    def __iter__(self):
+        buf = []
+        for i in self.sampler:
+            buf.append(i)
+            if len(buf) == self.batch_size:
+                yield self.dataset.batch(buf)
+                buf = []
+        if buf and not self.drop_last:
+            yield self.dataset.batch(buf)
