@@ -459,7 +459,18 @@ extern "C" int vaw_ln_modulate_fwd(vaw_dtype dt, const float* x, const float* sh
     VAW_CHECK_ARG(B > 0 && T > 0 && D > 0 && D % 4 == 0 && D <= 2048 && mod_ld % 4 == 0,
                   "ln_modulate_fwd: need D%%4==0, D<=2048, mod_ld%%4==0 (D=%d)", D);
     const int64_t M = (int64_t)B * T;
-    const int grid = ceil_div(M, 4) < 2048 ? ceil_div(M, 4) : 2048;       // 8 workgroups per CU, every wave several rows: see the kernel
+    // one resident round of workgroups (what the registers allow per CU x 256 CUs: 7 x 256 for 768-wide bf16 rows -- a grid of
+    // 8 per CU left the eighth to a second, nearly empty round), every wave several rows: see the kernel
+    static int per_cu[2][9] = {};
+    const int nvk = pick_nv(D) <= 6 ? pick_nv(D) : 8, ti = dt == VAW_F32 ? 0 : 1;
+    if (!per_cu[ti][nvk]) {
+        int nb = 0;
+        if (dt == VAW_F32) { DISPATCH_NV(nvk, (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ln_modulate_fwd_kernel<float, NV>, 256, 0)); }
+        else { DISPATCH_NV(nvk, (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ln_modulate_fwd_kernel<bf16_t, NV>, 256, 0)); }
+        per_cu[ti][nvk] = nb > 0 && nb <= 8 ? nb : 8;
+    }
+    const int64_t cap = 256LL * per_cu[ti][nvk];
+    const int grid = (int)(ceil_div(M, 4) < cap ? ceil_div(M, 4) : cap);
     hipStream_t s = (hipStream_t)stream;
     if (dt == VAW_F32) {
         DISPATCH_NV(pick_nv(D), (ln_modulate_fwd_kernel<float, NV><<<grid, 256, 0, s>>>(x, shift, scale, mod_ld, (float*)out, mean, rstd, M, T, D, eps)));
