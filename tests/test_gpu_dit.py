@@ -526,6 +526,7 @@ def test_bias_gradient_fold_follows_the_producers_row_counts():
         m = vaw_amd.DiT(image_size=32, patch_size=2, in_channels=4, hidden_size=256, depth=2, num_heads=4, num_classes=10,
                         class_dropout_prob=0.0, learn_sigma=False, compute_dtype="bf16").to(DEV).train()
         perturb_(m, 3, 0.05)
+        m.ensure_flat()
         return m
 
     g = torch.Generator().manual_seed(9)
