@@ -438,13 +438,15 @@ attn_bwd_t64_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __
                   const bf16_t* __restrict__ o, const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                   float* __restrict__ delta_out, bf16_t* __restrict__ dq, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv,
                   float* __restrict__ cs_part = nullptr, int64_t cs_ld = 0) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 images of 64 x HD bf16 (reused as output staging) + lse / delta
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 images of 64 x HD bf16 (reused as output staging; lse / delta: below)
     constexpr int KS = HD / 32, DT = HD / 16;
     char* qimg = smem;
     char* gimg = qimg + Img<HD>::BYTES;
     char* kimg = gimg + Img<HD>::BYTES;
     char* vimg = kimg + Img<HD>::BYTES;
-    float* lse_s = reinterpret_cast<float*>(vimg + Img<HD>::BYTES);
+    // (r4) the rows' lse / delta, which phase 2 reads for ALL 64 queries, live in the V image once phase 1 is through with it (they wait in
+    // registers until then) instead of in 512 bytes of their own: 4 x 8 KiB = 32 KiB exactly at hd 64 -> FIVE workgroups per CU, not four
+    float* lse_s = reinterpret_cast<float*>(vimg);
     float* del_s = lse_s + 64;
     const int lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -469,11 +471,7 @@ attn_bwd_t64_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __
     }
     const float c2 = a.scale * 1.4426950408889634f;
     const float li_lse = lse[(int64_t)bh * 64 + qi] * 1.4426950408889634f;             // base-2 domain
-    if (g == 0) {
-        delta_out[(int64_t)bh * 64 + qi] = dl;
-        lse_s[qi] = li_lse;
-        del_s[qi] = dl;
-    }
+    if (g == 0) delta_out[(int64_t)bh * 64 + qi] = dl;
     DMA_WAIT_SYNC();
     // Output staging (r3): dq, dk, dv leave through LDS as whole rows -- a lane of an accumulator tile owns 4 bf16 of one row, so
     // direct stores write 32-byte pieces of 16 rows per instruction; staged, eight lanes write one 128-byte row with 16 bytes each
@@ -529,8 +527,13 @@ attn_bwd_t64_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __
             kf[s] = frag_rows<HD>(kimg, 16 * wid, s, lane);
             vf[s] = frag_rows<HD>(vimg, 16 * wid, s, lane);
         }
-        __syncthreads();                  // nobody reads the K / V images any more: dq is staged over them
+        __syncthreads();                  // nobody reads the K / V images any more: dq is staged over K, lse / delta go into V
         stage_tile(kimg, acc);
+        if (g == 0) {
+            lse_s[qi] = li_lse;
+            del_s[qi] = dl;
+        }
+        __syncthreads();
         f32x4 p[4], ds[4];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) av[dt] = ak[dt] = f32x4{0, 0, 0, 0};
@@ -674,7 +677,7 @@ int vaw_attn_bwd_mfma(const vaw_attn_desc* d, const void* q, const void* k, cons
     dim3 grid(d->T / 64, d->B * d->H);
     if (d->T == 64) {      // single block of queries and keys: one fused launch
         DISPATCH_HD(d->hd,
-            const int lds = 4 * Img<HD>::BYTES + 2 * 64 * 4;
+            const int lds = 4 * Img<HD>::BYTES;
             (void)hipFuncSetAttribute((const void*)attn_bwd_t64_mfma<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             attn_bwd_t64_mfma<HD><<<d->B * d->H, 256, lds, s>>>(a, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o,
                                                               (const bf16_t*)d_o, lse, delta, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, cs_part, cs_ld);

@@ -249,7 +249,7 @@ row_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ x, const fl
     }
 }
 
-// ---- the fused LayerNorm-backward + gate-backward pass for bf16 rows up to 768 wide (DiT-S / DiT-B), rebuilt around memory-level
+// ---- the fused LayerNorm-backward + gate-backward pass for bf16 rows up to 1280 wide (DiT-S / B / L / XL), rebuilt around memory-level
 // parallelism (round 4).  row_bwd_kernel<FUSE> above keeps four accumulator sets in registers: at 1024 threads that leaves a wave
 // no room to have more than one slab of one row in flight, and the compiler ends every `if (c < D)` block that holds loads with a
 // wait for them -- 3.8-4.2 TB/s of its 18 B per element, 89 % of the wave time parked on memory (PMC, round 3).  Here:
@@ -433,9 +433,9 @@ static int pick_chunks(int B, int Tt, bool have_ws, int target_wgs = 256) {
 }
 extern "C" int64_t vaw_row_bwd_workspace_floats(int B, int T, int D) { return (int64_t)pick_chunks(B, T, true, 512) * B * 4 * D; }
 
-// (rows up to 768 wide: 8 waves everywhere, so that the fused pass -- row_bwd_fuse8_kernel -- and the pair of kernels it replaces cut a
+// (rows up to 1280 wide: 8 waves everywhere, so that the fused pass -- row_bwd_fuse8_kernel -- and the pair of kernels it replaces cut a
 // sample's rows into the same per-wave partial sums and stay bitwise equal)
-static int row_waves(int nv, int wide_default) { return nv <= 3 ? 8 : wide_default; }
+static int row_waves(int nv, int wide_default) { return nv <= 5 ? 8 : wide_default; }
 static int pick_block(int Tt, int max_waves = 16) {
     int nw = Tt < max_waves ? Tt : max_waves;
     if (nw < 1) nw = 1;
@@ -546,12 +546,12 @@ extern "C" int vaw_ln_modulate_bwd_gate(vaw_dtype dt, const void* dout, const fl
     dim3 grid(B, nc);
     if (dt == VAW_F32) {
         DISPATCH_NV(nv, (row_bwd_kernel<float, NV, false, false, true><<<grid, block, lds, s>>>((const float*)dout, x, mean, rstd, scale, mod_ld, dres_in, dx, dshift, dscale, dmod_ld, T, D, nullptr, (const float*)y_next, gate_next, (float*)dy_next, dgate_next, dy_colsum_partial, rpc, part)));
-    } else if (nv <= 3) {
+    } else if (nv <= 5) {
 #define LAUNCH_FUSE8(NVv)                                                                                                              \
     row_bwd_fuse8_kernel<NVv, false><<<grid, block, row_fuse8_lds<NVv, false>(D, block), s>>>(                                          \
         (const bf16_t*)dout, x, mean, rstd, scale, mod_ld, dres_in, dx, dshift, dscale, dmod_ld, T, D, (const bf16_t*)y_next, gate_next, \
         (bf16_t*)dy_next, dgate_next, dy_colsum_partial, rpc, part, nullptr, nullptr, 0)
-        if (nv == 1) LAUNCH_FUSE8(1); else if (nv == 2) LAUNCH_FUSE8(2); else LAUNCH_FUSE8(3);
+        if (nv == 1) LAUNCH_FUSE8(1); else if (nv == 2) LAUNCH_FUSE8(2); else if (nv == 3) LAUNCH_FUSE8(3); else if (nv == 4) LAUNCH_FUSE8(4); else LAUNCH_FUSE8(5);
     } else {
         DISPATCH_NV(nv, (row_bwd_kernel<bf16_t, NV, false, false, true><<<grid, block, lds, s>>>((const bf16_t*)dout, x, mean, rstd, scale, mod_ld, dres_in, dx, dshift, dscale, dmod_ld, T, D, nullptr, (const bf16_t*)y_next, gate_next, (bf16_t*)dy_next, dgate_next, dy_colsum_partial, rpc, part)));
     }
@@ -583,12 +583,12 @@ extern "C" int vaw_ln_modulate_bwd_gate_fp8(const void* dout, const float* x, co
     const int block = pick_block(rpc, 8);
     const size_t lds = 6 * (size_t)D * sizeof(float);
     dim3 grid(B, nc);
-    if (nv <= 3) {
+    if (nv <= 5) {
 #define LAUNCH_FUSE8Q(NVv)                                                                                                             \
     row_bwd_fuse8_kernel<NVv, true><<<grid, block, row_fuse8_lds<NVv, true>(D, block), s>>>(                                            \
         (const bf16_t*)dout, x, mean, rstd, scale, mod_ld, dres_in, dx, dshift, dscale, dmod_ld, T, D, (const bf16_t*)y_next, gate_next, \
         nullptr, dgate_next, dy_colsum_partial, rpc, part, (unsigned char*)dy_q, q_state, q_format == VAW_BF8)
-        if (nv == 1) LAUNCH_FUSE8Q(1); else if (nv == 2) LAUNCH_FUSE8Q(2); else LAUNCH_FUSE8Q(3);
+        if (nv == 1) LAUNCH_FUSE8Q(1); else if (nv == 2) LAUNCH_FUSE8Q(2); else if (nv == 3) LAUNCH_FUSE8Q(3); else if (nv == 4) LAUNCH_FUSE8Q(4); else LAUNCH_FUSE8Q(5);
     } else {
         DISPATCH_NV(nv, (row_bwd_kernel<bf16_t, NV, false, true, true><<<grid, block, lds, s>>>((const bf16_t*)dout, x, mean, rstd, scale, mod_ld, dres_in, dx, dshift, dscale, dmod_ld, T, D, nullptr, (const bf16_t*)y_next, gate_next, nullptr, dgate_next, dy_colsum_partial, rpc, part, (unsigned char*)dy_q, q_state, q_format == VAW_BF8)));
     }

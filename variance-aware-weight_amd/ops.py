@@ -498,10 +498,10 @@ def ln_modulate_bwd(dt, dout, x, mean, rstd, scale, mod_ld, dres_in, dx, dshift,
 
 def ln_modulate_bwd_gate(dt, dout, x, mean, rstd, scale, mod_ld, dres_in, dx, dshift, dscale, dmod_ld, y_next, gate_next, dy_next,
                          dgate_next, B, T, D, dy_colpart=0):
-    """ln_modulate_bwd + the gate_bwd that consumes its dx, one pass (vaw_ln_modulate_bwd_gate).  Rows wider than 768 run the
-    pair instead (bitwise the same results): four accumulator sets of a 1152-wide row need 176-190 registers, the fused kernel then
-    holds 16 waves per CU at 3.3 TB/s where the pair moves more bytes at 4.5 TB/s (DiT-XL/2: 196 against 119 + 57 us)."""
-    if D > 768:
+    """ln_modulate_bwd + the gate_bwd that consumes its dx, one pass (vaw_ln_modulate_bwd_gate: row_bwd_fuse8_kernel for bf16 rows up
+    to 1280 wide -- per-sample sums in LDS slabs, operand rows requested ahead).  Wider rows run the pair instead (bitwise the same
+    results): the fused kernel's LDS slabs no longer fit and the register-accumulator form held 16 waves per CU at 3.3 TB/s."""
+    if D > 1280:
         ln_modulate_bwd(dt, dout, x, mean, rstd, scale, mod_ld, dres_in, dx, dshift, dscale, dmod_ld, B, T, D)
         gate_bwd(dt, dx, y_next, gate_next, mod_ld, dy_next, dgate_next, dmod_ld, B, T, D, dy_colpart)
         return
@@ -514,7 +514,7 @@ def ln_modulate_bwd_gate(dt, dout, x, mean, rstd, scale, mod_ld, dres_in, dx, ds
 def ln_modulate_bwd_gate_fp8(dout, x, mean, rstd, scale, mod_ld, dres_in, dx, dshift, dscale, dmod_ld, y_next, gate_next, f8,
                              dgate_next, B, T, D, dy_colpart=0, pool=2):
     """The fused pass with dy_next going straight into the Fp8 `f8` (as gate_bwd_fp8); wide rows: the pair, as above."""
-    if D > 768:
+    if D > 1280:
         ln_modulate_bwd(BF16, dout, x, mean, rstd, scale, mod_ld, dres_in, dx, dshift, dscale, dmod_ld, B, T, D)
         gate_bwd_fp8(dx, y_next, gate_next, mod_ld, f8, dgate_next, dmod_ld, B, T, D, dy_colpart, pool)
         return
