@@ -60,23 +60,27 @@ gemm_sm_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
     }
     const unsigned step_a = 128u, step_b = BKM ? 128u : (unsigned)(64 * ldb * 2);
     unsigned so_a = 0, so_b = 0;
-    int iss = 0;                                                // next K tile to issue
-    auto issue = [&]() {
-        char* dst = smem + (iss % STAGES) * Cfg::stage_bytes;
+    // (r4) no end state: past the last K tile the stream keeps issuing pieces at out-of-range offsets (zeros into a stage nobody reads
+    // any more), so the K loop has ONE counted wait and no `if (iss < nk)` -- scalar branches in a K loop cost far more than they look
+    // (gemm_pd_kernel.h); stage indices are carried, not computed modulo STAGES
+    int iss = 0, iss_stage = 0;                                 // next K tile to issue, and its stage
+    auto issue = [&]() __attribute__((always_inline)) {
+        char* dst = smem + iss_stage * Cfg::stage_bytes;
+        const bool live = iss < nk;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
 #pragma unroll
-            for (int p = 0; p < MB; ++p) p8_dma16(rs_a, dst + p * P8_PART + (wid + 4 * h) * 1024, off_a[p][h], so_a);
+            for (int p = 0; p < MB; ++p) p8_dma16(rs_a, dst + p * P8_PART + (wid + 4 * h) * 1024, live ? off_a[p][h] : EPI_OOB, so_a);
 #pragma unroll
-            for (int p = 0; p < NB; ++p) p8_dma16(rs_b, dst + (MB + p) * P8_PART + (wid + 4 * h) * 1024, off_b[p][h], so_b);
+            for (int p = 0; p < NB; ++p) p8_dma16(rs_b, dst + (MB + p) * P8_PART + (wid + 4 * h) * 1024, live ? off_b[p][h] : EPI_OOB, so_b);
         }
         so_a += step_a;
         so_b += step_b;
         ++iss;
+        iss_stage = iss_stage == STAGES - 1 ? 0 : iss_stage + 1;
     };
 #pragma unroll
-    for (int s = 0; s < STAGES - 1; ++s)
-        if (iss < nk) issue();
+    for (int s = 0; s < STAGES - 1; ++s) issue();
 
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -84,13 +88,14 @@ gemm_sm_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
 
+    int cstage = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        // K tile kt has landed once at most the tiles issued after it are outstanding: (STAGES - 2) of them in steady state
-        if (kt + STAGES - 1 <= nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * Cfg::pieces) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // tail: fewer tiles behind it
+        // K tile kt has landed once at most the (STAGES - 2) tiles issued after it are outstanding
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * Cfg::pieces) : "memory");
         __builtin_amdgcn_s_barrier();          // every wave's pieces of tile kt are in; everyone has finished reading tile kt - 1
-        if (iss < nk) issue();                 // ... so its stage takes tile kt + STAGES - 1
-        const char* st = smem + (kt % STAGES) * Cfg::stage_bytes;
+        issue();                               // ... so its stage takes tile kt + STAGES - 1 (or out-of-range pieces past the end)
+        const char* st = smem + cstage * Cfg::stage_bytes;
+        cstage = cstage == STAGES - 1 ? 0 : cstage + 1;
         bf16x8 af[2][MT], bfr[2][NT];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -123,7 +128,8 @@ gemm_sm_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
     const int lr = lane & 15, g4 = 4 * (lane >> 4);
     constexpr int LD = Cfg::BN + 4;                                   // f32 row pitch: conflict-free for the 4-column accumulator writes
     float* cs = reinterpret_cast<float*>(smem);
-    __syncthreads();                                                  // every wave has left the K loop (its last wait was vmcnt(0))
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the stream's trailing out-of-range pieces have written their zeros
+    __syncthreads();                                                  // every wave has left the K loop
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
