@@ -33,6 +33,13 @@
 #ifndef PD_DBG
 #define PD_DBG 0
 #endif
+// 1: ONE barrier per K tile.  With three ring stages a piece is issued into the stage that was read a whole K tile ago, so the
+// barrier that makes a K tile's pieces visible to every wave also proves that everybody has left the stage the next pieces go
+// into: wait -> barrier -> issue the whole set two K tiles ahead -> all fragment reads of the K tile -> 8 NTW MFMAs, the waves
+// free-running in between (no phase structure, no wave-row stagger).  0: the two-phase, four-barrier form.
+#ifndef PD_ONEBAR
+#define PD_ONEBAR 0
+#endif
 template <int NTW> struct PdCfg {
     static constexpr int BN = 64 * NTW, WN = 16 * NTW;
     static constexpr int LS = 2 + NTW;                      // DMA pieces per wave and K tile: B parts 0..NTW-1, A parts 0, 1
@@ -387,7 +394,7 @@ gemm_pd_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int u = 0; u < NTW; ++u) acc[i][u] = f32x4{0, 0, 0, 0};
-        if (wr == 1) __builtin_amdgcn_s_barrier();       // waves 4-7 run half a phase behind waves 0-3
+        if (!PD_ONEBAR && wr == 1) __builtin_amdgcn_s_barrier();       // waves 4-7 run half a phase behind waves 0-3
         int lane_k = lane;
         asm volatile("" : "+v"(lane_k));
         // One K tile.  J >= 0: the J-th K tile of an item whose predecessor is parked -- its drain slot J (J < DMAX) runs in phase 2 and
@@ -421,6 +428,32 @@ gemm_pd_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
                     acc[2 * (j) + t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[s][u], af[s][t], acc[2 * (j) + t][u], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                                                \
     } while (0)
+            if (PD_ONEBAR) {
+                pd_vmwait<LS + C1 * ND>();     // every piece of this K tile's set (its last one was issued two K tiles ago); younger: the next set
+                __builtin_amdgcn_s_barrier();
+                issue_p1();
+                issue_p2();
+                bf16x8 af1[2][2];
+#pragma unroll
+                for (int u = 0; u < NTW; ++u) {
+                    const int n = wn0 + 16 * u;
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) bfr[s][u] = p8_frag<BKM>(st + Cfg::a_bytes + (n >> 6) * P8_PART, n & 63, s, lane_k);
+                }
+                load_a(0);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) af1[s][t] = p8_frag<true>(st + P8_PART, wr * 32 + 16 * t, s, lane_k);
+                if (live(J)) run_slot(std::integral_constant<int, (J >= 0 && J < DMAX ? J : 0)>{}, std::false_type{});
+                PD_MMA(0);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) af[s][t] = af1[s][t];
+                PD_MMA(1);
+                return;
+            }
             // ---- phase 1: B fragments of the whole K tile, A rows 0-31 of the wave's 64; pieces B0-B2 of the set two K tiles ahead
 #pragma unroll
             for (int u = 0; u < NTW; ++u) {
@@ -449,7 +482,7 @@ gemm_pd_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
             kt = DMAX + 2;
         }
         for (; kt < nk; ++kt) ktile(std::integral_constant<int, -1>{});
-        if (wr == 0) __builtin_amdgcn_s_barrier();       // level the two wave rows
+        if (!PD_ONEBAR && wr == 0) __builtin_amdgcn_s_barrier();       // level the two wave rows
         // ---- the finished tile is parked (measurement builds with PD_DBG = 3 drain the previous one in the open first) ----
         if (PD_DBG == 3 && parked) {
             pd_unroll([&](auto dd) __attribute__((always_inline)) { run_slot(dd, std::true_type{}); }, std::make_integer_sequence<int, DMAX>{});
