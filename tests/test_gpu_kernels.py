@@ -313,15 +313,16 @@ def _gemm_epilogues(dtype):
                                **(tol if dtype == torch.float32 else dict(rtol=2e-2, atol=5e-2)))
 
 
-@pytest.mark.parametrize("tile", [10, 11])
+@pytest.mark.parametrize("tile", [10, 11, 13, 14])
 @pytest.mark.parametrize("layout", ["fwd", "dgrad"])
 def test_gemm_parked_drain_exact_integers(layout, tile):
-    """gemm_pd_kernel (128-row tiles, the finished tile parked in registers and drained under the next tile's K loop): small
+    """(tiles 13 / 14: the same shapes on gemm_ws_kernel, the warp-specialised 128-row kernel -- 8 consumer + 4 loader waves.)
+    gemm_pd_kernel (128-row tiles, the finished tile parked in registers and drained under the next tile's K loop): small
     integers are exact, so every element of every tile must match; shapes cover edge tiles in M and N, the shortest K it
     takes (12 K tiles: the unrolled drain K tiles and nothing else), an odd K tile count, one item per workgroup (everything
     drains in the open) and 3-4 items per workgroup (steady state), with fused column sums."""
     b_k = layout == "fwd"
-    lib().vaw_debug_gemm_tile(tile)     # 10 / 11: the parked-drain kernel with 256 / 192 columns wherever it applies
+    lib().vaw_debug_gemm_tile(tile)     # 10 / 11: the parked-drain kernel with 256 / 192 columns wherever it applies; 13 / 14: the warp-specialised one
     try:
         for (M, N, K) in [(256, 512, 768), (200, 72, 832), (1160, 776, 832), (16384, 768, 768), (40008, 520, 768), (20000, 3072, 960)]:
             A, B = _mk(M, N, K, True, b_k, torch.bfloat16, seed=M + N + K, ints=True)
@@ -337,7 +338,7 @@ def test_gemm_parked_drain_exact_integers(layout, tile):
         lib().vaw_debug_gemm_tile(-1)
 
 
-@pytest.mark.parametrize("tile", [10, 11])
+@pytest.mark.parametrize("tile", [10, 11, 13, 14])
 def test_gemm_parked_drain_epilogues_vs_persistent_kernel(tile):
     """The four epilogue kinds of the Linear launches on gemm_pd_kernel against gemm_p8_kernel on the same operands: bias + store,
     GELU with the saved pre-activation and the gated residual must be BITWISE equal (both round acc + bias to bf16 first);
@@ -375,7 +376,7 @@ def test_gemm_parked_drain_epilogues_vs_persistent_kernel(tile):
         return out
 
     try:
-        ref, got = run(3 if tile == 11 else 2), run(tile)
+        ref, got = run(3 if tile in (11, 14) else 2), run(tile)
     finally:
         lib().vaw_debug_gemm_tile(-1)
     for k in ("qkv", "a", "hpre", "res", "y"):
@@ -404,7 +405,7 @@ def _colsum_partial_with_guard(rows, N):
     return part, big
 
 
-@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3, 5, 6, 7, 8, 10, 11])
+@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3, 5, 6, 7, 8, 10, 11, 13, 14])
 @pytest.mark.parametrize("M", [2048, 4096, 16384])
 def test_gemm_colsum_partial_each_path(tile, M):
     """vaw_gemm with colsum_partial_out on every dispatch target (vaw_debug_gemm_tile: 128 x 128, the 256 x 256 ring, the persistent

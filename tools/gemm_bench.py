@@ -83,11 +83,11 @@ if __name__ == "__main__":
     if a.m:
         DIT_B4[:] = [(n, l, a.m, N, K, e) for (n, l, _, N, K, e) in DIT_B4 if l != "wgrad"]
     from vaw_amd._lib import lib
-    tiles = {"auto": [-1], "128": [0], "256": [1], "both": [0, 1], "p8": [4], "cmp": [0, 2, 3], "p8_256": [2], "p8_192": [3], "sm": [-1, 6, 7, 8], "pd": [-1, 9], "pdcmp": [2, 3, 10, 11]}[a.tile]
+    tiles = {"auto": [-1], "128": [0], "256": [1], "both": [0, 1], "p8": [4], "cmp": [0, 2, 3], "p8_256": [2], "p8_192": [3], "sm": [-1, 6, 7, 8], "pd": [-1, 9], "pdcmp": [2, 3, 10, 11], "ws": [2, 3, 13, 14]}[a.tile]
     for row in {"dit_b4": DIT_B4, "square": SQUARE, "unet64": UNET64, "all": DIT_B4 + SQUARE, "rounds": ROUNDS}[a.shapes]:
         if a.only is None or a.only in row[0]:
             for t in tiles:
                 lib().vaw_debug_gemm_tile(t)
                 if len(tiles) > 1:
-                    print(f"[tile {('128', '256', 'p8/256', 'p8/192', 'p8', 'sm', 'sm/64', 'sm/128', 'sm/128x128', 'pd', 'pd/256', 'pd/192', 'auto')[t]}] ", end="")
+                    print(f"[tile {('128', '256', 'p8/256', 'p8/192', 'p8', 'sm', 'sm/64', 'sm/128', 'sm/128x128', 'pd', 'pd/256', 'pd/192', 'ws', 'ws/256', 'ws/192', 'auto')[t]}] ", end="")
                 run(*row, a.iters)

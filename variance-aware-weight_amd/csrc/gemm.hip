@@ -751,6 +751,9 @@ int vaw_pd_pick_ntw(int64_t M, int64_t N, int cus_avail);
 void vaw_pd_launch(int ntw, int epi, int b_kmajor, int64_t M, int64_t N, int64_t K, const bf16_t* a, int64_t lda, const bf16_t* b,
                    int64_t ldb, const EpiDev& e, int cus_avail, hipStream_t s);
 int vaw_p8_cus_available();
+// the warp-specialised kernel (gemm_ws.hip)
+void vaw_ws_launch(int ntw, int epi, int b_kmajor, int64_t M, int64_t N, int64_t K, const bf16_t* a, int64_t lda, const bf16_t* b,
+                   int64_t ldb, const EpiDev& e, int cus, hipStream_t s);
 
 static int g_force_generic = 0;
 extern "C" void vaw_debug_force_generic_gemm(int on) { g_force_generic = on; }
@@ -965,15 +968,18 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
             // vaw_debug_gemm_tile(9 / 10 / 11) forces it (tests, A/B runs).
             static int pd_auto = -1;
             if (pd_auto < 0) { const char* v = getenv("VAW_GEMM_PD"); pd_auto = v ? atoi(v) : 0; }
-            const bool pd_forced = g_gemm_tile >= 9 && g_gemm_tile <= 11;
+            const bool ws_forced = g_gemm_tile >= 12 && g_gemm_tile <= 14;       // 12 / 13 / 14: the warp-specialised kernel (width by shape / 256 / 192)
+            static int ws_auto = -1;
+            if (ws_auto < 0) { const char* v = getenv("VAW_GEMM_WS"); ws_auto = v ? atoi(v) : 0; }
+            const bool pd_forced = (g_gemm_tile >= 9 && g_gemm_tile <= 11) || ws_forced;
             const int64_t rows64 = (M + 63) / 64;
             EpiDev epd = e;          // (e.colpart is set above when this launch carries column sums)
-            const int pd_kind = (pd_forced || (pd_auto && g_gemm_tile == -1)) && bk_env == 0 && !rowsum_out &&
+            const int pd_kind = (pd_forced || ((pd_auto || ws_auto) && g_gemm_tile == -1)) && bk_env == 0 && !rowsum_out &&
                                         (!colsum_out || colsum_part || workspace_floats >= rows64 * N)
                                     ? vaw_pd_epi_kind(epd, a_kmajor != 0, b_kmajor != 0, M, N, K) : -1;
             if (pd_kind >= 0) {
                 const int cus = vaw_p8_cus_available();
-                const int ntw = g_gemm_tile == 10 ? 4 : g_gemm_tile == 11 ? 3 : vaw_pd_pick_ntw(M, N, cus);
+                const int ntw = (g_gemm_tile == 10 || g_gemm_tile == 13) ? 4 : (g_gemm_tile == 11 || g_gemm_tile == 14) ? 3 : vaw_pd_pick_ntw(M, N, cus);
                 const int64_t items = ((M + 127) / 128) * ((N + 64 * ntw - 1) / (64 * ntw));
                 // by shape: at least two rounds of workgroups (the first tile of a workgroup has nothing to hide its epilogue
                 // under... the last one's leaves in the open), K of the blocks' Linear layers
@@ -985,7 +991,8 @@ extern "C" int vaw_gemm(vaw_dtype dt, int a_kmajor, int b_kmajor, int64_t M, int
                     epd.nt_off = 1;
                     epd.nt_aux = nt_aux;
                     epd.colpart = colsum_out ? colsum_dst : nullptr;
-                    vaw_pd_launch(ntw, pd_kind, b_kmajor, M, N, K, a, lda, b, ldb, epd, cus, s);
+                    if (ws_forced || (ws_auto && !pd_forced)) vaw_ws_launch(ntw, pd_kind, b_kmajor, M, N, K, a, lda, b, ldb, epd, cus, s);
+                    else vaw_pd_launch(ntw, pd_kind, b_kmajor, M, N, K, a, lda, b, ldb, epd, cus, s);
                     VAW_CHECK_LAUNCH("gemm_pd");
                     if (colsum_out) return fold_colsum(rows64);
                     return VAW_OK;

@@ -1,0 +1,16 @@
+// Instantiations of the warp-specialised GEMM (gemm_ws_kernel.h) for the input-gradient layout: A [M][K] (dy), B [K][N] (weights as stored).
+#include "gemm_ws_kernel.h"
+
+void ws_launch_dgrad(int ntw, int epi, const bf16_t* a, int64_t lda, const bf16_t* b, int64_t ldb, int nk, int tiles_m, int tiles_n,
+                     int grid, const EpiDev& e, hipStream_t s) {
+#define WS_CASE(EPIv)                                                                                    \
+    case EPIv:                                                                                           \
+        if (ntw == 4) ws_launch_one<false, 4, EPIv>(a, lda, b, ldb, nk, tiles_m, tiles_n, grid, e, s);   \
+        else ws_launch_one<false, 3, EPIv>(a, lda, b, ldb, nk, tiles_m, tiles_n, grid, e, s);            \
+        break
+    switch (epi) {
+        WS_CASE(P8_STORE);
+        WS_CASE(P8_DGELU);
+        default: break;
+    }
+}
