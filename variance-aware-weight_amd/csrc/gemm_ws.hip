@@ -2,6 +2,13 @@
 // lives in gemm_ws_dgrad.hip.
 #include "gemm_ws_kernel.h"
 
+// VAW_WS_LOADERS=8: the 192-column kernels with eight loader waves (16 waves per workgroup) instead of four
+static bool ws_loaders8() {
+    static int v = -1;
+    if (v < 0) { const char* s = getenv("VAW_WS_LOADERS"); v = (s && atoi(s) == 8) ? 1 : 0; }
+    return v == 1;
+}
+
 void ws_launch_dgrad(int ntw, int epi, const bf16_t* a, int64_t lda, const bf16_t* b, int64_t ldb, int nk, int tiles_m, int tiles_n,
                      int grid, const EpiDev& e, hipStream_t s);
 
@@ -15,6 +22,7 @@ void vaw_ws_launch(int ntw, int epi, int b_kmajor, int64_t M, int64_t N, int64_t
 #define WS_CASE(EPIv)                                                                                   \
     case EPIv:                                                                                          \
         if (ntw == 4) ws_launch_one<true, 4, EPIv>(a, lda, b, ldb, nk, tiles_m, tiles_n, grid, e, s);   \
+        else if (ws_loaders8()) ws_launch_one<true, 3, EPIv, 8>(a, lda, b, ldb, nk, tiles_m, tiles_n, grid, e, s);   \
         else ws_launch_one<true, 3, EPIv>(a, lda, b, ldb, nk, tiles_m, tiles_n, grid, e, s);            \
         break
     switch (epi) {

@@ -34,8 +34,8 @@ template <int N> __device__ __forceinline__ void ws_vmwait() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <bool BKM, int NTW, int EPI>
-__global__ void __launch_bounds__(768)
+template <bool BKM, int NTW, int EPI, int NLW = 4>      // NLW loader waves: 4 (12 waves, <= 168 registers) or 8 (16 waves, <= 128 registers: NTW = 3 only)
+__global__ void __launch_bounds__(512 + 64 * NLW)
 gemm_ws_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb, int nk, int tiles_m, int tiles_n,
                EpiDev e) {
     using Cfg = WsCfg<NTW>;
@@ -69,13 +69,14 @@ gemm_ws_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
         __amdgpu_buffer_rsrc_t rs_a = epi_rsrc(A), rs_b = epi_rsrc(B);
         unsigned so_a = 0, so_b = 0;
         const unsigned step_a = 128u, step_b = BKM ? 128u : (unsigned)(64 * ldb * 2);
+        constexpr int NH = 8 / NLW;              // eighths of a part per loader wave
         unsigned off_a[2][2], off_b[NTW][2];
         auto open = [&]() __attribute__((always_inline)) {
             so_a = so_b = 0;
             iss_kt = 0;
             if (iss_item >= n_items) {           // past the last item: out-of-range pieces (zeros into a stage nobody reads)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
+                for (int h = 0; h < NH; ++h) {
 #pragma unroll
                     for (int p = 0; p < 2; ++p) off_a[p][h] = EPI_OOB;
 #pragma unroll
@@ -91,8 +92,8 @@ gemm_ws_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
             rs_a = epi_rsrc(A + m0 * lda);
             rs_b = epi_rsrc(BKM ? B + n0 * ldb : B + n0);
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int w8 = 2 * lw + h;       // which eighth of a part (8 rows of 128 bytes) this instruction fills
+            for (int h = 0; h < NH; ++h) {
+                const int w8 = NH * lw + h;      // which eighth of a part (8 rows of 128 bytes) this instruction fills
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {    // A part p: rows {32 p ..} and {64 + 32 p ..} of the 128-row tile
                     const int r = 8 * w8 + (lane >> 3);
@@ -108,8 +109,8 @@ gemm_ws_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
         auto issue_set = [&]() __attribute__((always_inline)) {
             char* dst = smem + iss_stage * Cfg::stage_bytes;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int w8 = 2 * lw + h;
+            for (int h = 0; h < NH; ++h) {
+                const int w8 = NH * lw + h;
 #pragma unroll
                 for (int p = 0; p < NTW; ++p) p8_dma16(rs_b, dst + Cfg::a_bytes + p * P8_PART + w8 * 1024, off_b[p][h], so_b);
 #pragma unroll
@@ -128,7 +129,7 @@ gemm_ws_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
         issue_set();
         for (int it = it0; it < n_items; it += G) {
             for (int kt = 0; kt < nk; ++kt) {
-                ws_vmwait<Cfg::PPS>();           // this wave's pieces of the K tile about to be consumed (younger: the next set)
+                ws_vmwait<Cfg::PPS * NH / 2>();  // this wave's pieces of the K tile about to be consumed (younger: the next set)
                 __builtin_amdgcn_s_barrier();    // ... visible to the consumers; everybody has left the stage of two K tiles ago
                 issue_set();                     // the set two K tiles ahead goes there
             }
@@ -296,14 +297,14 @@ gemm_ws_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
     }
 }
 
-template <bool BKM, int NTW, int EPI>
+template <bool BKM, int NTW, int EPI, int NLW = 4>
 static void ws_launch_one(const bf16_t* a, int64_t lda, const bf16_t* b, int64_t ldb, int nk, int tiles_m, int tiles_n, int grid,
                           const EpiDev& e, hipStream_t s) {
     static bool attr_done = false;
     const int lds = WsCfg<NTW>::lds_bytes;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gemm_ws_kernel<BKM, NTW, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm_ws_kernel<BKM, NTW, EPI, NLW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
-    gemm_ws_kernel<BKM, NTW, EPI><<<grid, 768, lds, s>>>(a, lda, b, ldb, nk, tiles_m, tiles_n, e);
+    gemm_ws_kernel<BKM, NTW, EPI, NLW><<<grid, 512 + 64 * NLW, lds, s>>>(a, lda, b, ldb, nk, tiles_m, tiles_n, e);
 }
