@@ -20,6 +20,11 @@
 #include "gemm_p8_kernel.h"
 
 #define WS_BM 128
+// measurement (make exp XF=-DWS_KROT=1): every workgroup of an XCD walks K from a different starting tile (wrapping round), so
+// that the CUs sharing an L2 do not all ask for the same operand lines at the same moment
+#ifndef WS_KROT
+#define WS_KROT 0
+#endif
 template <int NTW> struct WsCfg {
     static constexpr int BN = 64 * NTW, WN = 16 * NTW;
     static constexpr int LS = 2 + NTW;                       // 8 KiB parts per stage: A parts 0, 1 | B parts 0 .. NTW-1
@@ -71,8 +76,12 @@ gemm_ws_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
         const unsigned step_a = 128u, step_b = BKM ? 128u : (unsigned)(64 * ldb * 2);
         constexpr int NH = 8 / NLW;              // eighths of a part per loader wave
         unsigned off_a[2][2], off_b[NTW][2];
+        const int krot = WS_KROT ? (int)((blockIdx.x >> 3) * 5u % (unsigned)nk) : 0;
+        int kpos = 0;
         auto open = [&]() __attribute__((always_inline)) {
-            so_a = so_b = 0;
+            kpos = krot;
+            so_a = (unsigned)kpos * step_a;
+            so_b = (unsigned)kpos * step_b;
             iss_kt = 0;
             if (iss_item >= n_items) {           // past the last item: out-of-range pieces (zeros into a stage nobody reads)
 #pragma unroll
@@ -119,6 +128,7 @@ gemm_ws_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
             iss_stage = iss_stage == 2 ? 0 : iss_stage + 1;
             so_a += step_a;
             so_b += step_b;
+            if (WS_KROT && ++kpos == nk) { kpos = 0; so_a = so_b = 0; }
             if (++iss_kt == nk) {
                 iss_item += G;
                 open();
