@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Micro-benchmark of vaw_groupnorm_fwd / vaw_groupnorm_bwd (NHWC, 32 groups, SiLU + FiLM) against the HBM roofline.
-Bytes counted: forward = read x twice + write y (3 passes); backward = read dy, x twice + write dx (5 passes)."""
+"""Micro-benchmark of vaw_groupnorm_fwd / vaw_groupnorm_bwd (NHWC, 32 groups, SiLU + FiLM) against the HBM roofline, streaming
+kernels and cooperative single-read kernels (vaw_debug_gn_coop 0 / 1).  The TB/s column prices both at the STREAMING kernels' traffic
+(forward = x twice + y: 3 passes; backward = dy, x twice + dx: 5 passes) so the two lines of a shape compare directly; the
+cooperative kernels move 2 and 3 passes."""
 import os
 import sys
 
@@ -26,7 +28,9 @@ for (B, HW, C) in [(256, 4096, 192), (256, 1024, 384), (256, 256, 576), (256, 64
     bwd = lambda: lib().vaw_groupnorm_bwd(BF16, ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gam), ptr(bet), ptr(film), ptr(film) + 4 * C,
                                           2 * C, 1, None, ptr(dx), ptr(dg), ptr(db), 0.0, ptr(dfilm), ptr(dfilm) + 4 * C, 2 * C, B, HW, C, 32,
                                           ptr(ws), stream_ptr())
-    for fn, nm, passes in ((fwd, "fwd", 3), (bwd, "bwd", 5)):
+    for coop, fn, nm, passes in ((0, fwd, "fwd", 3), (1, fwd, "fwd", 3), (0, bwd, "bwd", 5), (1, bwd, "bwd", 5)):
+        lib().vaw_debug_gn_coop(coop)
+        nm = nm + ("/coop" if coop else "/stream")
         for _ in range(2):
             assert fn() == 0
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -37,4 +41,4 @@ for (B, HW, C) in [(256, 4096, 192), (256, 1024, 384), (256, 256, 576), (256, 64
         e1.record()
         torch.cuda.synchronize()
         us = 1e2 * e0.elapsed_time(e1)
-        print(f"B={B} HW={HW:5d} C={C:4d} {nm} {us:8.1f} us  {passes * M * C * 2 / us / 1e6:6.2f} TB/s over {passes} passes", flush=True)
+        print(f"B={B} HW={HW:5d} C={C:4d} {nm:10s} {us:8.1f} us  {passes * M * C * 2 / us / 1e6:6.2f} TB/s if {passes} passes", flush=True)

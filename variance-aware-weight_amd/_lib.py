@@ -135,6 +135,8 @@ def lib():
         L.vaw_debug_force_generic_gemm.restype = None
         L.vaw_debug_gemm_tile.argtypes = [_i]
         L.vaw_debug_gemm_tile.restype = None
+        L.vaw_debug_gn_coop.argtypes = [_i]
+        L.vaw_debug_gn_coop.restype = None
         L.vaw_p8_set_reserved_cus.argtypes = [_i]
         L.vaw_p8_set_reserved_cus.restype = None
         L.vaw_debug_cu_hog.argtypes = [_i, _i, _p]

@@ -4,6 +4,8 @@
 //   im2col / col2im for conv3x3 pad 1 (round 1: explicit patch matrix, GEMM does the arithmetic)
 //   2x2 average pool, nearest x2 upsample (+ their transposes), channel concat / split, NCHW <-> NHWC
 // All HBM-bound, 4 channels per thread (16 B f32 / 8 B bf16), reductions in a fixed order (no float atomics).
+#include <stdlib.h>
+
 #include "common.h"
 
 static inline int sgrid(int64_t work, int block) {
@@ -25,6 +27,18 @@ static inline int sgrid(int64_t work, int block) {
 //   apply   y = act(GN(x)*gamma+beta [*(1+scale)+shift])    /    dx = rstd*(dn1*gamma - S1/N - xhat*S2/N) (+ dx_add)
 // ---------------------------------------------------------------------------------------------
 #define GN_ROWS 512
+// SiLU and its derivative through v_rcp_f32 (1 ulp) instead of an IEEE division (~10 more instructions per element): the
+// GroupNorm passes are close enough to VALU-bound at 4 waves per SIMD for that to show (GN_FAST_SILU=0: the exact forms)
+#ifndef GN_FAST_SILU
+#define GN_FAST_SILU 1
+#endif
+__device__ __forceinline__ float gn_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float gn_silu(float x) { return GN_FAST_SILU ? x * gn_sigmoid(x) : silu_f(x); }
+__device__ __forceinline__ float gn_silu_grad(float x) {
+    if (!GN_FAST_SILU) return silu_grad_f(x);
+    const float s = gn_sigmoid(x);
+    return s * (1.f + x * (1.f - s));
+}
 
 struct GnQuad {   // per-thread constants for its 4 channels
     f32x4 mu, rs, ga, be, sc, sh;
@@ -110,7 +124,7 @@ gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean, const f
         if (scale) n = n * (1.f + k.sc) + k.sh;
         if (silu) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) n[j] = silu_f(n[j]);
+            for (int j = 0; j < 4; ++j) n[j] = gn_silu(n[j]);
         }
         store4(y + base + (int64_t)r * C, n);
     }
@@ -139,7 +153,7 @@ gn_bwd_sums_kernel(const T* __restrict__ dout, const T* __restrict__ x, const fl
             f32x4 dn2 = load4(dout + base + (int64_t)r * C);
             if (silu) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) dn2[j] *= silu_grad_f(n2[j]);
+                for (int j = 0; j < 4; ++j) dn2[j] *= gn_silu_grad(n2[j]);
             }
             const f32x4 dn1 = scale ? dn2 * (1.f + k.sc) : dn2;
             a += dn1 * xh;
@@ -262,7 +276,7 @@ gn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ x, const f
         f32x4 dn2 = load4(dout + e);
         if (silu) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) dn2[j] *= silu_grad_f(n2[j]);
+            for (int j = 0; j < 4; ++j) dn2[j] *= gn_silu_grad(n2[j]);
         }
         const f32x4 dn1 = scale ? dn2 * (1.f + k.sc) : dn2;
         f32x4 r4 = k.rs * (dn1 * k.ga - t1 - xh * t2);
@@ -270,6 +284,289 @@ gn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ x, const f
         store4(dx + e, r4);
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// The same four passes for bf16 with C % 8 == 0 on a FLAT mapping (the recipe that took the AdamW and row kernels from
+// 4-5 to 5-6.5 TB/s): a thread owns one channel OCTET (16-byte accesses) and every rpi-th row, nt = a multiple of C/8 lanes
+// are live, so one step of a workgroup is nt x 16 CONTIGUOUS bytes; U steps are in flight per lane and stream before the
+// first is consumed; non-temporal accesses for everything that is not read again soon (the forward sums pass leaves x in
+// the caches for the apply pass, which walks the chunks in the opposite order so that it starts on the freshest ones).
+// Chunks (GN_ROWS rows), workspace layouts and the small fold / group kernels are those of the quad-mapped kernels above,
+// which stay for f32, C % 8 != 0 and VAW_GN_FLAT=0.  Backward sums: with d = dout act'(n2) only sd = sum d and
+// sx = sum d (x - mu) are accumulated; A, Bs, DS, DH are formed from them when the chunk's sums are written.
+// ---------------------------------------------------------------------------------------------
+#define GNS_NT 256
+typedef unsigned gns_u32x4 __attribute__((ext_vector_type(4)));
+struct GnsGeom {
+    int C8, nt, rpi, rows;     // rows per chunk
+};
+// chunk rows: GN_ROWS, or less while that leaves fewer than two workgroups per CU (0: use the quad-mapped kernels)
+static inline int gns_rows(int B, int HW) {
+    for (int rows = GN_ROWS; rows >= GN_ROWS / 4; rows /= 2)
+        if ((int64_t)B * ((HW + rows - 1) / rows) >= 512) return rows;
+    return 0;
+}
+static inline GnsGeom gns_geom(int C, int rows) {
+    GnsGeom g;
+    g.C8 = C / 8;
+    g.nt = (GNS_NT / g.C8) * g.C8;
+    g.rpi = g.nt / g.C8;
+    g.rows = rows;
+    return g;
+}
+__device__ __forceinline__ gns_u32x4 gns_ld(const bf16_t* p) { return *reinterpret_cast<const gns_u32x4*>(p); }
+__device__ __forceinline__ gns_u32x4 gns_ld_nt(const bf16_t* p) { return __builtin_nontemporal_load(reinterpret_cast<const gns_u32x4*>(p)); }
+__device__ __forceinline__ void gns_unpack(gns_u32x4 v, float (&f)[8]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        f[2 * k] = __uint_as_float(v[k] << 16);
+        f[2 * k + 1] = __uint_as_float(v[k] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ void gns_st_nt(bf16_t* p, const float (&f)[8]) {
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (bf16_t)f[j];
+    __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(p));
+}
+// per-thread sums of 8 channels x 2 quantities -> per-channel sums of the chunk in chs[2][C] (C <= 2048)
+__device__ __forceinline__ void gns_fold(const float (&s)[8], const float (&q)[8], float* red, float* chs, int C, int rpi, int rl, int c0,
+                                         bool live) {
+    if (live) {
+        float* w0 = red + rl * C + c0;
+        float* w1 = red + (rpi + rl) * C + c0;
+        *reinterpret_cast<f32x4*>(w0) = f32x4{s[0], s[1], s[2], s[3]};
+        *reinterpret_cast<f32x4*>(w0 + 4) = f32x4{s[4], s[5], s[6], s[7]};
+        *reinterpret_cast<f32x4*>(w1) = f32x4{q[0], q[1], q[2], q[3]};
+        *reinterpret_cast<f32x4*>(w1 + 4) = f32x4{q[4], q[5], q[6], q[7]};
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * C; c += GNS_NT) {
+        const int k = c >= C ? 1 : 0, cc = c - k * C;
+        const float* p = red + k * rpi * C + cc;
+        float t = 0.f;
+        for (int r = 0; r < rpi; ++r) t += p[r * C];
+        chs[c] = t;
+    }
+    __syncthreads();
+}
+
+template <int U>
+__global__ void __launch_bounds__(GNS_NT)
+gns_fwd_sums_kernel(const bf16_t* __restrict__ x, int HW, int C, int B, int nchunk, GnsGeom gm, float* __restrict__ part /* [2][nchunk][B][C] */) {
+    __shared__ __attribute__((aligned(16))) float red[2 * GNS_NT * 8];
+    __shared__ float chs[2 * 2048];
+    const int t = threadIdx.x, b = blockIdx.x / nchunk, chunk = blockIdx.x - b * nchunk;
+    const bool live = t < gm.nt;
+    const int oct = live ? t % gm.C8 : 0, rl = live ? t / gm.C8 : 0, c0 = oct * 8;
+    const int r0 = chunk * gm.rows, r1 = r0 + gm.rows < HW ? r0 + gm.rows : HW;
+    const bf16_t* xs = x + (int64_t)b * HW * C;
+    float s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
+    for (int rb = r0 + rl; rb < r1; rb += U * gm.rpi) {
+        gns_u32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int r = rb + u * gm.rpi;
+            r = r < r1 ? r : r1 - 1;
+            v[u] = gns_ld(xs + (unsigned)(r * C + c0));
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool ok = live && rb + u * gm.rpi < r1;
+            float f[8];
+            gns_unpack(v[u], f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float a = ok ? f[j] : 0.f;
+                s[j] += a;
+                q[j] += a * a;
+            }
+        }
+    }
+    gns_fold(s, q, red, chs, C, gm.rpi, rl, c0, live);
+    for (int c = t; c < 2 * C; c += GNS_NT) {
+        const int k = c >= C ? 1 : 0, cc = c - k * C;
+        part[(((int64_t)k * nchunk + chunk) * B + b) * C + cc] = chs[c];
+    }
+}
+
+template <int U, bool SILU, bool FILM>
+__global__ void __launch_bounds__(GNS_NT)
+gns_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                 const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ scale,
+                 const float* __restrict__ shift, int64_t film_ld, bf16_t* __restrict__ y, int HW, int C, int G, int nchunk, GnsGeom gm) {
+    const int item = gridDim.x - 1 - blockIdx.x;             // the sums pass went 0 .. n-1: start on what it read last
+    const int t = threadIdx.x, b = item / nchunk, chunk = item - b * nchunk;
+    if (t >= gm.nt) return;
+    const int oct = t % gm.C8, rl = t / gm.C8, c0 = oct * 8, cg = C / G;
+    const int r0 = chunk * gm.rows, r1 = r0 + gm.rows < HW ? r0 + gm.rows : HW;
+    const bf16_t* xs = x + (int64_t)b * HW * C;
+    bf16_t* ys = y + (int64_t)b * HW * C;
+    float a1[8], b1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int g = (c0 + j) / cg;
+        const float mu = mean[b * G + g], rs = rstd[b * G + g], ga = gamma[c0 + j];
+        a1[j] = rs * ga;
+        b1[j] = beta[c0 + j] - mu * rs * ga;
+        if (FILM) {                                          // (x a + b)(1 + scale) + shift as one multiply-add
+            const float sc = 1.f + scale[(int64_t)b * film_ld + c0 + j];
+            a1[j] *= sc;
+            b1[j] = b1[j] * sc + shift[(int64_t)b * film_ld + c0 + j];
+        }
+    }
+    for (int rb = r0 + rl; rb < r1; rb += U * gm.rpi) {
+        gns_u32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int r = rb + u * gm.rpi;
+            r = r < r1 ? r : r1 - 1;
+            v[u] = gns_ld_nt(xs + (unsigned)(r * C + c0));
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = rb + u * gm.rpi;
+            float f[8], o[8];
+            gns_unpack(v[u], f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float n = f[j] * a1[j] + b1[j];
+                if (SILU) n = gn_silu(n);
+                o[j] = n;
+            }
+            if (r < r1) gns_st_nt(ys + (unsigned)(r * C + c0), o);
+        }
+    }
+}
+
+// n2 = x P + Q,  P = rstd gamma (1+scale),  Q = (beta - mu rstd gamma)(1+scale) + shift
+template <int U, bool SILU, bool FILM>
+__global__ void __launch_bounds__(GNS_NT)
+gns_bwd_sums_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ x, const float* __restrict__ mean,
+                    const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                    const float* __restrict__ scale, const float* __restrict__ shift, int64_t film_ld, int HW, int C, int G, int B,
+                    int nchunk, GnsGeom gm, float* __restrict__ part /* [4][nchunk][B][C] */) {
+    __shared__ __attribute__((aligned(16))) float red[2 * GNS_NT * 8];
+    __shared__ float chs[2 * 2048];
+    const int t = threadIdx.x, b = blockIdx.x / nchunk, chunk = blockIdx.x - b * nchunk;
+    const bool live = t < gm.nt;
+    const int oct = live ? t % gm.C8 : 0, rl = live ? t / gm.C8 : 0, c0 = oct * 8, cg = C / G;
+    const int r0 = chunk * gm.rows, r1 = r0 + gm.rows < HW ? r0 + gm.rows : HW;
+    const bf16_t *xs = x + (int64_t)b * HW * C, *ds = dout + (int64_t)b * HW * C;
+    float P[8], Q[8], mu[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int g = (c0 + j) / cg;
+        mu[j] = mean[b * G + g];
+        const float rs = rstd[b * G + g], ga = gamma[c0 + j];
+        const float s1 = FILM ? 1.f + scale[(int64_t)b * film_ld + c0 + j] : 1.f;
+        P[j] = rs * ga * s1;
+        Q[j] = (beta[c0 + j] - mu[j] * rs * ga) * s1 + (FILM ? shift[(int64_t)b * film_ld + c0 + j] : 0.f);
+    }
+    float sd[8], sx[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sd[j] = sx[j] = 0.f;
+    for (int rb = r0 + rl; rb < r1; rb += U * gm.rpi) {
+        gns_u32x4 xv[U], dv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int r = rb + u * gm.rpi;
+            r = r < r1 ? r : r1 - 1;
+            xv[u] = gns_ld(xs + (unsigned)(r * C + c0));
+            dv[u] = gns_ld(ds + (unsigned)(r * C + c0));
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool ok = live && rb + u * gm.rpi < r1;
+            float xf[8], df[8];
+            gns_unpack(xv[u], xf);
+            gns_unpack(dv[u], df);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float d = df[j];
+                if (SILU) d *= gn_silu_grad(xf[j] * P[j] + Q[j]);
+                d = ok ? d : 0.f;
+                sd[j] += d;
+                sx[j] += d * (xf[j] - mu[j]);
+            }
+        }
+    }
+    gns_fold(sd, sx, red, chs, C, gm.rpi, rl, c0, live);
+    // A = (1+scale) rstd sx,  Bs = (1+scale) sd,  DS = gamma rstd sx + beta sd,  DH = sd
+    const int64_t plane = (int64_t)nchunk * B * C;
+    for (int c = t; c < C; c += GNS_NT) {
+        const float d0 = chs[c], x0 = chs[C + c];
+        const float rs = rstd[b * G + c / cg];
+        const float s1 = FILM ? 1.f + scale[(int64_t)b * film_ld + c] : 1.f;
+        float* o = part + ((int64_t)chunk * B + b) * C + c;
+        o[0] = s1 * (rs * x0);
+        o[plane] = s1 * d0;
+        o[2 * plane] = gamma[c] * (rs * x0) + beta[c] * d0;
+        o[3 * plane] = d0;
+    }
+}
+
+// dx = rstd (dn1 gamma - S1/N - xhat S2/N) + dx_add  =  P d - K3 x - K2 (+ dx_add),  K3 = rstd^2 S2/N,  K2 = rstd S1/N - K3 mu
+template <int U, bool SILU, bool FILM, bool ADD>
+__global__ void __launch_bounds__(GNS_NT)
+gns_bwd_apply_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ x, const float* __restrict__ mean,
+                     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                     const float* __restrict__ scale, const float* __restrict__ shift, int64_t film_ld,
+                     const float* __restrict__ S1, const float* __restrict__ S2, const bf16_t* __restrict__ dx_add,
+                     bf16_t* __restrict__ dx, int HW, int C, int G, int nchunk, GnsGeom gm) {
+    const int item = gridDim.x - 1 - blockIdx.x;             // the sums pass went 0 .. n-1: start on what it read last
+    const int t = threadIdx.x, b = item / nchunk, chunk = item - b * nchunk;
+    if (t >= gm.nt) return;
+    const int oct = t % gm.C8, rl = t / gm.C8, c0 = oct * 8, cg = C / G;
+    const int r0 = chunk * gm.rows, r1 = r0 + gm.rows < HW ? r0 + gm.rows : HW;
+    const int64_t sample = (int64_t)b * HW * C;
+    const bf16_t *xs = x + sample, *ds = dout + sample, *as = dx_add + sample;
+    bf16_t* os = dx + sample;
+    const float invn = 1.f / ((float)cg * HW);
+    float P[8], Q[8], K2[8], K3[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int g = (c0 + j) / cg;
+        const float mu = mean[b * G + g], rs = rstd[b * G + g], ga = gamma[c0 + j];
+        const float s1 = FILM ? 1.f + scale[(int64_t)b * film_ld + c0 + j] : 1.f;
+        P[j] = rs * ga * s1;
+        Q[j] = (beta[c0 + j] - mu * rs * ga) * s1 + (FILM ? shift[(int64_t)b * film_ld + c0 + j] : 0.f);
+        K3[j] = rs * rs * (S2[b * G + g] * invn);
+        K2[j] = rs * (S1[b * G + g] * invn) - K3[j] * mu;
+    }
+    for (int rb = r0 + rl; rb < r1; rb += U * gm.rpi) {
+        gns_u32x4 xv[U], dv[U], av[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int r = rb + u * gm.rpi;
+            r = r < r1 ? r : r1 - 1;
+            xv[u] = gns_ld_nt(xs + (unsigned)(r * C + c0));
+            dv[u] = gns_ld_nt(ds + (unsigned)(r * C + c0));
+            if (ADD) av[u] = gns_ld_nt(as + (unsigned)(r * C + c0));
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = rb + u * gm.rpi;
+            float xf[8], df[8], af[8], o[8];
+            gns_unpack(xv[u], xf);
+            gns_unpack(dv[u], df);
+            if (ADD) gns_unpack(av[u], af);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float d = df[j];
+                if (SILU) d *= gn_silu_grad(xf[j] * P[j] + Q[j]);
+                float v = P[j] * d - K3[j] * xf[j] - K2[j];
+                if (ADD) v += af[j];
+                o[j] = v;
+            }
+            if (r < r1) gns_st_nt(os + (unsigned)(r * C + c0), o);
+        }
+    }
+}
+
+#include "groupnorm_coop.h"
 
 // ---------------------------------------------------------------------------------------------
 // conv3x3 (stride 1, pad 1) patch matrix: col[m, tap*C + c] = x[pixel(m) + (tap/3-1, tap%3-1), c]  (0 outside)
@@ -677,7 +974,107 @@ __global__ void layout_kernel(const float* __restrict__ nchw_in, float* __restri
 // ---------------------------------------------------------------------------------------------
 static inline int gn_chunks(int HW) { return (HW + GN_ROWS - 1) / GN_ROWS; }
 extern "C" int64_t vaw_groupnorm_workspace_floats(int B, int HW, int C) {
-    return (int64_t)4 * gn_chunks(HW) * B * C + (int64_t)4 * B * C + 2 * (int64_t)B * 64 + 64;
+    const int64_t streaming = (int64_t)4 * ceil_div(HW, GN_ROWS / 4) * B * C + (int64_t)4 * B * C + 2 * (int64_t)B * 64 + 64;   // the flat kernels' smallest chunks
+    const int64_t coop = gnc_workspace_floats(B, HW, C);
+    return streaming > coop ? streaming : coop;
+}
+// the cooperative single-read kernels (groupnorm_coop.h) unless VAW_GN_COOP=0 or the shape does not fit them
+#if GNC_PROF
+extern "C" int vaw_debug_gnc_prof(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gnc_prof_buf), sizeof(unsigned long long) * n);
+}
+#endif
+static bool gns_ok(vaw_dtype dt, int B, int HW, int C, int G) {
+    static int on = -1;
+    if (on < 0) {
+        const char* v = getenv("VAW_GN_FLAT");
+        on = v ? (atoi(v) != 0) : 1;
+    }
+    return on && dt == VAW_BF16 && C % 8 == 0 && C / 8 <= GNS_NT && C <= 2048 && C % G == 0 && gns_rows(B, HW) > 0 &&
+           (int64_t)B * HW < (1 << 30) && (int64_t)HW * C < ((int64_t)1 << 31);
+}
+static int g_gn_coop = -1;      // -1: VAW_GN_COOP (default off: an experiment, see groupnorm_coop.h); 0 / 1: forced by vaw_debug_gn_coop
+extern "C" void vaw_debug_gn_coop(int mode) { g_gn_coop = mode; }
+static bool gnc_enabled() {
+    static int env = -1;
+    if (env < 0) {
+        const char* v = getenv("VAW_GN_COOP");
+        env = v ? (atoi(v) != 0) : 0;
+    }
+    return g_gn_coop >= 0 ? g_gn_coop != 0 : env != 0;
+}
+template <typename K>
+static int gnc_grid_cached(K kernel, int block, int items) {
+    static int per_block[GNC_NT / 64 + 2] = {0};        // resident workgroups on the chip for this kernel at this block size
+    int& g = per_block[block / 64];
+    if (!g) g = gnc_grid((const void*)kernel, block, 1 << 30);
+    return g < items ? g : items;
+}
+#define GNC_FWD_CASE(S, F)                                                                                                       \
+    if ((silu != 0) == S && (scale != nullptr) == F) {                                                                           \
+        grid = gnc_grid_cached(gnc_fwd_kernel<GNC_NV_FWD, S, F>, block, gm.items);                                                           \
+        if (grid >= gm.nch && gm.nch <= 64) {                                                                                      \
+            if (hipMemsetAsync(part1, 0xff, sizeof(float) * B * gm.nch * 128, s) != hipSuccess) return -1;                       \
+            gnc_fwd_kernel<GNC_NV_FWD, S, F><<<grid, block, 0, s>>>((const bf16_t*)x, gamma, beta, scale, shift, film_ld, (bf16_t*)y, mean,  \
+                                                        rstd, HW, C, G, eps, gm, part1, counter);                                \
+            return 1;                                                                                                            \
+        }                                                                                                                        \
+        return 0;                                                                                                                \
+    }
+// 1 = launched, 0 = not eligible (caller takes the streaming kernels), -1 = error
+static int gnc_try_fwd(vaw_dtype dt, const void* x, const float* gamma, const float* beta, const float* scale, const float* shift,
+                       int64_t film_ld, int silu, void* y, float* mean, float* rstd, int B, int HW, int C, int G, float eps,
+                       float* workspace, hipStream_t s) {
+    if (!gnc_enabled() || !gnc_shape_ok(dt, B, HW, C, G)) return 0;
+    const GncGeom gm = gnc_geom(B, HW, C, GNC_NV_FWD);
+    const int block = GNC_NT + 64;                       // 8 data waves + the sync wave
+    float* part1 = workspace;
+    unsigned* counter = reinterpret_cast<unsigned*>(workspace + (int64_t)B * gm.nch * 128);
+    int grid = 0;
+    GNC_FWD_CASE(true, true)
+    GNC_FWD_CASE(true, false)
+    GNC_FWD_CASE(false, true)
+    GNC_FWD_CASE(false, false)
+    return 0;
+}
+#define GNC_BWD_CASE(S, F, A)                                                                                                    \
+    if ((silu != 0) == S && (scale != nullptr) == F && (dx_add != nullptr) == A) {                                               \
+        grid = gnc_grid_cached(gnc_bwd_kernel<GNC_NV_BWD, S, F, A>, block, gm.items);                                                        \
+        if (grid < gm.nch || gm.nch > 64) return 0;                                                                              \
+        if (gm.nch > 1 && hipMemsetAsync(counter, 0, sizeof(unsigned) * B, s) != hipSuccess) return -1;                          \
+        gnc_bwd_kernel<GNC_NV_BWD, S, F, A><<<grid, block, 0, s>>>((const bf16_t*)dout, (const bf16_t*)x, mean, rstd, gamma, beta, scale,    \
+                                                       shift, film_ld, (const bf16_t*)dx_add, (bf16_t*)dx, HW, C, G, gm, part1,  \
+                                                       part2, counter);                                                          \
+        launched = true;                                                                                                         \
+    }
+static int gnc_try_bwd(vaw_dtype dt, const void* dout, const void* x, const float* mean, const float* rstd, const float* gamma,
+                       const float* beta, const float* scale, const float* shift, int64_t film_ld, int silu, const void* dx_add,
+                       void* dx, float* dgamma, float* dbeta, float grad_beta, float* dscale, float* dshift, int64_t dfilm_ld, int B,
+                       int HW, int C, int G, float* workspace, hipStream_t s) {
+    if (!gnc_enabled() || !gnc_shape_ok(dt, B, HW, C, G)) return 0;
+    const GncGeom gm = gnc_geom(B, HW, C, GNC_NV_BWD);
+    const int block = ((gm.nt + 63) / 64) * 64;
+    const int64_t BC = (int64_t)B * C;
+    float* part1 = workspace;
+    float* part2 = part1 + (int64_t)B * gm.nch * 128;
+    float* sums = part2 + (int64_t)B * gm.nch * 2 * C;
+    unsigned* counter = reinterpret_cast<unsigned*>(sums + 4 * BC);
+    int grid = 0;
+    bool launched = false;
+    GNC_BWD_CASE(true, true, true)
+    GNC_BWD_CASE(true, true, false)
+    GNC_BWD_CASE(true, false, true)
+    GNC_BWD_CASE(true, false, false)
+    GNC_BWD_CASE(false, true, true)
+    GNC_BWD_CASE(false, true, false)
+    GNC_BWD_CASE(false, false, true)
+    GNC_BWD_CASE(false, false, false)
+    if (!launched) return 0;
+    gnc_bwd_fold_kernel<<<ceil_div(BC, 256), 256, 0, s>>>(part2, gm.nch, B, C, G, rstd, gamma, beta, scale, film_ld, sums);
+    const int nb2 = (int)ceil_div(C, 16), nb3 = scale && dscale ? (int)ceil_div(BC, 256) : 0;
+    gn_bwd_group_kernel<<<nb2 + nb3, 256, 0, s>>>(sums, gamma, B, C, G, nullptr, nullptr, dgamma, dbeta, grad_beta,
+                                                   scale ? dscale : nullptr, dshift, dfilm_ld, 0, nb2);
+    return 1;
 }
 
 extern "C" int vaw_groupnorm_fwd(vaw_dtype dt, const void* x, const float* gamma, const float* beta, const float* scale,
@@ -688,6 +1085,30 @@ extern "C" int vaw_groupnorm_fwd(vaw_dtype dt, const void* x, const float* gamma
     VAW_CHECK_ARG((scale == nullptr) == (shift == nullptr), "groupnorm_fwd: scale and shift go together");
     VAW_CHECK_ARG(!scale || film_ld % 4 == 0, "groupnorm_fwd: film_ld must be a multiple of 4");
     hipStream_t s = (hipStream_t)stream;
+    const int coop = gnc_try_fwd(dt, x, gamma, beta, scale, shift, film_ld, silu, y, mean, rstd, B, HW, C, G, eps, workspace, s);
+    VAW_CHECK_ARG(coop >= 0, "groupnorm_fwd: counter reset failed");
+    if (coop == 1) {
+        VAW_CHECK_LAUNCH("groupnorm_fwd");
+        return VAW_OK;
+    }
+    if (gns_ok(dt, B, HW, C, G)) {
+        const GnsGeom gm = gns_geom(C, gns_rows(B, HW));
+        const int nch = ceil_div(HW, gm.rows);
+        const bf16_t* xb = (const bf16_t*)x;
+        bf16_t* yb = (bf16_t*)y;
+        gns_fwd_sums_kernel<8><<<B * nch, GNS_NT, 0, s>>>(xb, HW, C, B, nch, gm, workspace);
+        gn_group_stats_kernel<<<ceil_div(B * G, 128), 128, 0, s>>>(workspace, nch, B, C, G, HW, eps, mean, rstd);
+#define GNS_APPLY(S, F)                                                                                                              \
+    if ((silu != 0) == S && (scale != nullptr) == F)                                                                                 \
+        gns_apply_kernel<4, S, F><<<B * nch, GNS_NT, 0, s>>>(xb, mean, rstd, gamma, beta, scale, shift, film_ld, yb, HW, C, G, nch, gm);
+        GNS_APPLY(true, true)
+        GNS_APPLY(true, false)
+        GNS_APPLY(false, true)
+        GNS_APPLY(false, false)
+#undef GNS_APPLY
+        VAW_CHECK_LAUNCH("groupnorm_fwd");
+        return VAW_OK;
+    }
     const int nch = gn_chunks(HW);
     dim3 grid(ceil_div(C, 64), B, nch);
     BY_DTYPE(dt, (gn_fwd_sums_kernel<T><<<grid, 256, 0, s>>>((const T*)x, HW, C, B, nch, workspace)));
@@ -706,18 +1127,56 @@ extern "C" int vaw_groupnorm_bwd(vaw_dtype dt, const void* dout, const void* x, 
                   "groupnorm_bwd: bad sizes");
     VAW_CHECK_ARG(!scale || (shift && dscale && dshift && film_ld % 4 == 0), "groupnorm_bwd: FiLM needs shift, dscale, dshift");
     hipStream_t s = (hipStream_t)stream;
-    const int nch = gn_chunks(HW);
+    const int coop = gnc_try_bwd(dt, dout, x, mean, rstd, gamma, beta, scale, shift, film_ld, silu, dx_add, dx, dgamma, dbeta, grad_beta,
+                                 dscale, dshift, dfilm_ld, B, HW, C, G, workspace, s);
+    VAW_CHECK_ARG(coop >= 0, "groupnorm_bwd: counter reset failed");
+    if (coop == 1) {
+        VAW_CHECK_LAUNCH("groupnorm_bwd");
+        return VAW_OK;
+    }
+    const bool flat = gns_ok(dt, B, HW, C, G);
+    const GnsGeom gm = gns_geom(flat ? C : 8, flat ? gns_rows(B, HW) : GN_ROWS);
+    const int nch = ceil_div(HW, gm.rows);
     const int64_t BC = (int64_t)B * C;
     float* part = workspace;
     float* sums = part + 4 * nch * BC;
     float* S1 = sums + 4 * BC;
     float* S2 = S1 + (int64_t)B * G;
     dim3 grid(ceil_div(C, 64), B, nch);
-    BY_DTYPE(dt, (gn_bwd_sums_kernel<T><<<grid, 256, 0, s>>>((const T*)dout, (const T*)x, mean, rstd, gamma, beta, scale, shift, film_ld, silu, HW, C, G, B, nch, part)));
+    const bf16_t *xb = (const bf16_t*)x, *db = (const bf16_t*)dout;
+    if (flat) {
+#define GNS_SUMS(S, F)                                                                                                             \
+    if ((silu != 0) == S && (scale != nullptr) == F)                                                                               \
+        gns_bwd_sums_kernel<4, S, F><<<B * nch, GNS_NT, 0, s>>>(db, xb, mean, rstd, gamma, beta, scale, shift, film_ld, HW, C, G, B, nch, gm, part);
+        GNS_SUMS(true, true)
+        GNS_SUMS(true, false)
+        GNS_SUMS(false, true)
+        GNS_SUMS(false, false)
+#undef GNS_SUMS
+    } else {
+        BY_DTYPE(dt, (gn_bwd_sums_kernel<T><<<grid, 256, 0, s>>>((const T*)dout, (const T*)x, mean, rstd, gamma, beta, scale, shift, film_ld, silu, HW, C, G, B, nch, part)));
+    }
     gn_bwd_fold_kernel<<<ceil_div(4 * BC, 256), 256, 0, s>>>(part, nch, B, C, sums);
     const int nb1 = (int)ceil_div(B * G, 256), nb2 = (int)ceil_div(C, 16), nb3 = scale && dscale ? (int)ceil_div(BC, 256) : 0;
     gn_bwd_group_kernel<<<nb1 + nb2 + nb3, 256, 0, s>>>(sums, gamma, B, C, G, S1, S2, dgamma, dbeta, grad_beta,
                                                          scale ? dscale : nullptr, dshift, dfilm_ld, nb1, nb2);
+    if (flat) {
+#define GNS_BAPPLY(S, F, A)                                                                                                        \
+    if ((silu != 0) == S && (scale != nullptr) == F && (dx_add != nullptr) == A)                                                   \
+        gns_bwd_apply_kernel<4, S, F, A><<<B * nch, GNS_NT, 0, s>>>(db, xb, mean, rstd, gamma, beta, scale, shift, film_ld, S1, S2, \
+                                                                    (const bf16_t*)dx_add, (bf16_t*)dx, HW, C, G, nch, gm);
+        GNS_BAPPLY(true, true, true)
+        GNS_BAPPLY(true, true, false)
+        GNS_BAPPLY(true, false, true)
+        GNS_BAPPLY(true, false, false)
+        GNS_BAPPLY(false, true, true)
+        GNS_BAPPLY(false, true, false)
+        GNS_BAPPLY(false, false, true)
+        GNS_BAPPLY(false, false, false)
+#undef GNS_BAPPLY
+        VAW_CHECK_LAUNCH("groupnorm_bwd");
+        return VAW_OK;
+    }
     BY_DTYPE(dt, (gn_bwd_apply_kernel<T><<<grid, 256, 0, s>>>((const T*)dout, (const T*)x, mean, rstd, gamma, beta, scale, shift, film_ld, silu, S1, S2, (const T*)dx_add, (T*)dx, HW, C, G)));
     VAW_CHECK_LAUNCH("groupnorm_bwd");
     return VAW_OK;
