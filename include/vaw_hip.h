@@ -437,6 +437,26 @@ int vaw_cast_bf16(const float* src, void* dst, int64_t n, vaw_stream stream);
  * collective summed.  src and dst 16-byte aligned. */
 int vaw_uncast_bf16(const void* src, float* dst, int64_t n, float scale, vaw_stream stream);
 
+/* ---- gradient-bucket collectives straight on RCCL ------------------------------------------------
+ * Replaces the bucket all-reduce torch DDP does for the reference (main.py:347; process group set up in tools/dist_util.py:55).
+ * One communicator per process (= per GPU) with a side HIP stream of its own; RCCL is opened with dlopen at the first call
+ * (VAW_ERR_UNSUPPORTED when the box has none), so the rest of the library never depends on it.
+ *   vaw_comm_unique_id(out)           rank 0: 128 opaque bytes to hand to every rank by any host channel
+ *   vaw_comm_init(id, rank, world)    every rank (collective); vaw_comm_world() = 0 before it; vaw_comm_destroy() ends it
+ *   vaw_allreduce_bucket_start        buf[0..count) <- MEAN over ranks, in place, ordered behind everything enqueued on `stream`
+ *   vaw_reduce_scatter_bucket_start   rank r's chunk (count/world elements at buf + r*chunk) <- mean of that chunk (ZeRO-1 form)
+ *   vaw_allgather_bucket_start        every rank's chunk of buf -> all ranks, in place
+ *   vaw_allreduce_bucket_wait         `stream` waits for every collective started so far; the host never blocks
+ * dt = VAW_F32 or VAW_BF16 (the wire type).  Not capturable into a hipGraph. */
+int vaw_comm_unique_id(void* out128);
+int vaw_comm_init(const void* id128, int rank, int world);
+int vaw_comm_world(void);
+int vaw_comm_destroy(void);
+int vaw_allreduce_bucket_start(void* buf, int64_t count, vaw_dtype dt, vaw_stream stream);
+int vaw_reduce_scatter_bucket_start(void* buf, int64_t count, vaw_dtype dt, vaw_stream stream);
+int vaw_allgather_bucket_start(void* buf, int64_t count, vaw_dtype dt, vaw_stream stream);
+int vaw_allreduce_bucket_wait(vaw_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -91,6 +91,11 @@ def _worker(rank, world, port, q):
         assert torch.allclose(m.b.bias.grad, torch.full_like(m.b.bias, mean))
         with pytest.raises(ValueError):
             vaw_amd.DistributedDataParallel(m, broadcast=False, bucket_dtype="fp8")
+        # the library's own RCCL communicator needs a GPU and an RCCL process group: refused here, not silently torch.distributed
+        with pytest.raises(ValueError, match="RCCL"):
+            vaw_amd.DistributedDataParallel(m, broadcast=False, collectives="direct")
+        with pytest.raises(ValueError, match="collectives"):
+            vaw_amd.DistributedDataParallel(m, broadcast=False, collectives="mpi")
         del ddp16
         # loss-aware sampler: ranks hold different numbers of (t, loss) pairs; histories must end identical
         s = vaw_amd.create_named_schedule_sampler("loss-second-moment", SimpleNamespace(num_timesteps=6))

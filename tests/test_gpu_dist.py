@@ -219,3 +219,67 @@ def test_sharded_optimizer_bf16_mode_matches_unsharded_bitwise():
         for a, b in zip(out[False][rank][0], out[True][rank][0]):
             assert (a == b).all(), (rank, a, b)
         assert (out[False][rank][1] == out[True][rank][1]).all()
+
+
+def _direct_world1_worker(q):
+    """Runs in a child process: the library's RCCL communicator lives for the life of a process."""
+    try:
+        import ctypes
+        sys.path.insert(0, REPO)
+        import vaw_amd  # noqa: F401
+        from vaw_amd import _lib as L
+        lib = L.lib()
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(0)
+        buf = torch.ones(1024, device=dev)
+        # before vaw_comm_init every data call is refused, loudly
+        assert lib.vaw_comm_world() == 0
+        assert lib.vaw_allreduce_bucket_start(L.ptr(buf), buf.numel(), L.F32, L.stream_ptr()) != 0
+        assert b"no communicator" in lib.vaw_last_error_string()
+        ident = (ctypes.c_ubyte * 128)()
+        L.check(lib.vaw_comm_unique_id(ident), "unique_id")
+        L.check(lib.vaw_comm_init(ident, 0, 1), "comm_init")
+        assert lib.vaw_comm_world() == 1
+        assert lib.vaw_comm_init(ident, 0, 1) != 0                     # one communicator per process
+        g = torch.Generator().manual_seed(3)
+        for dt, code in ((torch.float32, L.F32), (torch.bfloat16, L.BF16)):
+            n = 3 * 1024 * 1024 + 8
+            want = torch.randn(n, generator=g).to(dt)
+            x = torch.zeros(n, device=dev, dtype=dt)
+            big = torch.randn(4096, 4096, device=dev)
+            for _ in range(4):
+                big = big @ big * 1e-3                                   # keeps the compute stream busy in front of the bucket's producer
+            x.copy_(want.to(dev), non_blocking=True)                    # the "last wgrad kernel" of the bucket, on the current stream
+            L.check(lib.vaw_allreduce_bucket_start(L.ptr(x), n, code, L.stream_ptr()), "allreduce")
+            L.check(lib.vaw_allreduce_bucket_wait(L.stream_ptr()), "wait")
+            got = x.clone()                                             # current stream: ordered behind the collective by the wait
+            torch.cuda.synchronize()
+            assert torch.equal(got.cpu(), want), dt                     # mean over one rank: the bucket itself, to the bit
+            y = x.clone()
+            L.check(lib.vaw_reduce_scatter_bucket_start(L.ptr(y), n, code, L.stream_ptr()), "reduce_scatter")
+            L.check(lib.vaw_allgather_bucket_start(L.ptr(y), n, code, L.stream_ptr()), "allgather")
+            L.check(lib.vaw_allreduce_bucket_wait(L.stream_ptr()), "wait")
+            torch.cuda.synchronize()
+            assert torch.equal(y.cpu(), want), dt
+        assert lib.vaw_reduce_scatter_bucket_start(None, 8, L.F32, L.stream_ptr()) != 0
+        L.check(lib.vaw_comm_destroy(), "comm_destroy")
+        assert lib.vaw_comm_world() == 0
+        q.put("ok")
+    except Exception:
+        q.put(traceback.format_exc())
+
+
+@pytest.mark.gpu
+def test_direct_rccl_bucket_collectives_on_one_rank():
+    """vaw_allreduce_bucket_start / _wait (csrc/collective.hip) on the only world size a one-GPU box offers: the
+    communicator comes up from its own unique id, a bucket produced on the compute stream is reduced on the library's side stream
+    behind it and read back behind the wait (mean over one rank = the bucket, bit for bit, f32 and bf16 wire types), the ZeRO pair
+    reduce-scatter + all-gather round-trips, and every call without a communicator or with a bad bucket is refused with a message."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_direct_world1_worker, args=(q,))
+    p.start()
+    p.join(300)
+    assert not p.is_alive()
+    res = q.get(timeout=10)
+    assert res == "ok", res

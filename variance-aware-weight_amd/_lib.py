@@ -54,6 +54,14 @@ _PROTOS = {
     "vaw_attn_fwd": [_i, C.POINTER(AttnDesc), _p, _p, _p, _p, _p, _p],
     "vaw_attn_bwd": [_i, C.POINTER(AttnDesc), _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "vaw_attn_bwd_colsum": [_i, C.POINTER(AttnDesc), _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, C.POINTER(C.c_int64), _p],
+    "vaw_comm_unique_id": [_p],
+    "vaw_comm_init": [_p, _i, _i],
+    "vaw_comm_world": [],
+    "vaw_comm_destroy": [],
+    "vaw_allreduce_bucket_start": [_p, _l, _i, _p],
+    "vaw_reduce_scatter_bucket_start": [_p, _l, _i, _p],
+    "vaw_allgather_bucket_start": [_p, _l, _i, _p],
+    "vaw_allreduce_bucket_wait": [_p],
     "vaw_groupnorm_fwd": [_i, _p, _p, _p, _p, _p, _l, _i, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p],
     "vaw_groupnorm_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _l, _i, _p, _p, _p, _p, _f, _p, _p, _l, _i, _i, _i, _i, _p, _p],
     "vaw_im2col3x3": [_i, _p, _p, _i, _i, _i, _i, _p],
@@ -135,8 +143,9 @@ def lib():
         L.vaw_debug_force_generic_gemm.restype = None
         L.vaw_debug_gemm_tile.argtypes = [_i]
         L.vaw_debug_gemm_tile.restype = None
-        L.vaw_debug_gn_coop.argtypes = [_i]
-        L.vaw_debug_gn_coop.restype = None
+        if hasattr(L, "vaw_debug_gn_coop"):              # absent from older measurement builds loaded through VAW_HIP_LIB
+            L.vaw_debug_gn_coop.argtypes = [_i]
+            L.vaw_debug_gn_coop.restype = None
         L.vaw_p8_set_reserved_cus.argtypes = [_i]
         L.vaw_p8_set_reserved_cus.restype = None
         L.vaw_debug_cu_hog.argtypes = [_i, _i, _p]

@@ -27,7 +27,7 @@ class DistributedDataParallel(nn.Module):
     in parity runs."""
 
     def __init__(self, module, device_ids=None, output_device=None, process_group=None, broadcast=True, bucket_dtype="f32",
-                 shard_optimizer=False):
+                 shard_optimizer=False, collectives="torch"):
         super().__init__()
         if not isinstance(module, FlatModule):
             raise TypeError("vaw_amd.DistributedDataParallel wraps FlatModule denoisers (e.g. vaw_amd.DiT)")
@@ -35,6 +35,10 @@ class DistributedDataParallel(nn.Module):
             raise RuntimeError("init the process group first (vaw_amd.dist_util.setup_dist)")
         if bucket_dtype not in ("f32", "bf16"):
             raise ValueError("bucket_dtype must be 'f32' or 'bf16'")
+        if collectives not in ("torch", "direct"):
+            raise ValueError("collectives must be 'torch' (torch.distributed) or 'direct' (the library's own RCCL communicator)")
+        if collectives == "direct" and shard_optimizer:
+            raise ValueError("collectives='direct' covers the bucket all-reduce; the sharded optimizer's collectives go through torch.distributed")
         self.module = module
         self.pg = process_group
         self.world = dist.get_world_size(process_group)
@@ -44,6 +48,14 @@ class DistributedDataParallel(nn.Module):
         self._cuda = module._flat.is_cuda
         self._comm = torch.cuda.Stream() if self._cuda else None
         self._backend_avg = dist.get_backend(process_group) == "nccl"     # RCCL has ReduceOp.AVG; gloo does not
+        # collectives="direct": the bucket all-reduce is vaw_allreduce_bucket_start / _wait (csrc/collective.hip: the library's own
+        # RCCL communicator and side stream, no torch.distributed on the data path); the process group only carries the 128-byte
+        # communicator id at start-up.  Off by default: without a multi-GPU node it has run at world size 1 only.
+        self._direct = collectives == "direct"
+        if self._direct:
+            if not (self._cuda and self._backend_avg):
+                raise ValueError("collectives='direct' needs the denoiser on a GPU and an RCCL ('nccl') process group")
+            self._init_direct()
         self._wire = None
         if bucket_dtype == "bf16":
             self._wire = torch.empty(module._flat_n_train, device=module._flat.device, dtype=torch.bfloat16)
@@ -156,9 +168,44 @@ class DistributedDataParallel(nn.Module):
         else:
             g.copy_(w.float() * scale)
 
+    def _init_direct(self):
+        """Every rank joins the library's RCCL communicator; rank 0's id travels over the process group."""
+        import ctypes
+
+        from . import _lib as L
+        lib = L.lib()
+        if lib.vaw_comm_world() == self.world:
+            return                                              # (one communicator per process: a second wrapper shares it)
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if self.rank_of_group() == 0:
+            raw = (ctypes.c_ubyte * 128)()
+            L.check(lib.vaw_comm_unique_id(raw), "comm_unique_id")
+            ident = torch.tensor(list(raw), dtype=torch.uint8)
+        ident = ident.to(self.module._flat.device)
+        dist.broadcast(ident, src=0, group=self.pg)
+        raw = (ctypes.c_ubyte * 128)(*ident.cpu().tolist())
+        if lib.vaw_comm_world():
+            L.check(lib.vaw_comm_destroy(), "comm_destroy")
+        L.check(lib.vaw_comm_init(raw, self.rank_of_group(), self.world), "comm_init")
+
+    def rank_of_group(self):
+        return dist.get_rank(self.pg)
+
+    class _DirectWork:
+        """What `_retire` waits on in direct mode: the current stream joins the library's collective stream."""
+
+        def wait(self):
+            from . import _lib as L
+            L.check(L.lib().vaw_allreduce_bucket_wait(L.stream_ptr()), "allreduce_bucket_wait")
+
     def _reduce(self, g, buf, op):
         """The bucket's collective.  -> (work, the f32 gradient range the result belongs to, the buffer it arrives in).
         all-reduce: the whole bucket; shard_optimizer: reduce-scatter, this rank's chunk of the bucket only."""
+        if self._direct:
+            from . import _lib as L
+            dt = L.BF16 if buf.dtype == torch.bfloat16 else L.F32
+            L.check(L.lib().vaw_allreduce_bucket_start(L.ptr(buf), buf.numel(), dt, L.stream_ptr()), "allreduce_bucket_start")
+            return self._DirectWork(), g, buf
         if not self.shard_optimizer:
             return dist.all_reduce(buf, op=op, group=self.pg, async_op=True), g, buf
         c = g.numel() // self.world
