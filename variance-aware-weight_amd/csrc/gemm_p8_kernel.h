@@ -83,6 +83,9 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 #ifndef P8_NOBR
 #define P8_NOBR 1
 #endif
+#ifndef P8_NOBR_CONV3
+#define P8_NOBR_CONV3 1
+#endif
 #define P8_BM 256
 #define P8_PART 8192
 #define P8_EPI_BYTES 32768
@@ -220,7 +223,7 @@ gemm_p8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
     static_assert(CONV == 0 || (CONV == 1 && AK && BKM) || (CONV == 2 && AK && !BKM) || (CONV == 3 && !AK && !BKM), "conv layouts");
     using Cfg = P8Cfg<NTW>;
     constexpr int LS = 4 + NTW;                                  // DMA pieces per wave and K tile
-    constexpr bool NOBR = P8_NOBR != 0 && CONV != 3;             // (the transposed conv weight gradient spills 24 bytes with it)
+    constexpr bool NOBR = P8_NOBR != 0 && (CONV != 3 || (P8_NOBR_CONV3 != 0 && NTW == 3));   // (the 256-column transposed conv weight gradient spills with it)
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A parts 0-3 | B parts] | 8 x 4 KiB epilogue images
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
