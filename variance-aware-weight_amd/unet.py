@@ -211,6 +211,7 @@ class UNetModel(FlatModule):
         # order and shapes the reference's CPU run draws them (parity runs; set by Trainer from args.cpu_rng); False = device RNG
         self.host_dropout_rng = False
         self.grad_ready_hook = None
+        self._pend_wgrad, self._wgrad_groups, self._grouped_wgrad = {}, {}, None
 
     # ---- flat storage -----------------------------------------------------------------------
     @property
@@ -389,14 +390,20 @@ class UNetModel(FlatModule):
 
         def bw():
             dy = y.grad
-            # weight gradient; the bias gradient (row sums of dy^T) rides on the same launch
-            ops.gemm(dt, 0, 0, Co, Ci, M, ptr(dy), Co, ptr(a.t), Ci, self._g(wname), Ci, beta=self._beta, out_f32=True,
-                     rowsum_a_out=self._g(bname), rowsum_a_beta=self._beta)
+            deferred = self._defer_wgrad(M, Co, Ci, dy, a.t)
+            if deferred:
+                # deferred: one grouped launch per stage and pixel count (_flush_wgrads); the bias gradient now
+                self._pend_wgrad.setdefault(M, []).append((dy, a.t, self._g(wname), Co, Ci))
+                ops.colsum(dt, ptr(dy), M, Co, Co, self._g(bname), self._beta, device=self._flat.device)
+            else:
+                # weight gradient; the bias gradient (row sums of dy^T) rides on the same launch
+                ops.gemm(dt, 0, 0, Co, Ci, M, ptr(dy), Co, ptr(a.t), Ci, self._g(wname), Ci, beta=self._beta, out_f32=True,
+                         rowsum_a_out=self._g(bname), rowsum_a_beta=self._beta)
             dx = self._new(M, Ci)
             ops.gemm(dt, 1, 0, M, Ci, Co, ptr(dy), Co, self._w(wname), Ci, ptr(dx), Ci)
             self._acc(a, dx)
-            if resid is not None:
-                self._acc(resid, dy)
+            if resid is not None:      # (_acc may adopt its argument as resid's gradient buffer and add into it later: not the kept dy)
+                self._acc(resid, dy.clone() if deferred else dy)
             y.grad = None
         self._push(bw)
         return y
@@ -550,8 +557,35 @@ class UNetModel(FlatModule):
         return h
 
     def _stage_done(self, stage):
+        self._flush_wgrads()
         if self.grad_ready_hook:
             self.grad_ready_hook(stage)
+
+    # ---- deferred weight gradients of the 1x1 layers (attention qkv / proj_out, skip connections) ---------------------------
+    # Per layer these are dy^T x products with K = pixels long and a few hundred rows and columns: a launch of its own must split K
+    # over the chip and push every tile through f32 slabs (150-500 TFLOP/s measured, 48 launches per UNet_64 step).  All layers of
+    # one backward stage that share a pixel count go into ONE vaw_wgrad_grouped launch instead (whole tiles for every CU, only the
+    # last round K-split), as dit.py does for its blocks; the operands are kept alive until then.  bf16 mode only.
+    def _defer_wgrad(self, M, Co, Ci, dy, x):
+        if self._grouped_wgrad is None:
+            import os
+            self._grouped_wgrad = os.environ.get("VAW_UNET_GROUPED_WGRAD", "1") != "0"
+        return (self._grouped_wgrad and self._dt == L.BF16 and M % 64 == 0 and Co % 8 == 0 and Ci % 8 == 0 and Co >= 16 and Ci >= 16
+                and (dy.data_ptr() | x.data_ptr()) % 16 == 0)
+
+    def _flush_wgrads(self):
+        pend = self._pend_wgrad
+        if not pend:
+            return
+        for K, items in pend.items():
+            probs = tuple((ptr(dy), ptr(x), gw, Co, Ci, Co, Ci, Ci) for dy, x, gw, Co, Ci in items)
+            grp = self._wgrad_groups.get(probs)
+            if grp is None:
+                if len(self._wgrad_groups) >= 64:         # (addresses moved: activations are allocated per step)
+                    self._wgrad_groups.clear()
+                grp = self._wgrad_groups[probs] = ops.WgradGroup(list(probs), K, self._flat.device)
+            grp.launch(self._dt, self._beta)
+        pend.clear()                                        # the operands may go: the launches are enqueued on this stream
 
     def _needs_grad(self, a):
         return a is not self._x_act or self._need_dx
@@ -661,6 +695,7 @@ class UNetModel(FlatModule):
         for bw in reversed(self._tape):
             bw()
         self._tape = []
+        self._flush_wgrads()
         dx = None
         if self._need_dx:
             xa = self._x_act
