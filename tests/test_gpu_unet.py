@@ -291,6 +291,35 @@ def test_resample_concat_layout(dtype):
     torch.testing.assert_close(back, xin, rtol=1e-2 if dtype == torch.bfloat16 else 0, atol=1e-2 if dtype == torch.bfloat16 else 0)
 
 
+def test_data_movement_fast_paths_bf16_exact():
+    """bf16 with channel counts on the 8 grid takes the 16-byte kernels (pool / nearest x2, concat / split, gradient add): ragged
+    totals (the last workgroup's octets run out mid-tile), every result bit for bit what the 8-byte kernels' arithmetic gives."""
+    B, C, H, W = 3, 40, 10, 14
+    x = _rand(B, C, H, W, seed=1).bfloat16()
+    xd = _nhwc(x).to(DEV)
+    dn = torch.empty(B * (H // 2) * (W // 2), C, device=DEV, dtype=torch.bfloat16)
+    assert lib().vaw_resample2(BF16, ptr(xd), ptr(dn), B, H // 2, W // 2, C, 0, 0.25, stream_ptr()) == 0
+    xf = x.float()
+    want = ((((xf[:, :, 0::2, 0::2] + xf[:, :, 0::2, 1::2]) + xf[:, :, 1::2, 0::2]) + xf[:, :, 1::2, 1::2]) * 0.25).bfloat16()
+    assert torch.equal(_nchw(dn.cpu(), B, H // 2, W // 2), want)
+    up = torch.empty(B * 4 * H * W, C, device=DEV, dtype=torch.bfloat16)
+    assert lib().vaw_resample2(BF16, ptr(xd), ptr(up), B, 2 * H, 2 * W, C, 1, 1.0, stream_ptr()) == 0
+    assert torch.equal(_nchw(up.cpu().float(), B, 2 * H, 2 * W), F.interpolate(xf, scale_factor=2, mode="nearest"))
+    M = 1237
+    a, b = _rand(M, 24, seed=2).bfloat16().to(DEV), _rand(M, 40, seed=3).bfloat16().to(DEV)
+    cat = torch.empty(M, 64, device=DEV, dtype=torch.bfloat16)
+    assert lib().vaw_concat_channels(BF16, ptr(a), ptr(b), ptr(cat), M, 24, 40, 0, stream_ptr()) == 0
+    assert torch.equal(cat, torch.cat([a, b], 1))
+    a2, b2 = torch.zeros_like(a), torch.zeros_like(b)
+    assert lib().vaw_concat_channels(BF16, ptr(a2), ptr(b2), ptr(cat), M, 24, 40, 1, stream_ptr()) == 0
+    assert torch.equal(a2, a) and torch.equal(b2, b)
+    n = 8 * 12345
+    d0, sr = _rand(n, seed=4).bfloat16().to(DEV), _rand(n, seed=5).bfloat16().to(DEV)
+    d = torch.cat([d0, torch.full((64,), 7.0, device=DEV, dtype=torch.bfloat16)])          # canary behind the buffer
+    assert lib().vaw_add_inplace(BF16, ptr(d), ptr(sr), n, stream_ptr()) == 0
+    assert torch.equal(d[:n], (d0.float() + sr.float()).bfloat16()) and bool((d[n:] == 7.0).all())
+
+
 @pytest.mark.parametrize("tag", ["new", "legacy_ss", "legacy"])     # legacy: use_scale_shift_norm=False, resblock_updown=False (conv
 def test_unet_tiny_fp32_matches_reference_golden(tag):                 # Upsample / stride-2 Downsample), legacy attention order
     g = load_pt("unet_tiny.pt")
