@@ -190,14 +190,27 @@ __global__ void gn_bwd_fold_kernel(const float* __restrict__ part, int nchunk, i
 //   blocks [0, nb1)        S1, S2 per (sample, group)
 //   blocks [nb1, nb1+nb2)  dgamma, dbeta: 16 channels per block, 16 lanes stride the batch, shuffle tree over them
 //   blocks [nb1+nb2, ...)  FiLM gradients copied out per (sample, channel)
+// nchunk > 0: `sums` is the chunk partials [4][nchunk][B][C] and every read folds the chunks in place, in the order
+// gn_bwd_fold_kernel does (the flat path: one launch fewer per GroupNorm backward); nchunk == 0: `sums` is already [4][B][C]
+struct GnSums {
+    const float* p;
+    int nchunk;
+    int64_t BC;
+    __device__ __forceinline__ float operator()(int k, int64_t bc) const {
+        if (nchunk == 0) return p[k * BC + bc];
+        float t = 0.f;
+        for (int ch = 0; ch < nchunk; ++ch) t += p[((int64_t)k * nchunk + ch) * BC + bc];
+        return t;
+    }
+};
 __global__ void __launch_bounds__(256)
-gn_bwd_group_kernel(const float* __restrict__ sums, const float* __restrict__ gamma, int B, int C, int G,
+gn_bwd_group_kernel(const float* __restrict__ sums, int nchunk, const float* __restrict__ gamma, int B, int C, int G,
                     float* __restrict__ S1, float* __restrict__ S2, float* __restrict__ dgamma,
                     float* __restrict__ dbeta, float gbeta, float* __restrict__ dscale,
                     float* __restrict__ dshift, int64_t dfilm_ld, int nb1, int nb2) {
     const int cg = C / G;
     const int64_t BC = (int64_t)B * C;
-    const float *A = sums, *Bs = sums + BC, *DS = sums + 2 * BC, *DH = sums + 3 * BC;
+    const GnSums sum{sums, nchunk, BC};
     int blk = blockIdx.x;
     if (blk < nb1) {
         const int i = blk * 256 + threadIdx.x;
@@ -206,8 +219,8 @@ gn_bwd_group_kernel(const float* __restrict__ sums, const float* __restrict__ ga
         float s1 = 0.f, s2 = 0.f;
         for (int j = 0; j < cg; ++j) {
             const int c = g * cg + j;
-            s1 += gamma[c] * Bs[(int64_t)b * C + c];
-            s2 += gamma[c] * A[(int64_t)b * C + c];
+            s1 += gamma[c] * sum(1, (int64_t)b * C + c);
+            s2 += gamma[c] * sum(0, (int64_t)b * C + c);
         }
         S1[i] = s1;
         S2[i] = s2;
@@ -219,8 +232,8 @@ gn_bwd_group_kernel(const float* __restrict__ sums, const float* __restrict__ ga
         float dg = 0.f, db = 0.f;
         if (c < C)
             for (int b = bl; b < B; b += 16) {
-                dg += A[(int64_t)b * C + c];
-                db += Bs[(int64_t)b * C + c];
+                dg += sum(0, (int64_t)b * C + c);
+                db += sum(1, (int64_t)b * C + c);
             }
         // lanes of one channel sit 16 apart: in-wave tree over lane bits 4,5, then the 4 waves through LDS
         dg += __shfl_xor(dg, 16, 64); dg += __shfl_xor(dg, 32, 64);
@@ -241,8 +254,8 @@ gn_bwd_group_kernel(const float* __restrict__ sums, const float* __restrict__ ga
     const int64_t i = (int64_t)blk * 256 + threadIdx.x;
     if (dscale && i < BC) {
         const int64_t b = i / C, c = i % C;
-        dscale[b * dfilm_ld + c] = DS[i];
-        dshift[b * dfilm_ld + c] = DH[i];
+        dscale[b * dfilm_ld + c] = sum(2, i);
+        dshift[b * dfilm_ld + c] = sum(3, i);
     }
 }
 
@@ -1182,7 +1195,7 @@ static int gnc_try_bwd(vaw_dtype dt, const void* dout, const void* x, const floa
     if (!launched) return 0;
     gnc_bwd_fold_kernel<<<ceil_div(BC, 256), 256, 0, s>>>(part2, gm.nch, B, C, G, rstd, gamma, beta, scale, film_ld, sums);
     const int nb2 = (int)ceil_div(C, 16), nb3 = scale && dscale ? (int)ceil_div(BC, 256) : 0;
-    gn_bwd_group_kernel<<<nb2 + nb3, 256, 0, s>>>(sums, gamma, B, C, G, nullptr, nullptr, dgamma, dbeta, grad_beta,
+    gn_bwd_group_kernel<<<nb2 + nb3, 256, 0, s>>>(sums, 0, gamma, B, C, G, nullptr, nullptr, dgamma, dbeta, grad_beta,
                                                    scale ? dscale : nullptr, dshift, dfilm_ld, 0, nb2);
     return 1;
 }
@@ -1266,10 +1279,15 @@ extern "C" int vaw_groupnorm_bwd(vaw_dtype dt, const void* dout, const void* x, 
     } else {
         BY_DTYPE(dt, (gn_bwd_sums_kernel<T><<<grid, 256, 0, s>>>((const T*)dout, (const T*)x, mean, rstd, gamma, beta, scale, shift, film_ld, silu, HW, C, G, B, nch, part)));
     }
-    gn_bwd_fold_kernel<<<ceil_div(4 * BC, 256), 256, 0, s>>>(part, nch, B, C, sums);
     const int nb1 = (int)ceil_div(B * G, 256), nb2 = (int)ceil_div(C, 16), nb3 = scale && dscale ? (int)ceil_div(BC, 256) : 0;
-    gn_bwd_group_kernel<<<nb1 + nb2 + nb3, 256, 0, s>>>(sums, gamma, B, C, G, S1, S2, dgamma, dbeta, grad_beta,
-                                                         scale ? dscale : nullptr, dshift, dfilm_ld, nb1, nb2);
+    if (flat) {          // the chunk fold rides in the group kernel
+        gn_bwd_group_kernel<<<nb1 + nb2 + nb3, 256, 0, s>>>(part, nch, gamma, B, C, G, S1, S2, dgamma, dbeta, grad_beta,
+                                                             scale ? dscale : nullptr, dshift, dfilm_ld, nb1, nb2);
+    } else {
+        gn_bwd_fold_kernel<<<ceil_div(4 * BC, 256), 256, 0, s>>>(part, nch, B, C, sums);
+        gn_bwd_group_kernel<<<nb1 + nb2 + nb3, 256, 0, s>>>(sums, 0, gamma, B, C, G, S1, S2, dgamma, dbeta, grad_beta,
+                                                             scale ? dscale : nullptr, dshift, dfilm_ld, nb1, nb2);
+    }
     if (flat) {
 #define GNS_BAPPLY(S, F, A)                                                                                                        \
     if ((silu != 0) == S && (scale != nullptr) == F && (dx_add != nullptr) == A)                                                   \
