@@ -418,6 +418,46 @@ def _run_trainer(model, args, batches, steps, fused, var_type="FIXED_LARGE"):
     return losses, psum, esum
 
 
+def test_unet_bf16_hip_graph_step_follows_eager_step():
+    """A bf16 UNet with 1 x 1 layers (attention qkv / proj_out, skip connections on channel changes): the eager step defers their
+    weight gradients into grouped launches (unet.py: _flush_wgrads), a captured step cannot (a new group uploads a descriptor table)
+    and takes the per-layer launches.  Both must train, on the same trajectory up to the summation order of those weight gradients;
+    with VAW_UNET_GROUPED_WGRAD=0 semantics (no deferral at all) eager and captured steps are the same kernels.  (A capture that
+    reached the upload used to abort the step: this is its regression test.)"""
+    class FixedDraws(vaw_amd.GaussianDiffusion):
+        def training_losses(self, model, x_start, features=None, t=None, model_kwargs=None, noise=None):
+            return super().training_losses(model, x_start, features, t=self._t, model_kwargs=model_kwargs, noise=self._noise)
+
+    def run(graph, grouped):
+        args = base_args(image_size=16, lr=1e-3, grad_clip=0.5, defer_loss_sync=True, hip_graph=graph)
+        random.seed(42); np.random.seed(42); torch.manual_seed(42)
+        model = vaw_amd.UNetModel(16, 3, 32, 3, 1, attention_resolutions=(1, 2), channel_mult=(1, 2), num_heads=2, use_scale_shift_norm=True,
+                                  resblock_updown=True, use_new_attention_order=True, compute_dtype="bf16").to(DEV)
+        perturb_(model, 5)
+        model._grouped_wgrad = grouped
+        ema_model = copy.deepcopy(model)
+        opt = vaw_amd.FusedAdamW(model, lr=args.lr, betas=(0.9, 0.95), weight_decay=0.0, eps=1e-8)
+        sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=vaw_amd.get_lr_lambda(args))
+        diff = FixedDraws(args=args, betas=vaw_amd.get_named_beta_schedule("cosine", 1000), model_mean_type=vaw_amd.ModelMeanType.EPSILON,
+                          model_var_type=vaw_amd.ModelVarType.FIXED_LARGE, loss_type=vaw_amd.LossType.MSE, rescale_timesteps=True)
+        g = torch.Generator().manual_seed(9)
+        diff._t = torch.randint(0, 1000, (8,), generator=g).to(DEV)
+        diff._noise = torch.randn(8, 3, 16, 16, generator=g).to(DEV)
+        batches = [(torch.randn(8, 3, 16, 16, generator=g), torch.zeros(8, dtype=torch.long)) for _ in range(3)]
+        tr = vaw_amd.Trainer(args, torch.device(DEV), model, ema_model, opt, sched, diff, batches, Pbar())
+        losses = [float(tr.train_step(s)) for s in range(1, 9)]
+        return losses, model._flat.clone()
+
+    le, pe = run(False, True)
+    lg, pg = run(True, True)
+    assert all(np.isfinite(le)) and all(np.isfinite(lg)) and le[-1] < le[0] and lg[-1] < lg[0]
+    np.testing.assert_allclose(lg, le, rtol=2e-2)
+    assert float((pg - pe).norm() / pe.norm()) < 1e-3
+    le0, pe0 = run(False, False)
+    lg0, pg0 = run(True, False)
+    assert le0 == lg0 and torch.equal(pe0, pg0)
+
+
 CFG1 = lambda: vaw_amd.UNetModel(32, 3, 64, 3, 2, attention_resolutions=(), channel_mult=(1, 2, 2, 2), num_heads=4,
                                  use_scale_shift_norm=True, resblock_updown=True, use_new_attention_order=True,
                                  compute_dtype="fp32")

@@ -570,6 +570,8 @@ class UNetModel(FlatModule):
         if self._grouped_wgrad is None:
             import os
             self._grouped_wgrad = os.environ.get("VAW_UNET_GROUPED_WGRAD", "1") != "0"
+        if torch.cuda.is_current_stream_capturing():
+            return False          # a new group uploads its descriptor table from pinned memory it allocates: not capturable
         return (self._grouped_wgrad and self._dt == L.BF16 and M % 64 == 0 and Co % 8 == 0 and Ci % 8 == 0 and Co >= 16 and Ci >= 16
                 and (dy.data_ptr() | x.data_ptr()) % 16 == 0)
 
