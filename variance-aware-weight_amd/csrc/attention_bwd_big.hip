@@ -428,6 +428,22 @@ attn_bwd_big(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __restr
 // in 32-key slices; online softmax per query with the running maximum on the lane (base-2 domain, deferred rescale as in
 // attn_fwd_mfma: the maximum only moves when a slice exceeds it by more than 2^6).  S^T[key][q] = K_s Q_w^T, O^T[hd][q] += V_s^T P^T.
 // ------------------------------------------------------------------------------------------------
+#ifndef ATTN_PROF
+#define ATTN_PROF 0
+#endif
+#if ATTN_PROF
+__device__ unsigned long long attn_prof_buf[1024];
+extern "C" int vaw_debug_attn_prof(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(attn_prof_buf), sizeof(unsigned long long) * n);
+}
+#define ATTN_STAMP(slot)                                                                                                     \
+    do {                                                                                                                     \
+        if (threadIdx.x == 0 && blockIdx.x == 1 && blockIdx.y == 777 && prof_n < 1000)                                       \
+            attn_prof_buf[prof_n++] = ((unsigned long long)(slot) << 56) | (wall_clock64() & 0xffffffffffffffull);           \
+    } while (0)
+#else
+#define ATTN_STAMP(slot) do {} while (0)
+#endif
 template <int HD, int NT>
 __global__ void __launch_bounds__(256, NT == 2 ? 2 : 1)
 attn_fwd_big(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
@@ -435,6 +451,10 @@ attn_fwd_big(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __restr
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = HD / 32, DT = HD / 16, SIMG = BigLds<HD, NT>::SIMG, WGR = BigLds<HD, NT>::WGR;
     constexpr int NB = BigLds<HD, NT>::NB, DEPTH = NB - 1;
+#if ATTN_PROF
+    int prof_n = 0;
+#endif
+    ATTN_STAMP(1);
     char* slices = smem;
     char* stage = smem;
     const int lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
@@ -479,6 +499,7 @@ attn_fwd_big(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __restr
             const int last = sl + DEPTH - 1 < n_slices - 1 ? sl + DEPTH - 1 : n_slices - 1;
             wait_vm((last - sl) * dma_per_slice);
             __builtin_amdgcn_s_barrier();
+            ATTN_STAMP(2);
             if (sl + DEPTH < n_slices) issue(sl + DEPTH);
         }
         bf16x8 xa[2][KS];
@@ -501,6 +522,7 @@ attn_fwd_big(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __restr
             for (int s = 0; s < KS; ++s)
 #pragma unroll
                 for (int qt = 0; qt < NT; ++qt) c[kt][qt] = MFMA(xa[kt][s], qf[qt][s], s == 0 ? zero4 : c[kt][qt]);      // S^T [key 4g + r][query li]
+        ATTN_STAMP(3);
         bf16x8 pf[NT];
         bool any_rescale = false;
         float alpha[NT];
@@ -533,6 +555,7 @@ attn_fwd_big(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __restr
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) ot[qt][dt] *= alpha[qt];
         }
+        ATTN_STAMP(4);
 #pragma unroll
         for (int dh = 0; dh < DT; dh += 2) {
             const int pp = (dh >> 1) & 1;
@@ -546,8 +569,10 @@ attn_fwd_big(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __restr
             }
         }
     }
+    ATTN_STAMP(5);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();                                     // the last slice's reads: O is staged over the ring
+    ATTN_STAMP(6);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const float lt = group_sum(l[t]);
@@ -558,7 +583,9 @@ attn_fwd_big(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __restr
         if (g == 0) lse[(int64_t)bh * a.T + own0 + 16 * t + li] = m[t] * 0.6931471805599453f + __logf(lt);   // back to the natural log
     }
     __syncthreads();
+    ATTN_STAMP(7);
     out_flush<HD>(stage, WGR, o + obase + (int64_t)blockIdx.x * WGR * a.o_st, a.o_st, a.hd);
+    ATTN_STAMP(8);
 }
 
 static AttnMfmaArgs mk_args_big(const vaw_attn_desc* d) {
