@@ -444,13 +444,24 @@ extern "C" int vaw_debug_attn_prof(unsigned long long* out, int n) {
 #else
 #define ATTN_STAMP(slot) do {} while (0)
 #endif
+// the forward's own ring depth / occupancy target (A/B: -DATTN_FWD_NB=3 -DATTN_FWD_OCC=4 = four workgroups per CU on a 3-deep ring)
+#ifndef ATTN_FWD_NB
+#define ATTN_FWD_NB 4
+#endif
+#ifndef ATTN_FWD_OCC
+#define ATTN_FWD_OCC 2
+#endif
+template <int HD, int NT> struct FwdLds {
+    static constexpr int SIMG = BigLds<HD, NT>::SIMG, NB = ATTN_FWD_NB, RING = NB * 2 * SIMG, WGR = BigLds<HD, NT>::WGR;
+    static constexpr int STAGE = BigLds<HD, NT>::STAGE, FRONT = RING > STAGE ? RING : STAGE;
+};
 template <int HD, int NT>
-__global__ void __launch_bounds__(256, NT == 2 ? 2 : 1)
+__global__ void __launch_bounds__(256, NT == 2 ? ATTN_FWD_OCC : 1)
 attn_fwd_big(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
              bf16_t* __restrict__ o, float* __restrict__ lse) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int KS = HD / 32, DT = HD / 16, SIMG = BigLds<HD, NT>::SIMG, WGR = BigLds<HD, NT>::WGR;
-    constexpr int NB = BigLds<HD, NT>::NB, DEPTH = NB - 1;
+    constexpr int KS = HD / 32, DT = HD / 16, SIMG = FwdLds<HD, NT>::SIMG, WGR = FwdLds<HD, NT>::WGR;
+    constexpr int NB = FwdLds<HD, NT>::NB, DEPTH = NB - 1;
 #if ATTN_PROF
     int prof_n = 0;
 #endif
@@ -629,8 +640,8 @@ bool vaw_attn_bwd_big(const vaw_attn_desc* d, const void* q, const void* k, cons
 
 template <int HD, int NT>
 static void big_fwd_go(const AttnMfmaArgs& a, const vaw_attn_desc* d, const void* q, const void* k, const void* v, void* o, float* lse, hipStream_t s) {
-    const int lds = BigLds<HD, NT>::FRONT;
-    dim3 grid(d->T / BigLds<HD, NT>::WGR, d->B * d->H);
+    const int lds = FwdLds<HD, NT>::FRONT;
+    dim3 grid(d->T / FwdLds<HD, NT>::WGR, d->B * d->H);
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)attn_fwd_big<HD, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
