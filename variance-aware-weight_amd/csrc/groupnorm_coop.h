@@ -63,8 +63,10 @@ static inline bool gnc_shape_ok(vaw_dtype dt, int B, int HW, int C, int G) {
 // floats of workspace: part1 [B][nch][2][64] | part2 [B][nch][2][C] | sums [4][B][C] | counters [B]
 static inline int64_t gnc_workspace_floats(int B, int HW, int C) {
     if (C % 8 != 0 || C / 8 > GNC_NT) return 0;
-    const GncGeom g = gnc_geom(B, HW, C, GNC_NV_BWD);      // the backward has the smaller chunks
-    return (int64_t)B * g.nch * 2 * (64 + C) + (int64_t)4 * B * C + B + 64;
+    const GncGeom gb = gnc_geom(B, HW, C, GNC_NV_BWD), gf = gnc_geom(B, HW, C, GNC_NV_FWD);
+    const int64_t bwd = (int64_t)B * gb.nch * 2 * (64 + C) + (int64_t)4 * B * C + B + 64;      // part1 | part2 | sums | counters
+    const int64_t fwd = (int64_t)B * gf.nch * 128 + 64;                                          // part1 only
+    return bwd > fwd ? bwd : fwd;
 }
 
 typedef unsigned gnc_u32x4 __attribute__((ext_vector_type(4)));
