@@ -76,6 +76,71 @@ def test_groupnorm_film_silu_fwd_bwd(dtype, B, C, H, film, silu):
         torch.testing.assert_close(demb.cpu().double(), er.grad, rtol=rt, atol=tol["atol"] * 10)
 
 
+@pytest.mark.parametrize("B,C,H,film,silu,add", [(3, 192, 24, True, True, True), (2, 576, 16, False, True, False), (2, 1536, 8, True, False, True),
+                                                 (5, 96, 20, True, True, False), (2, 384, 23, False, False, True), (1, 128, 33, True, True, True)])
+def test_groupnorm_flat_mapping_kernels(B, C, H, film, silu, add):
+    """The bf16 GroupNorm passes of large launches run on the flat 16-byte kernels (unet_ops.hip: gns_*; chosen when a launch has >=
+    512 workgroups, so the small shapes of the other tests never reach them): forced here (vaw_debug_gn_flat 1 / 0) on shapes with
+    ragged chunk tails (HW % 128 != 0), 216 / 240 / 192 live lanes, groups that straddle a lane's channel octet, against the f64 torch
+    GroupNorm and against the quad-mapped kernels."""
+    HW = H * H
+    x = (_rand(B, C, H, H, seed=1) * 1.5 + 0.3).bfloat16()
+    gamma, beta = _rand(C, seed=2) * 0.5 + 1, _rand(C, seed=3) * 0.2
+    emb = _rand(B, 3 * C, seed=4) * 0.3
+    dout, dadd = _rand(B, C, H, H, seed=5).bfloat16(), _rand(B, C, H, H, seed=6).bfloat16()
+    xr = x.double().requires_grad_(True)
+    gr, br, er = gamma.double().requires_grad_(True), beta.double().requires_grad_(True), emb.double().requires_grad_(True)
+    ref = F.group_norm(xr, 32, gr, br, eps=1e-5)
+    if film:
+        ref = ref * (1 + er[:, C:2 * C, None, None]) + er[:, 2 * C:, None, None]
+    if silu:
+        ref = F.silu(ref)
+    (ref * dout.double()).sum().backward()
+    xd, gd, bd, ed = _nhwc(x).to(DEV), gamma.to(DEV), beta.to(DEV), emb.to(DEV)
+    dod, dad = _nhwc(dout).to(DEV), _nhwc(dadd).to(DEV)
+    sc = ptr(ed) + 4 * C if film else None
+    sh = ptr(ed) + 8 * C if film else None
+    ws = torch.empty(lib().vaw_groupnorm_workspace_floats(B, HW, C), device=DEV)
+    got = {}
+    try:
+        lib().vaw_debug_gn_coop(0)
+        for mode in (1, 0):
+            lib().vaw_debug_gn_flat(mode)
+            ws.fill_(float("nan"))
+            y = torch.empty(B * HW, C, device=DEV, dtype=torch.bfloat16)
+            mean, rstd = torch.empty(B * 32, device=DEV), torch.empty(B * 32, device=DEV)
+            assert lib().vaw_groupnorm_fwd(BF16, ptr(xd), ptr(gd), ptr(bd), sc, sh, 3 * C, int(silu), ptr(y), ptr(mean), ptr(rstd), B, HW, C,
+                                           32, 1e-5, ptr(ws), stream_ptr()) == 0
+            dx = torch.empty_like(xd)
+            dg, db, demb = torch.ones(C, device=DEV), torch.ones(C, device=DEV), torch.zeros(B, 3 * C, device=DEV)
+            ws.fill_(float("nan"))
+            assert lib().vaw_groupnorm_bwd(BF16, ptr(dod), ptr(xd), ptr(mean), ptr(rstd), ptr(gd), ptr(bd), sc, sh, 3 * C, int(silu),
+                                           ptr(dad) if add else None, ptr(dx), ptr(dg), ptr(db), 1.0, (ptr(demb) + 4 * C) if film else None,
+                                           (ptr(demb) + 8 * C) if film else None, 3 * C, B, HW, C, 32, ptr(ws), stream_ptr()) == 0
+            torch.cuda.synchronize()
+            got[mode] = [t.cpu().double() for t in (y, mean, rstd, dx, dg, db, demb)]
+    finally:
+        lib().vaw_debug_gn_flat(-1)
+        lib().vaw_debug_gn_coop(-1)
+    tol = dict(rtol=3e-2, atol=3e-2)
+    want_dx = xr.grad + (dadd.double() if add else 0)
+    for mode in (1, 0):
+        y, mean, rstd, dx, dg, db, demb = got[mode]
+        torch.testing.assert_close(_nchw(y, B, H, H), ref.detach(), **tol)
+        torch.testing.assert_close(_nchw(dx, B, H, H), want_dx, **tol)
+        torch.testing.assert_close(dg, 1 + gr.grad, rtol=3e-2, atol=0.3)
+        torch.testing.assert_close(db, 1 + br.grad, rtol=3e-2, atol=0.3)
+        if film:
+            torch.testing.assert_close(demb, er.grad, rtol=3e-2, atol=0.3)
+    torch.testing.assert_close(got[1][1], got[0][1], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(got[1][2], got[0][2], rtol=1e-5, atol=1e-5)
+    for k in (4, 5, 6):
+        torch.testing.assert_close(got[1][k], got[0][k], rtol=2e-4, atol=2e-3)
+    for k in (0, 3):
+        assert float(((got[1][k] - got[0][k]).abs() > 0).double().mean()) < 0.05
+        torch.testing.assert_close(got[1][k], got[0][k], rtol=1.6e-2, atol=1e-3)
+
+
 @pytest.mark.parametrize("B,C,H,film,silu,add", [(3, 192, 32, True, True, True), (2, 576, 16, False, True, False), (2, 1536, 8, True, False, True),
                                                  (5, 96, 20, True, True, False), (2, 384, 24, False, False, True), (1, 128, 33, True, True, True),
                                                  (40, 64, 12, True, True, True)])

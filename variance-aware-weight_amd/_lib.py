@@ -145,9 +145,10 @@ def lib():
         L.vaw_debug_force_generic_gemm.restype = None
         L.vaw_debug_gemm_tile.argtypes = [_i]
         L.vaw_debug_gemm_tile.restype = None
-        if hasattr(L, "vaw_debug_gn_coop"):              # absent from older measurement builds loaded through VAW_HIP_LIB
-            L.vaw_debug_gn_coop.argtypes = [_i]
-            L.vaw_debug_gn_coop.restype = None
+        for dbg in ("vaw_debug_gn_coop", "vaw_debug_gn_flat"):      # absent from older measurement builds loaded through VAW_HIP_LIB
+            if hasattr(L, dbg):
+                getattr(L, dbg).argtypes = [_i]
+                getattr(L, dbg).restype = None
         L.vaw_p8_set_reserved_cus.argtypes = [_i]
         L.vaw_p8_set_reserved_cus.restype = None
         L.vaw_debug_cu_hog.argtypes = [_i, _i, _p]

@@ -314,10 +314,13 @@ struct GnsGeom {
     int C8, nt, rpi, rows;     // rows per chunk
 };
 // chunk rows: GN_ROWS, or less while that leaves fewer than two workgroups per CU (0: use the quad-mapped kernels)
+static int g_gn_flat = -1;       // vaw_debug_gn_flat: -1 by shape (VAW_GN_FLAT=0 switches the flat kernels off), 0 never, 1 always (tests)
+extern "C" void vaw_debug_gn_flat(int mode) { g_gn_flat = mode; }
 static inline int gns_rows(int B, int HW) {
+    if (g_gn_flat == 0) return 0;
     for (int rows = GN_ROWS; rows >= GN_ROWS / 4; rows /= 2)
         if ((int64_t)B * ((HW + rows - 1) / rows) >= 512) return rows;
-    return 0;
+    return g_gn_flat == 1 ? GN_ROWS / 4 : 0;
 }
 static inline GnsGeom gns_geom(int C, int rows) {
     GnsGeom g;
