@@ -116,8 +116,14 @@ class _Workspace:
         M = B * T
         e = lambda *s, dtype=adt: torch.empty(*s, device=dev, dtype=dtype)
         self.B, self.adt, self.gen = B, adt, 0
-        self.tfreq, self.h1, self.h1s = e(B, 256), e(B, D, dtype=f32), e(B, D)
-        self.temb, self.c, self.cs = e(B, D, dtype=f32), e(B, D, dtype=f32), e(B, D)
+        # The conditioning path's weight gradients are dy^T x products with K = BATCH.  The MFMA GEMMs take K in whole 64s, so the
+        # bf16 operands of those products (tfreq, h1s, cs here; dmod_a, dc_a, dh1_a below) carry zero rows up to the next multiple of
+        # 64: nothing ever writes them, the products run with K = Bk on the MFMA kernels instead of the generic one (32 images per
+        # GPU: 0.19 ms of the 4.5 ms step), and the bias gradients (column sums) still walk the first B rows only.
+        self.Bk = Bk = ((B + 63) // 64) * 64 if adt == torch.bfloat16 else B
+        z = lambda cols: torch.zeros(Bk, cols, device=dev, dtype=adt)
+        self.tfreq, self.h1, self.h1s = z(256), e(B, D, dtype=f32), z(D)
+        self.temb, self.c, self.cs = e(B, D, dtype=f32), e(B, D, dtype=f32), z(D)
         self.mod = e(B, m.mod_cols, dtype=f32)
         self.xp = e(M, m.Kp)
         self.xres = [e(M, D, dtype=f32) for _ in range(2 * Lyr + 1)]   # inputs of LN1/LN2 of each block, + final
@@ -160,9 +166,9 @@ class _Workspace:
             b["cp_fc2"].rows.value = b["cp_proj"].rows.value = B
         self.dyb = e(M, D)          # dy of a gated branch when the block keeps no buffer of its own (f32 / fp8 / per-layer wgrad modes)
         self.delta = e(B * m.num_heads * T, dtype=f32)
-        self.dmod, self.dmod_a = e(B, m.mod_cols, dtype=f32), e(B, m.mod_cols)
-        self.dcs, self.dc, self.dc_a = e(B, D, dtype=f32), e(B, D, dtype=f32), e(B, D)
-        self.dh1s, self.dh1, self.dh1_a = e(B, D, dtype=f32), e(B, D, dtype=f32), e(B, D)
+        self.dmod, self.dmod_a = e(B, m.mod_cols, dtype=f32), z(m.mod_cols)
+        self.dcs, self.dc, self.dc_a = e(B, D, dtype=f32), e(B, D, dtype=f32), z(D)
+        self.dh1s, self.dh1, self.dh1_a = e(B, D, dtype=f32), e(B, D, dtype=f32), z(D)
         self.dxp = e(M, m.Kp, dtype=f32)
 
 
@@ -518,8 +524,8 @@ class DiT(FlatModule):
             dmod_a, es = ptr(ws.dmod_a), 2
         else:
             dmod_a, es = ptr(ws.dmod), 4
-        ops.gemm(dt, 0, 0, nrows, D, B, dmod_a + es * r0, ld, ptr(ws.cs), D, self._g("blocks.0.adaLN_modulation.1.weight") + 4 * r0 * D,
-                 D, beta=beta, out_f32=True)
+        ops.gemm(dt, 0, 0, nrows, D, ws.Bk, dmod_a + es * r0, ld, ptr(ws.cs), D, self._g("blocks.0.adaLN_modulation.1.weight") + 4 * r0 * D,
+                 D, beta=beta, out_f32=True)                 # K = the batch, zero rows up to ws.Bk (see _Workspace)
         ops.colsum(dt, dmod_a + es * r0, B, nrows, ld, self._g("blocks.0.adaLN_modulation.1.bias") + 4 * r0, beta)
         return dmod_a
 
@@ -701,7 +707,7 @@ class DiT(FlatModule):
             dc_a = ptr(ws.dc_a)
         else:
             dc_a = ptr(ws.dc)
-        self._wgrad(dt, "t_embedder.mlp.2.", dc_a, ptr(ws.h1s), D, D, B, beta)
+        self._wgrad(dt, "t_embedder.mlp.2.", dc_a, ptr(ws.h1s), D, D, ws.Bk, beta)
         ops.gemm(dt, 1, 0, B, D, D, dc_a, D, self._w("t_embedder.mlp.2.weight"), D, ptr(ws.dh1s), D, out_f32=True)
         L.check(lib.vaw_silu_bwd(ptr(ws.h1), ptr(ws.dh1s), ptr(ws.dh1), B * D, st), "silu_bwd")
         if dt == BF16:
@@ -709,7 +715,7 @@ class DiT(FlatModule):
             dh1_a = ptr(ws.dh1_a)
         else:
             dh1_a = ptr(ws.dh1)
-        self._wgrad(dt, "t_embedder.mlp.0.", dh1_a, ptr(ws.tfreq), D, 256, B, beta)
+        self._wgrad(dt, "t_embedder.mlp.0.", dh1_a, ptr(ws.tfreq), D, 256, ws.Bk, beta)
         self.attach_grads()
         if fp8:
             ws.calib_bwd = True
