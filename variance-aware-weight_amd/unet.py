@@ -402,8 +402,10 @@ class UNetModel(FlatModule):
             dx = self._new(M, Ci)
             ops.gemm(dt, 1, 0, M, Ci, Co, ptr(dy), Co, self._w(wname), Ci, ptr(dx), Ci)
             self._acc(a, dx)
-            if resid is not None:      # (_acc may adopt its argument as resid's gradient buffer and add into it later: not the kept dy)
-                self._acc(resid, dy.clone() if deferred else dy)
+            if resid is not None:      # (_acc may adopt its argument as resid's gradient buffer: a kept dy is then added to out of place)
+                if deferred:
+                    dy._vaw_keep = True
+                self._acc(resid, dy)
             y.grad = None
         self._push(bw)
         return y
@@ -572,8 +574,15 @@ class UNetModel(FlatModule):
             self._grouped_wgrad = os.environ.get("VAW_UNET_GROUPED_WGRAD", "1") != "0"
         if torch.cuda.is_current_stream_capturing():
             return False          # a new group uploads its descriptor table from pinned memory it allocates: not capturable
-        return (self._grouped_wgrad and self._dt == L.BF16 and M % 64 == 0 and Co % 8 == 0 and Ci % 8 == 0 and Co >= 16 and Ci >= 16
-                and (dy.data_ptr() | x.data_ptr()) % 16 == 0)
+        if not (self._grouped_wgrad and self._dt == L.BF16 and M % 64 == 0 and Co % 8 == 0 and Ci % 8 == 0 and Co >= 16 and Ci >= 16
+                and (dy.data_ptr() | x.data_ptr()) % 16 == 0):
+            return False
+        # what deferral buys is the gap between a lone split-K launch and the grouped one; what it costs is a column-sum pass over dy
+        # (the bias gradient no longer rides on the weight-gradient launch).  A layer with many output tiles AND a long K runs at
+        # ~600 TFLOP/s on its own and has a wide dy: ADM_64's qkv at 32 x 32 (1152 x 384, 262 144 pixels: +58 us against a 110 us
+        # pass) stays per-layer; measured net of the rule on ADM_64 / UNet_64 in DESIGN.md §6.0
+        tiles = ((Co + 255) // 256) * ((Ci + 191) // 192)
+        return tiles < 10 or M <= 65536
 
     def _flush_wgrads(self):
         pend = self._pend_wgrad
@@ -595,6 +604,8 @@ class UNetModel(FlatModule):
     def _acc(self, a, g):
         if a.grad is None:
             a.grad = g
+        elif getattr(a.grad, "_vaw_keep", False):     # a deferred weight gradient still reads this buffer: same traffic, new tensor
+            a.grad = torch.add(a.grad, g)
         else:
             L.check(L.lib().vaw_add_inplace(self._dt, ptr(a.grad), ptr(g), g.numel(), L.stream_ptr()), "add_inplace")
 
