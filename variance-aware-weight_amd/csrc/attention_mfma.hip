@@ -28,6 +28,9 @@
 // LDS then feeds two MFMAs, and the per-key-block barrier + DMA wait is paid once per 128 queries.
 // DB: K / V blocks double-buffered (the next block streams in while this one is consumed; one barrier per block):
 // +10..19 % for head dims <= 64; the wider images lose a resident workgroup to the extra LDS and keep one buffer.
+#ifndef ATTN64_XCD
+#define ATTN64_XCD 0        // 1: each XCD takes a contiguous run of (sample, head) pairs -- measured level to worse (fwd 21.9 -> 24.8 us)
+#endif
 template <int HD, int QG, bool DB = (HD <= 64)>
 __global__ void __launch_bounds__(256)
 attn_fwd_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
@@ -38,7 +41,11 @@ attn_fwd_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __rest
     char* kv = smem + QG * IMG;                                   // [1 or 2 buffers][K image | V image]
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
+    // one query block per (sample, head) (T = 64 QG): workgroups follow blockIdx.y round-robin over the XCDs; each XCD takes a
+    // contiguous run of pairs instead (see attn_bwd_t64_mfma)
+    int bh = blockIdx.y;
+    if (ATTN64_XCD && gridDim.x == 1 && (gridDim.y & 7) == 0) bh = (blockIdx.y & 7) * (gridDim.y >> 3) + (blockIdx.y >> 3);
+    const int b = bh / a.H, h = bh % a.H;
     const int qb = blockIdx.x * 64 * QG;
     const int64_t base = b * a.q_sb + h * a.q_sh;
 #pragma unroll
@@ -432,6 +439,22 @@ attn_bwd_dkv_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __
 // are latency-bound at this size).  Phase 1 = attn_bwd_dq_mfma's body, phase 2 = attn_bwd_dkv_mfma's, lse / delta
 // handed over through LDS.
 // ------------------------------------------------------------------------------------------------
+#ifndef ATTN64_PROF
+#define ATTN64_PROF 0
+#endif
+#if ATTN64_PROF
+__device__ unsigned long long attn64_prof_buf[64];
+extern "C" int vaw_debug_attn64_prof(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(attn64_prof_buf), sizeof(unsigned long long) * n);
+}
+#define A64_STAMP(slot)                                                                                               \
+    do {                                                                                                              \
+        if (threadIdx.x == 0 && blockIdx.x == 1500 && prof_n < 60)                                                    \
+            attn64_prof_buf[prof_n++] = ((unsigned long long)(slot) << 56) | (wall_clock64() & 0xffffffffffffffull);  \
+    } while (0)
+#else
+#define A64_STAMP(slot) do {} while (0)
+#endif
 template <int HD>
 __global__ void __launch_bounds__(256)
 attn_bwd_t64_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
@@ -440,6 +463,10 @@ attn_bwd_t64_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __
                   float* __restrict__ cs_part = nullptr, int64_t cs_ld = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 images of 64 x HD bf16 (reused as output staging; lse / delta: below)
     constexpr int KS = HD / 32, DT = HD / 16;
+#if ATTN64_PROF
+    int prof_n = 0;
+#endif
+    A64_STAMP(1);
     char* qimg = smem;
     char* gimg = qimg + Img<HD>::BYTES;
     char* kimg = gimg + Img<HD>::BYTES;
@@ -450,7 +477,11 @@ attn_bwd_t64_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __
     float* del_s = lse_s + 64;
     const int lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
+    // (ATTN64_XCD=1: workgroups are dealt round-robin over the 8 XCDs; give each XCD a CONTIGUOUS run of (sample, head) pairs, so that
+    // the 128-byte row pieces of a sample's heads -- adjacent in memory -- are asked for by one L2 at about the same time)
+    int bh = blockIdx.x;
+    if (ATTN64_XCD && (gridDim.x & 7) == 0) bh = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int b = bh / a.H, h = bh % a.H;
     const int64_t base = b * a.q_sb + h * a.q_sh, obase = b * a.o_sb + h * a.o_sh;
     stage_block<HD>(q + base, a.q_st, qimg, wid, lane, a.hd);
     stage_block<HD>(d_o + obase, a.o_st, gimg, wid, lane, a.hd);
@@ -472,7 +503,9 @@ attn_bwd_t64_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __
     const float c2 = a.scale * 1.4426950408889634f;
     const float li_lse = lse[(int64_t)bh * 64 + qi] * 1.4426950408889634f;             // base-2 domain
     if (g == 0) delta_out[(int64_t)bh * 64 + qi] = dl;
+    A64_STAMP(2);
     DMA_WAIT_SYNC();
+    A64_STAMP(3);
     // Output staging (r3): dq, dk, dv leave through LDS as whole rows -- a lane of an accumulator tile owns 4 bf16 of one row, so
     // direct stores write 32-byte pieces of 16 rows per instruction; staged, eight lanes write one 128-byte row with 16 bytes each
     // -- and their column sums (the qkv bias gradient) are taken from the staged tiles by 3 hd threads in a fixed row order
@@ -518,6 +551,7 @@ attn_bwd_t64_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __
             for (int dt = 0; dt < DT; ++dt) acc[dt] = MFMA(frag_cols_perm<HD>(kimg, 16 * dt, 32 * s2, lane), sf, acc[dt]);
         }
     }
+    A64_STAMP(4);
     // ---- phase 2: dK, dV of this wave's 16 keys (lse_s / del_s were written before the sync) ----
     f32x4 av[DT], ak[DT];
     {
@@ -564,10 +598,12 @@ attn_bwd_t64_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __
             }
         }
     }
+    A64_STAMP(5);
     __syncthreads();                      // nobody reads the Q / dO images any more
     stage_tile(qimg, ak);
     stage_tile(gimg, av);
     __syncthreads();
+    A64_STAMP(6);
     // whole rows out: tile 0 = dq (staged at kimg), 1 = dk (qimg), 2 = dv (gimg); 16 bytes per thread and access
     constexpr int CPR = HD / 8;
 #pragma unroll
@@ -580,6 +616,7 @@ attn_bwd_t64_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __
         bf16_t* dst = (tile == 0 ? dq : tile == 1 ? dk : dv) + base + (int64_t)r * a.q_st + 8 * c16;
         *reinterpret_cast<bf16x8*>(dst) = *reinterpret_cast<const bf16x8*>(src);
     }
+    A64_STAMP(7);
     if (cs_part) {     // this (sample, head)'s column sums of dq | dk | dv (as stored, rows in ascending order) -> its columns of the
                        // sample's partial row [3 H hd]
         for (int t = threadIdx.x; t < 3 * HD; t += 256) {
