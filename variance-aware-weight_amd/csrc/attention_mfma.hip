@@ -488,21 +488,18 @@ attn_bwd_t64_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __
     stage_block<HD>(k + base, a.q_st, kimg, wid, lane, a.hd);
     stage_block<HD>(v + base, a.q_st, vimg, wid, lane, a.hd);
     const int qi = 16 * wid + li;
-    float dl = 0.f;
-    {
-        const bf16_t* gp = d_o + obase + (int64_t)qi * a.o_st + g * (HD / 4);
-        const bf16_t* op = o + obase + (int64_t)qi * a.o_st + g * (HD / 4);
+    // delta = rowsum(dO * O) of this lane's query: O comes from global (requested now, 16 bytes per lane and k-step at the columns of
+    // this lane's dO fragment), dO from its LDS image once that has landed -- the kernel used to read dO twice (image + registers)
+    bf16x8 of[KS];
 #pragma unroll
-        for (int d = 0; d < HD / 4; d += 4) {
-            if (g * (HD / 4) + d >= a.hd) continue;
-            const f32x4 x = load4(gp + d), y = load4(op + d);
-            dl += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
-        }
-        dl = group_sum(dl);
+    for (int s = 0; s < KS; ++s) {
+        const int c = 32 * s + 8 * g;
+        const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        of[s] = c < a.hd ? *reinterpret_cast<const bf16x8*>(o + obase + (int64_t)qi * a.o_st + c) : z;
     }
+    float dl = 0.f;
     const float c2 = a.scale * 1.4426950408889634f;
     const float li_lse = lse[(int64_t)bh * 64 + qi] * 1.4426950408889634f;             // base-2 domain
-    if (g == 0) delta_out[(int64_t)bh * 64 + qi] = dl;
     A64_STAMP(2);
     DMA_WAIT_SYNC();
     A64_STAMP(3);
@@ -530,6 +527,12 @@ attn_bwd_t64_mfma(AttnMfmaArgs a, const bf16_t* __restrict__ q, const bf16_t* __
             qf[s] = frag_rows<HD>(qimg, 16 * wid, s, lane);
             gf[s] = frag_rows<HD>(gimg, 16 * wid, s, lane);
         }
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dl += (float)gf[s][e] * (float)of[s][e];      // (columns beyond hd are zero in the image)
+        dl = group_sum(dl);
+        if (g == 0) delta_out[(int64_t)bh * 64 + qi] = dl;
         f32x4 ds[4];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) acc[dt] = f32x4{0, 0, 0, 0};
